@@ -1,0 +1,162 @@
+/*
+ * redsec_hip.h -- C ABI of the MI355X gate-bootstrapping backend (libredsec_hip.so).
+ *
+ * This is the drop-in boundary for REDsec's encrypted hot path. Each entry point replaces a call
+ * that the reference makes into the external TFHE library (paths relative to /root/reference):
+ *
+ *   rs_bootstrap / rs_bootstrap_dev     tfhe_bootstrap_FFT             lib/BinOps_enc.cpp:185,191
+ *                                       (Quantize::execute loops       lib/BinFunc.cpp:1056-1071,
+ *                                                                       lib/IntFunc.cpp:871-887)
+ *   rs_gate / rs_gate_dev               bootsAND/OR/XOR/...            lib/BinOps_enc.cpp:49-52,104-113,
+ *                                                                       153-166,205; lib/IntOps_enc.cpp:63
+ *   rs_mux / rs_mux_dev                 bootsMUX                       lib/IntFunc.cpp:962
+ *   rs_lincomb_dev, rs_linear_*         lweAddTo/lweSubTo/lweAddMulTo/ lib/BinFunc.cpp:195-320,
+ *                                       lweNoiselessTrivial loops      lib/IntFunc.cpp:207-308,643-700
+ *   rs_create / rs_load_keys            new_tfheGateBootstrappingCloudKeySet_fromFile + the
+ *                                       bkFFT precomputation           nets/mnist/sign1024x1/net.cpp:53-55
+ *
+ * Plain pointers and sizes only. "_dev" entry points take DEVICE pointers (hipMalloc / torch CUDA
+ * tensors) and enqueue on the given hipStream_t (passed as void*; NULL = default stream) without
+ * synchronising; the others take HOST pointers and are synchronous.
+ *
+ * Ciphertext layout: an LWE sample of dimension n is W = n+1 consecutive int32 words
+ * (a[0..n-1], b); a batch is int32[B][W], row-major, contiguous. Torus32 arithmetic wraps mod 2^32.
+ *
+ * Errors: every function returns 0 on success or a negative rs_status; rs_last_error() gives the
+ * message for the calling thread. There is NO CPU fallback: without a HIP device every compute
+ * entry point fails with RS_ERR_NO_DEVICE.
+ */
+#ifndef REDSEC_HIP_H
+#define REDSEC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rs_status {
+  RS_OK = 0,
+  RS_ERR_INVALID = -1,     /* bad argument / unsupported parameter set */
+  RS_ERR_NO_DEVICE = -2,   /* no HIP device or device is not gfx950-compatible */
+  RS_ERR_HIP = -3,         /* a HIP runtime call failed */
+  RS_ERR_STATE = -4        /* keys not loaded, etc. */
+} rs_status;
+
+/* Mirrors TFheGateBootstrappingParameterSet (ks_t, ks_basebit, in_out_params->n, tgsw_params->l,
+ * Bgbit, tlwe_params->N, k) as constructed at client/gen_secure_keyset.cpp:82-90. */
+typedef struct rs_params {
+  int32_t n;          /* LWE dimension */
+  int32_t N;          /* ring degree; this backend supports N = 1024 */
+  int32_t k;          /* must be 1 */
+  int32_t bk_l;       /* gadget length: 3 (with bk_Bgbit 7) or 10 (with bk_Bgbit 3) */
+  int32_t bk_Bgbit;
+  int32_t ks_t;
+  int32_t ks_basebit;
+} rs_params;
+
+typedef struct rs_ctx rs_ctx;
+
+typedef enum rs_gate_op {
+  RS_NAND = 0, RS_OR = 1, RS_AND = 2, RS_NOR = 3, RS_XOR = 4, RS_XNOR = 5,
+  RS_ANDNY = 6, RS_ANDYN = 7, RS_ORNY = 8, RS_ORYN = 9
+} rs_gate_op;
+
+const char* rs_last_error(void);
+const char* rs_version(void);
+
+/* Parameter sets shipped with the reference / TFHE. */
+int rs_params_default128(rs_params* p);        /* TFHE default 128-bit set (NAND microbench) */
+int rs_params_redsec_small_v2(rs_params* p);   /* client/gen_secure_keyset.cpp:70-91 */
+
+/* Context bound to one HIP device (device index as in hipSetDevice). */
+int rs_create(rs_ctx** out, const rs_params* p, int device);
+int rs_destroy(rs_ctx* ctx);
+
+/* Upload the evaluation key (HOST pointers):
+ *   bk  int32[n][(k+1)*l][k+1][N]   TGSW rows, row p = c*l + j (bk->bk[i].all_sample[p].a[col])
+ *   ksk int32[k*N][t][1<<basebit][n+1]   bk->ks->ks[i][j][v] as (a[0..n-1], b)
+ * Transforms bk to the transform domain on the device (the bkFFT analogue). */
+int rs_load_keys(rs_ctx* ctx, const int32_t* bk, const int32_t* ksk);
+
+/* Workspace is grown on demand; this pre-sizes it for batches of up to max_batch ciphertexts. */
+int rs_reserve(rs_ctx* ctx, size_t max_batch);
+
+/* out[b] = tfhe_bootstrap_FFT(mu, in[b]) for b < B. */
+int rs_bootstrap_dev(rs_ctx* ctx, int32_t* out, const int32_t* in, int32_t mu, size_t B, void* stream);
+int rs_bootstrap(rs_ctx* ctx, int32_t* out, const int32_t* in, int32_t mu, size_t B);
+
+/* out[b] = boots<OP>(a[b], b[b]) (mu = 1/8 encoding). */
+int rs_gate_dev(rs_ctx* ctx, rs_gate_op op, int32_t* out, const int32_t* a, const int32_t* b, size_t B, void* stream);
+int rs_gate(rs_ctx* ctx, rs_gate_op op, int32_t* out, const int32_t* a, const int32_t* b, size_t B);
+
+/* out[i] = bootsMUX(a[i], b[i], c[i]) = a ? b : c. */
+int rs_mux_dev(rs_ctx* ctx, int32_t* out, const int32_t* a, const int32_t* b, const int32_t* c, size_t B, void* stream);
+int rs_mux(rs_ctx* ctx, int32_t* out, const int32_t* a, const int32_t* b, const int32_t* c, size_t B);
+
+/* Pieces of the bootstrap, exposed for parity tests and for callers that fuse differently:
+ *   blind rotate + sample extract (tfhe_bootstrap_woKS_FFT): in int32[B][n+1] -> u int32[B][k*N+1]
+ *   keyswitch (lweKeySwitch):                                 u int32[B][k*N+1] -> out int32[B][n+1] */
+int rs_bootstrap_wo_ks_dev(rs_ctx* ctx, int32_t* u, const int32_t* in, int32_t mu, size_t B, void* stream);
+int rs_keyswitch_dev(rs_ctx* ctx, int32_t* out, const int32_t* u, size_t B, void* stream);
+
+/* Debug/parity tap: negacyclic product of a small-coefficient polynomial with a torus polynomial
+ * through exactly the device transform path used by the external product (HOST pointers). */
+int rs_debug_polymul(rs_ctx* ctx, int32_t* out, const int32_t* a_small, const int32_t* b_torus, size_t count);
+
+/* ---- linear stage on LWE words (no bootstrap), DEVICE pointers ---------------------------------
+ * out[m] = bias_b[m % bias_depth] (on the b word, optional) + zero_tap_b * (#zero taps of m)
+ *          + sum_k s(k,m) * in[k]
+ * with s = +1 where sign[k*M+m] == 1, -1 where 0, and the tap replaced by the constant where
+ * zero[k*M+m] == 1 (zero may be NULL). Fully-connected form of Convolution::execute
+ * (lib/BinFunc.cpp:217-320: zero_tap_b = 0; lib/IntFunc.cpp:227-308: zero_tap_b = -1/4096). */
+int rs_linear_fc_dev(rs_ctx* ctx, int32_t* out, const int32_t* in, const uint8_t* sign, const uint8_t* zero,
+                     int32_t K, int32_t M, int32_t zero_tap_b, const int32_t* bias_b, int32_t bias_depth,
+                     void* stream);
+
+/* General 2-D convolution over ciphertext feature maps (NHWC), same semantics as above per tap;
+ * out-of-bounds taps under same-padding contribute pad_tap_b on the b word.
+ * in  int32[H][Wd][Cin][W], out int32[Ho][Wo][Cout][W], sign/zero uint8[fh][fw][Cin][Cout]
+ * (get_filter_i, lib/BinFunc.cpp:388). */
+typedef struct rs_conv_shape {
+  int32_t H, Wd, Cin, Cout, fh, fw, stride_h, stride_w, off_h, off_w, Ho, Wo;
+} rs_conv_shape;
+int rs_conv_ternary_dev(rs_ctx* ctx, int32_t* out, const int32_t* in, const uint8_t* sign, const uint8_t* zero,
+                        const rs_conv_shape* shape, int32_t zero_tap_b, int32_t pad_tap_b,
+                        const int32_t* bias_b, int32_t bias_depth, void* stream);
+
+/* Windowed LWE sum (SumPooling::execute, lib/BinFunc.cpp:677-732, lib/IntFunc.cpp:643-700):
+ * in int32[H][Wd][C][W] -> out int32[Ho][Wo][C][W]; taps outside the image are skipped. */
+typedef struct rs_pool_shape {
+  int32_t H, Wd, C, win_h, win_w, stride_h, stride_w, off_h, off_w, Ho, Wo;
+} rs_pool_shape;
+int rs_sumpool_dev(rs_ctx* ctx, int32_t* out, const int32_t* in, const rs_pool_shape* shape,
+                   const int32_t* bias_b, int32_t bias_depth, void* stream);
+
+/* out[i] = ca * a[i] + cb * b[i] word-wise, plus bconst on the b word (b may be NULL).
+ * lweAddTo / lweSubTo / lweAddMulTo / lweNoiselessTrivial compositions (lib/BinOps_enc.cpp:37-41,
+ * 121-143; lib/IntOps_enc.cpp:35-56). */
+int rs_lincomb_dev(rs_ctx* ctx, int32_t* out, const int32_t* a, int32_t ca, const int32_t* b, int32_t cb,
+                   int32_t bconst, size_t B, void* stream);
+
+/* Device memory helpers for hosts that do not link HIP themselves (the C++ layer mirror). */
+int rs_dev_alloc(rs_ctx* ctx, void** ptr, size_t bytes);
+int rs_dev_free(rs_ctx* ctx, void* ptr);
+int rs_copy_to_dev(rs_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int rs_copy_to_host(rs_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int rs_sync(rs_ctx* ctx);
+
+/* Time (ms) of the kernels enqueued by the last *_dev / host call, by HIP events on the stream the
+ * kernels ran on; -1 if not available. Index: 0 blind-rotate, 1 keyswitch. */
+int rs_set_timing(rs_ctx* ctx, int enable);
+int rs_last_kernel_ms(rs_ctx* ctx, float* blind_rotate_ms, float* keyswitch_ms);
+
+/* Static facts used by bench.py's roofline accounting. */
+int rs_info(rs_ctx* ctx, int64_t* bk_device_bytes, int64_t* ksk_device_bytes, int32_t* waves_per_block,
+            int32_t* num_cus);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,302 @@
+"""ctypes binding of libredsec_hip.so (the C ABI in include/redsec_hip.h).
+
+PyTorch is used only as plumbing: device buffers are int32 CUDA (HIP) tensors and launches go on
+torch's current stream. All arithmetic happens in the HIP kernels; there is no CPU or eager
+fallback -- if the library or a gfx950 device is missing, calls raise RedsecHipError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_i32p = C.POINTER(C.c_int32)
+_u8p = C.POINTER(C.c_uint8)
+
+# every symbol include/redsec_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "rs_last_error", "rs_version", "rs_params_default128", "rs_params_redsec_small_v2", "rs_create", "rs_destroy",
+    "rs_load_keys", "rs_reserve", "rs_bootstrap_dev", "rs_bootstrap", "rs_gate_dev", "rs_gate", "rs_mux_dev", "rs_mux",
+    "rs_bootstrap_wo_ks_dev", "rs_keyswitch_dev", "rs_debug_polymul", "rs_linear_fc_dev", "rs_conv_ternary_dev",
+    "rs_sumpool_dev", "rs_lincomb_dev", "rs_dev_alloc", "rs_dev_free", "rs_copy_to_dev", "rs_copy_to_host", "rs_sync",
+    "rs_set_timing", "rs_last_kernel_ms", "rs_info",
+]
+
+GATES = {"NAND": 0, "OR": 1, "AND": 2, "NOR": 3, "XOR": 4, "XNOR": 5, "ANDNY": 6, "ANDYN": 7, "ORNY": 8, "ORYN": 9}
+
+
+class RedsecHipError(RuntimeError):
+    pass
+
+
+class RsParams(C.Structure):
+    _fields_ = [("n", C.c_int32), ("N", C.c_int32), ("k", C.c_int32), ("bk_l", C.c_int32), ("bk_Bgbit", C.c_int32),
+                ("ks_t", C.c_int32), ("ks_basebit", C.c_int32)]
+
+
+class RsConvShape(C.Structure):
+    _fields_ = [(f, C.c_int32) for f in
+                ("H", "Wd", "Cin", "Cout", "fh", "fw", "stride_h", "stride_w", "off_h", "off_w", "Ho", "Wo")]
+
+
+class RsPoolShape(C.Structure):
+    _fields_ = [(f, C.c_int32) for f in
+                ("H", "Wd", "C", "win_h", "win_w", "stride_h", "stride_w", "off_h", "off_w", "Ho", "Wo")]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libredsec_hip.so (building it in-tree first if the sources are newer)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    so = path or _build.build_hip()
+    if not os.path.exists(so):
+        raise RedsecHipError("libredsec_hip.so is missing: run `python -m redsec_amd.build`")
+    try:
+        L = C.CDLL(so)
+    except OSError as e:  # pragma: no cover
+        raise RedsecHipError("cannot load %s: %s" % (so, e))
+    L.rs_last_error.restype = C.c_char_p
+    L.rs_version.restype = C.c_char_p
+    P = C.POINTER(RsParams)
+    vp = C.c_void_p
+    L.rs_params_default128.argtypes = [P]
+    L.rs_params_redsec_small_v2.argtypes = [P]
+    L.rs_create.argtypes = [C.POINTER(vp), P, C.c_int]
+    L.rs_destroy.argtypes = [vp]
+    L.rs_load_keys.argtypes = [vp, _i32p, _i32p]
+    L.rs_reserve.argtypes = [vp, C.c_size_t]
+    L.rs_bootstrap_dev.argtypes = [vp, vp, vp, C.c_int32, C.c_size_t, vp]
+    L.rs_bootstrap.argtypes = [vp, _i32p, _i32p, C.c_int32, C.c_size_t]
+    L.rs_gate_dev.argtypes = [vp, C.c_int, vp, vp, vp, C.c_size_t, vp]
+    L.rs_gate.argtypes = [vp, C.c_int, _i32p, _i32p, _i32p, C.c_size_t]
+    L.rs_mux_dev.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, vp]
+    L.rs_mux.argtypes = [vp, _i32p, _i32p, _i32p, _i32p, C.c_size_t]
+    L.rs_bootstrap_wo_ks_dev.argtypes = [vp, vp, vp, C.c_int32, C.c_size_t, vp]
+    L.rs_keyswitch_dev.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    L.rs_debug_polymul.argtypes = [vp, _i32p, _i32p, _i32p, C.c_size_t]
+    L.rs_linear_fc_dev.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, vp]
+    L.rs_conv_ternary_dev.argtypes = [vp, vp, vp, vp, vp, C.POINTER(RsConvShape), C.c_int32, C.c_int32, vp, C.c_int32, vp]
+    L.rs_sumpool_dev.argtypes = [vp, vp, vp, C.POINTER(RsPoolShape), vp, C.c_int32, vp]
+    L.rs_lincomb_dev.argtypes = [vp, vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, C.c_size_t, vp]
+    L.rs_dev_alloc.argtypes = [vp, C.POINTER(vp), C.c_size_t]
+    L.rs_dev_free.argtypes = [vp, vp]
+    L.rs_copy_to_dev.argtypes = [vp, vp, vp, C.c_size_t]
+    L.rs_copy_to_host.argtypes = [vp, vp, vp, C.c_size_t]
+    L.rs_sync.argtypes = [vp]
+    L.rs_set_timing.argtypes = [vp, C.c_int]
+    L.rs_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.rs_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    if path is None:
+        _lib = L
+    return L
+
+
+def _check(L, rc):
+    if rc != 0:
+        raise RedsecHipError("redsec_hip error %d: %s" % (rc, (L.rs_last_error() or b"").decode()))
+
+
+def params(name, n=None):
+    """'default128' | 'redsec_small_v2'; `n` overrides the LWE dimension (reduced-size test keys)."""
+    L = load_library()
+    p = RsParams()
+    if name == "default128":
+        _check(L, L.rs_params_default128(C.byref(p)))
+    elif name == "redsec_small_v2":
+        _check(L, L.rs_params_redsec_small_v2(C.byref(p)))
+    else:
+        raise KeyError(name)
+    if n is not None:
+        p.n = int(n)
+    return p
+
+
+def _np_i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_i32p)
+
+
+class Backend:
+    """One context = one GPU + one evaluation key (mirrors TFheGateBootstrappingCloudKeySet usage,
+    /root/reference/lib/BinOps_enc.cpp: every primitive takes `bk` as its last argument)."""
+
+    def __init__(self, p, device=0):
+        self.L = load_library()
+        self.p = p
+        self.W = p.n + 1
+        self.device = device
+        h = C.c_void_p()
+        _check(self.L, self.L.rs_create(C.byref(h), C.byref(p), device))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- keys ----
+    def load_keys(self, bk, ksk):
+        bk, pbk = _np_i32(bk)
+        ksk, pksk = _np_i32(ksk)
+        p = self.p
+        assert bk.size == p.n * 2 * p.bk_l * 2 * p.N, "bk has the wrong size"
+        assert ksk.size == p.N * p.ks_t * (1 << p.ks_basebit) * (p.n + 1), "ksk has the wrong size"
+        _check(self.L, self.L.rs_load_keys(self.h, pbk, pksk))
+
+    def reserve(self, max_batch):
+        _check(self.L, self.L.rs_reserve(self.h, int(max_batch)))
+
+    # ---- torch plumbing ----
+    @staticmethod
+    def _stream():
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _ck_dev(self, t, cols=None):
+        import torch
+        assert t.is_cuda and t.dtype == torch.int32 and t.is_contiguous(), "need contiguous int32 CUDA tensors"
+        assert t.device.index == self.device, "tensor is on another device than the context"
+        if cols is not None:
+            assert t.shape[-1] == cols, "last dimension must be %d words" % cols
+        return C.c_void_p(t.data_ptr())
+
+    def empty(self, *shape):
+        import torch
+        return torch.empty(*shape, dtype=torch.int32, device="cuda:%d" % self.device)
+
+    # ---- bootstraps on device tensors [B][W] ----
+    def bootstrap(self, x, mu, out=None):
+        B = x.shape[0]
+        out = self.empty(B, self.W) if out is None else out
+        _check(self.L, self.L.rs_bootstrap_dev(self.h, self._ck_dev(out, self.W), self._ck_dev(x, self.W), int(mu), B, self._stream()))
+        return out
+
+    def gate(self, op, a, b, out=None):
+        B = a.shape[0]
+        out = self.empty(B, self.W) if out is None else out
+        _check(self.L, self.L.rs_gate_dev(self.h, GATES[op], self._ck_dev(out, self.W), self._ck_dev(a, self.W),
+                                           self._ck_dev(b, self.W), B, self._stream()))
+        return out
+
+    def mux(self, a, b, c, out=None):
+        B = a.shape[0]
+        out = self.empty(B, self.W) if out is None else out
+        _check(self.L, self.L.rs_mux_dev(self.h, self._ck_dev(out, self.W), self._ck_dev(a, self.W), self._ck_dev(b, self.W),
+                                          self._ck_dev(c, self.W), B, self._stream()))
+        return out
+
+    def bootstrap_wo_ks(self, x, mu):
+        B = x.shape[0]
+        u = self.empty(B, self.p.N + 1)
+        _check(self.L, self.L.rs_bootstrap_wo_ks_dev(self.h, self._ck_dev(u), self._ck_dev(x, self.W), int(mu), B, self._stream()))
+        return u
+
+    def keyswitch(self, u):
+        B = u.shape[0]
+        out = self.empty(B, self.W)
+        _check(self.L, self.L.rs_keyswitch_dev(self.h, self._ck_dev(out), self._ck_dev(u, self.p.N + 1), B, self._stream()))
+        return out
+
+    # ---- linear stage ----
+    def lincomb(self, a, ca, b=None, cb=0, bconst=0):
+        B = a.numel() // self.W
+        out = self.empty(*a.shape)
+        pb = self._ck_dev(b, self.W) if b is not None else None
+        _check(self.L, self.L.rs_lincomb_dev(self.h, self._ck_dev(out), self._ck_dev(a, self.W), int(ca), pb, int(cb),
+                                              int(bconst), B, self._stream()))
+        return out
+
+    def _u8(self, t):
+        import torch
+        if t is None:
+            return None
+        assert t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()
+        return C.c_void_p(t.data_ptr())
+
+    def linear_fc(self, x, sign, zero=None, zero_tap_b=0, bias_b=None):
+        """x [K][W]; sign/zero uint8 [K][M] -> [M][W]."""
+        K = x.shape[0]
+        M = sign.shape[1]
+        out = self.empty(M, self.W)
+        pbias = self._ck_dev(bias_b) if bias_b is not None else None
+        depth = int(bias_b.numel()) if bias_b is not None else 0
+        _check(self.L, self.L.rs_linear_fc_dev(self.h, self._ck_dev(out), self._ck_dev(x, self.W), self._u8(sign), self._u8(zero),
+                                                K, M, int(zero_tap_b), pbias, depth, self._stream()))
+        return out
+
+    def conv_ternary(self, x, sign, zero, shape, zero_tap_b=0, pad_tap_b=0, bias_b=None):
+        """x [H][Wd][Cin][W] -> [Ho][Wo][Cout][W]; shape: dict of rs_conv_shape fields."""
+        s = RsConvShape(**shape)
+        out = self.empty(s.Ho, s.Wo, s.Cout, self.W)
+        pbias = self._ck_dev(bias_b) if bias_b is not None else None
+        depth = int(bias_b.numel()) if bias_b is not None else 0
+        _check(self.L, self.L.rs_conv_ternary_dev(self.h, self._ck_dev(out), self._ck_dev(x, self.W), self._u8(sign),
+                                                   self._u8(zero), C.byref(s), int(zero_tap_b), int(pad_tap_b), pbias, depth,
+                                                   self._stream()))
+        return out
+
+    def sumpool(self, x, shape, bias_b=None):
+        s = RsPoolShape(**shape)
+        out = self.empty(s.Ho, s.Wo, s.C, self.W)
+        pbias = self._ck_dev(bias_b) if bias_b is not None else None
+        depth = int(bias_b.numel()) if bias_b is not None else 0
+        _check(self.L, self.L.rs_sumpool_dev(self.h, self._ck_dev(out), self._ck_dev(x, self.W), C.byref(s), pbias, depth,
+                                              self._stream()))
+        return out
+
+    # ---- host (numpy) conveniences: synchronous H2D -> kernels -> D2H inside the library ----
+    def bootstrap_host(self, x, mu):
+        x, px = _np_i32(x)
+        out = np.empty_like(x)
+        _check(self.L, self.L.rs_bootstrap(self.h, out.ctypes.data_as(_i32p), px, int(mu), x.shape[0]))
+        return out
+
+    def gate_host(self, op, a, b):
+        a, pa = _np_i32(a)
+        b, pb = _np_i32(b)
+        out = np.empty_like(a)
+        _check(self.L, self.L.rs_gate(self.h, GATES[op], out.ctypes.data_as(_i32p), pa, pb, a.shape[0]))
+        return out
+
+    def mux_host(self, a, b, c):
+        a, pa = _np_i32(a)
+        b, pb = _np_i32(b)
+        c, pc = _np_i32(c)
+        out = np.empty_like(a)
+        _check(self.L, self.L.rs_mux(self.h, out.ctypes.data_as(_i32p), pa, pb, pc, a.shape[0]))
+        return out
+
+    def polymul_host(self, a_small, b_torus):
+        a, pa = _np_i32(a_small)
+        b, pb = _np_i32(b_torus)
+        out = np.empty_like(b)
+        _check(self.L, self.L.rs_debug_polymul(self.h, out.ctypes.data_as(_i32p), pa, pb, a.size // self.p.N))
+        return out
+
+    # ---- timing / facts ----
+    def set_timing(self, on=True):
+        _check(self.L, self.L.rs_set_timing(self.h, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        a, b = C.c_float(), C.c_float()
+        _check(self.L, self.L.rs_last_kernel_ms(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def info(self):
+        bk, ksk, wpb, cus = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
+        _check(self.L, self.L.rs_info(self.h, C.byref(bk), C.byref(ksk), C.byref(wpb), C.byref(cus)))
+        return {"bk_device_bytes": bk.value, "ksk_device_bytes": ksk.value, "waves_per_block": wpb.value, "num_cus": cus.value}
+
+    def sync(self):
+        _check(self.L, self.L.rs_sync(self.h))

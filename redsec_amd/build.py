@@ -1,0 +1,81 @@
+"""In-tree build of the native libraries.
+
+  libredsec_hip.so   the product: HIP kernels + C ABI (include/redsec_hip.h), gfx950 only
+  librs_emulate.so   test-only host emulation of one wavefront (csrc/rs_emulate.cpp)
+
+hipcc cross-compiles for gfx950 without a GPU, so `build()` works in the CPU-only container. The
+built .so files stay in-tree (git-ignored) so that they travel to the GPU box with the snapshot.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+
+HIP_LIB = os.path.join(HERE, "libredsec_hip.so")
+EMU_LIB = os.path.join(HERE, "librs_emulate.so")
+
+HIP_SOURCES = ["rs_kernels.hip", "rs_api.cpp"]
+HIP_DEPS = HIP_SOURCES + ["rs_kernels.h", "rs_ntt.h", "rs_host.h", os.path.join(INCLUDE, "redsec_hip.h")]
+EMU_SOURCES = ["rs_emulate.cpp"]
+EMU_DEPS = EMU_SOURCES + ["rs_ntt.h", "rs_host.h"]
+
+
+def _abs(paths):
+    return [p if os.path.isabs(p) else os.path.join(CSRC, p) for p in paths]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in _abs(deps) + [os.path.abspath(__file__)])
+
+
+def find_hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def build_hip(force=False, verbose=False):
+    if not force and not _stale(HIP_LIB, HIP_DEPS):
+        return HIP_LIB
+    hipcc = find_hipcc()
+    if hipcc is None:
+        if os.path.exists(HIP_LIB):
+            return HIP_LIB  # prebuilt library shipped with the snapshot
+        raise RuntimeError("hipcc not found and no prebuilt libredsec_hip.so present")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           "-I" + INCLUDE, "-I" + CSRC] + _abs(HIP_SOURCES) + ["-o", HIP_LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return HIP_LIB
+
+
+def build_emulator(force=False, verbose=False):
+    if not force and not _stale(EMU_LIB, EMU_DEPS):
+        return EMU_LIB
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        raise RuntimeError("no host C++ compiler for the emulator")
+    cmd = [cxx, "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", "-msse4.1", "-fPIC", "-shared",
+           "-Wno-unknown-pragmas", "-I" + CSRC] + _abs(EMU_SOURCES) + ["-o", EMU_LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return EMU_LIB
+
+
+def build_all(force=False, verbose=False):
+    return build_hip(force, verbose), build_emulator(force, verbose)
+
+
+if __name__ == "__main__":
+    import sys
+    print(build_all(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,491 @@
+// rs_api.cpp -- C ABI of libredsec_hip.so (declared in include/redsec_hip.h).
+//
+// Host-side control only: context, key upload + transform, workspace, launches. No arithmetic on
+// ciphertexts happens on the CPU here, and there is no fallback path: without a HIP device every
+// compute entry point returns RS_ERR_NO_DEVICE.
+#include "redsec_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "rs_host.h"
+#include "rs_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define RS_HIP(call)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess) return fail(RS_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+}  // namespace
+
+struct rs_ctx {
+  rs_params p{};
+  int device = 0;
+  int cfg = 0;  // 0 default128-shaped gadget, 1 redsec_v2-shaped gadget
+  rs::Tables tables;
+  double* d_tw = nullptr;
+  double* d_bk_ntt = nullptr;
+  int32_t* d_ksk = nullptr;
+  size_t bk_bytes = 0, ksk_bytes = 0;
+  bool keys = false;
+  int32_t* d_u0 = nullptr;
+  int32_t* d_u1 = nullptr;
+  size_t ws_batch = 0;
+  int32_t* d_io[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t io_batch = 0;
+  int num_cus = 256;
+  bool timing = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool ev_valid = false;
+};
+
+namespace {
+
+struct GateCoef { int32_t bconst, sa, sb; };
+
+// TFHE boolean-gates.cpp constants; mirrored at /root/reference/lib/GPU/gates.cu:246-286.
+bool gate_coef(rs_gate_op op, GateCoef* g) {
+  const int32_t e8 = 1 << 29, e4 = 1 << 30;  // modSwitchToTorus32(1,8), (1,4)
+  switch (op) {
+    case RS_NAND:  *g = {e8, -1, -1}; return true;
+    case RS_OR:    *g = {e8, 1, 1}; return true;
+    case RS_AND:   *g = {-e8, 1, 1}; return true;
+    case RS_NOR:   *g = {-e8, -1, -1}; return true;
+    case RS_XOR:   *g = {e4, 2, 2}; return true;
+    case RS_XNOR:  *g = {-e4, -2, -2}; return true;
+    case RS_ANDNY: *g = {-e8, -1, 1}; return true;
+    case RS_ANDYN: *g = {-e8, 1, -1}; return true;
+    case RS_ORNY:  *g = {e8, -1, 1}; return true;
+    case RS_ORYN:  *g = {e8, 1, -1}; return true;
+  }
+  return false;
+}
+
+int use_device(rs_ctx* c) {
+  if (!c) return fail(RS_ERR_INVALID, "null context");
+  RS_HIP(hipSetDevice(c->device));
+  return RS_OK;
+}
+
+int ensure_ws(rs_ctx* c, size_t B) {
+  if (B <= c->ws_batch) return RS_OK;
+  if (c->d_u0) { (void)hipFree(c->d_u0); c->d_u0 = nullptr; }
+  if (c->d_u1) { (void)hipFree(c->d_u1); c->d_u1 = nullptr; }
+  c->ws_batch = 0;
+  const size_t bytes = B * (size_t)(rs::kN + 1) * sizeof(int32_t);
+  RS_HIP(hipMalloc(&c->d_u0, bytes));
+  RS_HIP(hipMalloc(&c->d_u1, bytes));
+  c->ws_batch = B;
+  return RS_OK;
+}
+
+int ensure_io(rs_ctx* c, size_t B) {
+  if (B <= c->io_batch) return RS_OK;
+  for (auto& p : c->d_io) { if (p) { (void)hipFree(p); p = nullptr; } }
+  c->io_batch = 0;
+  const size_t bytes = B * (size_t)(c->p.n + 1) * sizeof(int32_t);
+  for (auto& p : c->d_io) RS_HIP(hipMalloc(&p, bytes));
+  c->io_batch = B;
+  return RS_OK;
+}
+
+int pick_wpb(const rs_ctx* c, size_t B) {
+  const size_t cus = (size_t)c->num_cus;
+  if (B >= 8 * cus) return 8;
+  if (B >= 4 * cus) return 4;
+  if (B >= 2 * cus) return 2;
+  return 1;
+}
+
+int ready(rs_ctx* c) {
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (!c->keys) return fail(RS_ERR_STATE, "rs_load_keys has not been called");
+  return RS_OK;
+}
+
+rs::BlindRotateArgs br_args(rs_ctx* c, const int32_t* in0, const int32_t* in1, int32_t c0, int32_t c1, int32_t bconst, int32_t mu,
+                            size_t B, int32_t* u) {
+  rs::BlindRotateArgs a;
+  a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.bconst = bconst; a.mu = mu;
+  a.bk_ntt = c->d_bk_ntt; a.tw = c->d_tw; a.f = c->tables.f;
+  a.n = c->p.n; a.W = c->p.n + 1; a.B = (long)B; a.u_out = u;
+  return a;
+}
+
+rs::KeyswitchArgs ks_args(rs_ctx* c, const int32_t* u0, const int32_t* u1, int32_t bconst, size_t B, int32_t* out) {
+  rs::KeyswitchArgs a;
+  a.u0 = u0; a.u1 = u1; a.bconst = bconst; a.ksk = c->d_ksk;
+  a.W = c->p.n + 1; a.t = c->p.ks_t; a.basebit = c->p.ks_basebit; a.B = (long)B; a.out = out;
+  return a;
+}
+
+// blind rotate(s) then keyswitch, with optional event timing on the launch stream
+int run_bootstrap(rs_ctx* c, int32_t* out, const int32_t* in0, const int32_t* in1, int32_t c0, int32_t c1, int32_t bconst,
+                  int32_t mu, size_t B, hipStream_t st) {
+  int rc = ensure_ws(c, B);
+  if (rc) return rc;
+  const int wpb = pick_wpb(c, B);
+  if (c->timing) RS_HIP(hipEventRecord(c->ev[0], st));
+  RS_HIP(rs::launch_blind_rotate(c->cfg, br_args(c, in0, in1, c0, c1, bconst, mu, B, c->d_u0), wpb, st));
+  if (c->timing) RS_HIP(hipEventRecord(c->ev[1], st));
+  RS_HIP(rs::launch_keyswitch(ks_args(c, c->d_u0, nullptr, 0, B, out), st));
+  if (c->timing) { RS_HIP(hipEventRecord(c->ev[2], st)); c->ev_valid = true; }
+  return RS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rs_last_error(void) { return g_err.c_str(); }
+const char* rs_version(void) { return "redsec_hip 0.1 (gfx950, fp64-ntt)"; }
+
+int rs_params_default128(rs_params* p) {
+  if (!p) return fail(RS_ERR_INVALID, "null params");
+  *p = {630, 1024, 1, 3, 7, 8, 2};
+  return RS_OK;
+}
+int rs_params_redsec_small_v2(rs_params* p) {
+  if (!p) return fail(RS_ERR_INVALID, "null params");
+  *p = {350, 1024, 1, 10, 3, 9, 3};
+  return RS_OK;
+}
+
+int rs_create(rs_ctx** out, const rs_params* p, int device) {
+  if (!out || !p) return fail(RS_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (p->N != rs::kN || p->k != 1) return fail(RS_ERR_INVALID, "unsupported ring: N=%d k=%d (need N=1024, k=1)", p->N, p->k);
+  if (p->n < 1 || p->n + 1 > 1024) return fail(RS_ERR_INVALID, "unsupported LWE dimension n=%d", p->n);
+  if (p->ks_t < 1 || p->ks_basebit < 1 || p->ks_t * p->ks_basebit > 31) return fail(RS_ERR_INVALID, "bad keyswitch parameters");
+  rs::PrimeSpec ps;
+  if (!rs::prime_for(p->bk_l, p->bk_Bgbit, &ps))
+    return fail(RS_ERR_INVALID, "unsupported gadget l=%d Bgbit=%d (supported: 3/7, 10/3)", p->bk_l, p->bk_Bgbit);
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(RS_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= count) return fail(RS_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, count);
+  rs_ctx* c = new (std::nothrow) rs_ctx();
+  if (!c) return fail(RS_ERR_INVALID, "out of host memory");
+  c->p = *p;
+  c->device = device;
+  c->cfg = (p->bk_l == 3) ? 0 : 1;
+  c->tables = rs::make_tables(ps);
+  const unsigned fwd_mask = c->cfg == 0 ? rs::CfgDefault128::FWD_MASK : rs::CfgRedsecV2::FWD_MASK;
+  const unsigned inv_mask = c->cfg == 0 ? rs::CfgDefault128::INV_MASK : rs::CfgRedsecV2::INV_MASK;
+  const std::string why = rs::validate_schedule(c->tables.f.p, p->bk_l, p->bk_Bgbit, fwd_mask, inv_mask);
+  if (!why.empty()) { delete c; return fail(RS_ERR_INVALID, "transform schedule not exact: %s", why.c_str()); }
+  if (hipSetDevice(device) != hipSuccess) { delete c; return fail(RS_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device); }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+    c->num_cus = prop.multiProcessorCount;
+    if (!strstr(prop.gcnArchName, "gfx950")) {
+      delete c;
+      return fail(RS_ERR_NO_DEVICE, "device %d is %s; this library ships gfx950 code only", device, prop.gcnArchName);
+    }
+  }
+  if (hipMalloc(&c->d_tw, sizeof(double) * 2 * rs::kN) != hipSuccess ||
+      hipMemcpy(c->d_tw, c->tables.tw.data(), sizeof(double) * 2 * rs::kN, hipMemcpyHostToDevice) != hipSuccess) {
+    delete c;
+    return fail(RS_ERR_HIP, "twiddle table upload failed");
+  }
+  for (auto& e : c->ev) (void)hipEventCreate(&e);
+  *out = c;
+  return RS_OK;
+}
+
+int rs_destroy(rs_ctx* c) {
+  if (!c) return RS_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  (void)hipFree(c->d_tw); (void)hipFree(c->d_bk_ntt); (void)hipFree(c->d_ksk);
+  (void)hipFree(c->d_u0); (void)hipFree(c->d_u1);
+  for (auto& p : c->d_io) (void)hipFree(p);
+  for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  delete c;
+  return RS_OK;
+}
+
+int rs_load_keys(rs_ctx* c, const int32_t* bk, const int32_t* ksk) {
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (!bk || !ksk) return fail(RS_ERR_INVALID, "null key pointer");
+  const rs_params& p = c->p;
+  const size_t n_polys = (size_t)p.n * (size_t)(2 * p.bk_l) * 2;
+  const size_t bk_words = n_polys * rs::kN;
+  const size_t ksk_words = (size_t)rs::kN * p.ks_t * ((size_t)1 << p.ks_basebit) * (size_t)(p.n + 1);
+  if (c->d_bk_ntt) { (void)hipFree(c->d_bk_ntt); c->d_bk_ntt = nullptr; }
+  if (c->d_ksk) { (void)hipFree(c->d_ksk); c->d_ksk = nullptr; }
+  c->keys = false;
+  int32_t* d_bk = nullptr;
+  RS_HIP(hipMalloc(&d_bk, bk_words * sizeof(int32_t)));
+  RS_HIP(hipMemcpy(d_bk, bk, bk_words * sizeof(int32_t), hipMemcpyHostToDevice));
+  RS_HIP(hipMalloc(&c->d_bk_ntt, bk_words * sizeof(double)));
+  RS_HIP(rs::launch_bk_transform(c->cfg, d_bk, c->d_bk_ntt, c->d_tw, c->tables.f, c->tables.ninv, (long)n_polys, nullptr));
+  RS_HIP(hipDeviceSynchronize());
+  RS_HIP(hipFree(d_bk));
+  RS_HIP(hipMalloc(&c->d_ksk, ksk_words * sizeof(int32_t)));
+  RS_HIP(hipMemcpy(c->d_ksk, ksk, ksk_words * sizeof(int32_t), hipMemcpyHostToDevice));
+  c->bk_bytes = bk_words * sizeof(double);
+  c->ksk_bytes = ksk_words * sizeof(int32_t);
+  c->keys = true;
+  return RS_OK;
+}
+
+int rs_reserve(rs_ctx* c, size_t max_batch) {
+  int rc = use_device(c);
+  if (rc) return rc;
+  return ensure_ws(c, max_batch);
+}
+
+int rs_bootstrap_dev(rs_ctx* c, int32_t* out, const int32_t* in, int32_t mu, size_t B, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (B == 0) return RS_OK;
+  if (!out || !in) return fail(RS_ERR_INVALID, "null ciphertext pointer");
+  return run_bootstrap(c, out, in, nullptr, 1, 0, 0, mu, B, (hipStream_t)stream);
+}
+
+int rs_gate_dev(rs_ctx* c, rs_gate_op op, int32_t* out, const int32_t* a, const int32_t* b, size_t B, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  GateCoef g;
+  if (!gate_coef(op, &g)) return fail(RS_ERR_INVALID, "unknown gate %d", (int)op);
+  if (B == 0) return RS_OK;
+  if (!out || !a || !b) return fail(RS_ERR_INVALID, "null ciphertext pointer");
+  return run_bootstrap(c, out, a, b, g.sa, g.sb, g.bconst, 1 << 29, B, (hipStream_t)stream);
+}
+
+int rs_mux_dev(rs_ctx* c, int32_t* out, const int32_t* a, const int32_t* b, const int32_t* cc, size_t B, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (B == 0) return RS_OK;
+  if (!out || !a || !b || !cc) return fail(RS_ERR_INVALID, "null ciphertext pointer");
+  rc = ensure_ws(c, B);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int wpb = pick_wpb(c, B);
+  const int32_t e8 = 1 << 29;
+  if (c->timing) RS_HIP(hipEventRecord(c->ev[0], st));
+  // u1 = woKS(AND(a,b)), u2 = woKS(ANDNY(a,c)); out = KS((0,1/8) + u1 + u2)
+  RS_HIP(rs::launch_blind_rotate(c->cfg, br_args(c, a, b, 1, 1, -e8, e8, B, c->d_u0), wpb, st));
+  RS_HIP(rs::launch_blind_rotate(c->cfg, br_args(c, a, cc, -1, 1, -e8, e8, B, c->d_u1), wpb, st));
+  if (c->timing) RS_HIP(hipEventRecord(c->ev[1], st));
+  RS_HIP(rs::launch_keyswitch(ks_args(c, c->d_u0, c->d_u1, e8, B, out), st));
+  if (c->timing) { RS_HIP(hipEventRecord(c->ev[2], st)); c->ev_valid = true; }
+  return RS_OK;
+}
+
+int rs_bootstrap_wo_ks_dev(rs_ctx* c, int32_t* u, const int32_t* in, int32_t mu, size_t B, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (B == 0) return RS_OK;
+  if (!u || !in) return fail(RS_ERR_INVALID, "null ciphertext pointer");
+  RS_HIP(rs::launch_blind_rotate(c->cfg, br_args(c, in, nullptr, 1, 0, 0, mu, B, u), pick_wpb(c, B), (hipStream_t)stream));
+  return RS_OK;
+}
+
+int rs_keyswitch_dev(rs_ctx* c, int32_t* out, const int32_t* u, size_t B, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (B == 0) return RS_OK;
+  if (!out || !u) return fail(RS_ERR_INVALID, "null ciphertext pointer");
+  RS_HIP(rs::launch_keyswitch(ks_args(c, u, nullptr, 0, B, out), (hipStream_t)stream));
+  return RS_OK;
+}
+
+// ---- host-pointer conveniences ----
+static int host_roundtrip(rs_ctx* c, int32_t* out, const int32_t* const* ins, int n_in, size_t B,
+                          int (*run)(rs_ctx*, int32_t*, int32_t* const*, size_t, void*), void* extra) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (B == 0) return RS_OK;
+  rc = ensure_io(c, B);
+  if (rc) return rc;
+  const size_t bytes = B * (size_t)(c->p.n + 1) * sizeof(int32_t);
+  for (int i = 0; i < n_in; ++i) {
+    if (!ins[i]) return fail(RS_ERR_INVALID, "null ciphertext pointer");
+    RS_HIP(hipMemcpy(c->d_io[i], ins[i], bytes, hipMemcpyHostToDevice));
+  }
+  rc = run(c, c->d_io[3], c->d_io, B, extra);
+  if (rc) return rc;
+  RS_HIP(hipDeviceSynchronize());
+  RS_HIP(hipMemcpy(out, c->d_io[3], bytes, hipMemcpyDeviceToHost));
+  return RS_OK;
+}
+
+int rs_bootstrap(rs_ctx* c, int32_t* out, const int32_t* in, int32_t mu, size_t B) {
+  if (!out) return fail(RS_ERR_INVALID, "null output");
+  const int32_t* ins[1] = {in};
+  return host_roundtrip(c, out, ins, 1, B,
+                        [](rs_ctx* cc, int32_t* o, int32_t* const* d, size_t b, void* ex) {
+                          return rs_bootstrap_dev(cc, o, d[0], *(int32_t*)ex, b, nullptr);
+                        }, &mu);
+}
+
+int rs_gate(rs_ctx* c, rs_gate_op op, int32_t* out, const int32_t* a, const int32_t* b, size_t B) {
+  if (!out) return fail(RS_ERR_INVALID, "null output");
+  const int32_t* ins[2] = {a, b};
+  return host_roundtrip(c, out, ins, 2, B,
+                        [](rs_ctx* cc, int32_t* o, int32_t* const* d, size_t bb, void* ex) {
+                          return rs_gate_dev(cc, *(rs_gate_op*)ex, o, d[0], d[1], bb, nullptr);
+                        }, &op);
+}
+
+int rs_mux(rs_ctx* c, int32_t* out, const int32_t* a, const int32_t* b, const int32_t* cc, size_t B) {
+  if (!out) return fail(RS_ERR_INVALID, "null output");
+  const int32_t* ins[3] = {a, b, cc};
+  return host_roundtrip(c, out, ins, 3, B,
+                        [](rs_ctx* c2, int32_t* o, int32_t* const* d, size_t bb, void*) {
+                          return rs_mux_dev(c2, o, d[0], d[1], d[2], bb, nullptr);
+                        }, nullptr);
+}
+
+int rs_debug_polymul(rs_ctx* c, int32_t* out, const int32_t* a_small, const int32_t* b_torus, size_t count) {
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (count == 0) return RS_OK;
+  if (!out || !a_small || !b_torus) return fail(RS_ERR_INVALID, "null pointer");
+  const size_t bytes = count * rs::kN * sizeof(int32_t);
+  int32_t *da = nullptr, *db = nullptr, *dout = nullptr;
+  RS_HIP(hipMalloc(&da, bytes)); RS_HIP(hipMalloc(&db, bytes)); RS_HIP(hipMalloc(&dout, bytes));
+  RS_HIP(hipMemcpy(da, a_small, bytes, hipMemcpyHostToDevice));
+  RS_HIP(hipMemcpy(db, b_torus, bytes, hipMemcpyHostToDevice));
+  RS_HIP(rs::launch_polymul(c->cfg, da, db, dout, c->d_tw, c->tables.f, c->tables.ninv, (long)count, nullptr));
+  RS_HIP(hipDeviceSynchronize());
+  RS_HIP(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
+  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+  return RS_OK;
+}
+
+// ---- linear stage ----
+int rs_lincomb_dev(rs_ctx* c, int32_t* out, const int32_t* a, int32_t ca, const int32_t* b, int32_t cb, int32_t bconst, size_t B,
+                   void* stream) {
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (B == 0) return RS_OK;
+  if (!out || !a) return fail(RS_ERR_INVALID, "null ciphertext pointer");
+  RS_HIP(rs::launch_lincomb(out, a, ca, b, cb, bconst, c->p.n + 1, (long)B, (hipStream_t)stream));
+  return RS_OK;
+}
+
+int rs_linear_fc_dev(rs_ctx* c, int32_t* out, const int32_t* in, const uint8_t* sign, const uint8_t* zero, int32_t K, int32_t M,
+                     int32_t zero_tap_b, const int32_t* bias_b, int32_t bias_depth, void* stream) {
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (!out || !in || !sign) return fail(RS_ERR_INVALID, "null pointer");
+  if (K < 1 || M < 1 || M > 65535) return fail(RS_ERR_INVALID, "bad fully-connected shape K=%d M=%d", K, M);
+  if (bias_b && bias_depth < 1) return fail(RS_ERR_INVALID, "bias_depth must be >= 1");
+  RS_HIP(rs::launch_linear_fc(out, in, sign, zero, K, M, c->p.n + 1, zero_tap_b, bias_b, bias_depth, (hipStream_t)stream));
+  return RS_OK;
+}
+
+int rs_conv_ternary_dev(rs_ctx* c, int32_t* out, const int32_t* in, const uint8_t* sign, const uint8_t* zero,
+                        const rs_conv_shape* s, int32_t zero_tap_b, int32_t pad_tap_b, const int32_t* bias_b, int32_t bias_depth,
+                        void* stream) {
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (!out || !in || !sign || !s) return fail(RS_ERR_INVALID, "null pointer");
+  if (s->Cout < 1 || s->Cout > 65535 || s->Ho * s->Wo < 1 || s->Ho * s->Wo > 65535 || s->stride_h < 1 || s->stride_w < 1)
+    return fail(RS_ERR_INVALID, "bad convolution shape");
+  if (bias_b && bias_depth < 1) return fail(RS_ERR_INVALID, "bias_depth must be >= 1");
+  rs::ConvShape cs{s->H, s->Wd, s->Cin, s->Cout, s->fh, s->fw, s->stride_h, s->stride_w, s->off_h, s->off_w, s->Ho, s->Wo};
+  RS_HIP(rs::launch_conv_ternary(out, in, sign, zero, cs, c->p.n + 1, zero_tap_b, pad_tap_b, bias_b, bias_depth, (hipStream_t)stream));
+  return RS_OK;
+}
+
+int rs_sumpool_dev(rs_ctx* c, int32_t* out, const int32_t* in, const rs_pool_shape* s, const int32_t* bias_b, int32_t bias_depth,
+                   void* stream) {
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (!out || !in || !s) return fail(RS_ERR_INVALID, "null pointer");
+  if (s->C < 1 || s->C > 65535 || s->Ho * s->Wo < 1 || s->Ho * s->Wo > 65535 || s->stride_h < 1 || s->stride_w < 1)
+    return fail(RS_ERR_INVALID, "bad pooling shape");
+  if (bias_b && bias_depth < 1) return fail(RS_ERR_INVALID, "bias_depth must be >= 1");
+  rs::PoolShape ps{s->H, s->Wd, s->C, s->win_h, s->win_w, s->stride_h, s->stride_w, s->off_h, s->off_w, s->Ho, s->Wo};
+  RS_HIP(rs::launch_sumpool(out, in, ps, c->p.n + 1, bias_b, bias_depth, (hipStream_t)stream));
+  return RS_OK;
+}
+
+// ---- memory helpers ----
+int rs_dev_alloc(rs_ctx* c, void** ptr, size_t bytes) {
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (!ptr) return fail(RS_ERR_INVALID, "null pointer");
+  RS_HIP(hipMalloc(ptr, bytes ? bytes : 1));
+  return RS_OK;
+}
+int rs_dev_free(rs_ctx* c, void* ptr) {
+  int rc = use_device(c);
+  if (rc) return rc;
+  RS_HIP(hipFree(ptr));
+  return RS_OK;
+}
+int rs_copy_to_dev(rs_ctx* c, void* dst, const void* src, size_t bytes) {
+  int rc = use_device(c);
+  if (rc) return rc;
+  RS_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return RS_OK;
+}
+int rs_copy_to_host(rs_ctx* c, void* dst, const void* src, size_t bytes) {
+  int rc = use_device(c);
+  if (rc) return rc;
+  RS_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return RS_OK;
+}
+int rs_sync(rs_ctx* c) {
+  int rc = use_device(c);
+  if (rc) return rc;
+  RS_HIP(hipDeviceSynchronize());
+  return RS_OK;
+}
+
+int rs_set_timing(rs_ctx* c, int enable) {
+  if (!c) return fail(RS_ERR_INVALID, "null context");
+  c->timing = enable != 0;
+  c->ev_valid = false;
+  return RS_OK;
+}
+
+int rs_last_kernel_ms(rs_ctx* c, float* br_ms, float* ks_ms) {
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (!c->ev_valid) return fail(RS_ERR_STATE, "no timed launch recorded");
+  RS_HIP(hipEventSynchronize(c->ev[2]));
+  float a = -1.f, b = -1.f;
+  RS_HIP(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+  RS_HIP(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
+  if (br_ms) *br_ms = a;
+  if (ks_ms) *ks_ms = b;
+  return RS_OK;
+}
+
+int rs_info(rs_ctx* c, int64_t* bk_bytes, int64_t* ksk_bytes, int32_t* wpb, int32_t* cus) {
+  if (!c) return fail(RS_ERR_INVALID, "null context");
+  if (bk_bytes) *bk_bytes = (int64_t)c->bk_bytes;
+  if (ksk_bytes) *ksk_bytes = (int64_t)c->ksk_bytes;
+  if (wpb) *wpb = 8;
+  if (cus) *cus = c->num_cus;
+  return RS_OK;
+}
+
+}  // extern "C"

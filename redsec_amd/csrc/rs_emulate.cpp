@@ -1,0 +1,205 @@
+// rs_emulate.cpp -- TEST-ONLY host emulation of one wavefront of the HIP kernels.
+//
+// Runs the very same phase functions (rs_ntt.h) lane by lane, with a plain array standing in for
+// the LDS exchange buffer, so that the transform's index mapping, the reduction schedule and the
+// CMUX bookkeeping can be checked bit-for-bit against the oracle on a machine without a GPU
+// (pytest -m "not gpu"). It is NOT part of libredsec_hip.so and is never a fallback: the product
+// library has no CPU compute path. Built by redsec_amd/build.py as librs_emulate.so.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "rs_host.h"
+#include "rs_ntt.h"
+
+namespace {
+
+using rs::Field;
+using rs::kLanes;
+using rs::kN;
+using rs::kRegs;
+
+struct Wave {
+  double x[kLanes][kRegs];
+};
+
+template <class C>
+void emu_forward(Wave& w, const double* tw, double* buf, const Field& f) {
+  for (int l = 0; l < kLanes; ++l) rs::fwd_F1<C>(l, w.x[l], tw, buf, f);
+  for (int l = 0; l < kLanes; ++l) rs::fwd_F2<C>(l, w.x[l], tw, buf, f);
+  for (int l = 0; l < kLanes; ++l) rs::fwd_F3(l, w.x[l], buf);
+  for (int l = 0; l < kLanes; ++l) rs::fwd_F4<C>(l, w.x[l], tw, buf, f);
+}
+template <class C>
+void emu_inverse(Wave& w, const double* twi, double* buf, const Field& f) {
+  for (int l = 0; l < kLanes; ++l) rs::inv_I1<C>(l, w.x[l], twi, buf, f);
+  for (int l = 0; l < kLanes; ++l) rs::inv_I2<C>(l, w.x[l], twi, buf, f);
+  for (int l = 0; l < kLanes; ++l) rs::inv_I3(l, w.x[l], buf);
+  for (int l = 0; l < kLanes; ++l) rs::inv_I4<C>(l, w.x[l], twi, buf, f);
+}
+
+// key polynomial -> device layout [v][lane][2], scaled by 1/N, reduced (bk_transform_kernel)
+template <class C>
+void emu_key_transform(const int32_t* poly, double* dst, const rs::Tables& t, double* buf) {
+  Wave w;
+  for (int l = 0; l < kLanes; ++l)
+    for (int r = 0; r < kRegs; ++r) w.x[l][r] = (double)poly[l + 64 * r];
+  emu_forward<C>(w, t.tw.data(), buf, t.f);
+  for (int l = 0; l < kLanes; ++l)
+    for (int v = 0; v < 8; ++v)
+      for (int e = 0; e < 2; ++e) {
+        double a = rs::f_reduce(rs::f_mulmod(rs::f_reduce(w.x[l][2 * v + e], t.f), t.ninv, t.f), t.f);
+        dst[(v * 64 + l) * 2 + e] = a;
+      }
+}
+
+template <class C>
+int emu_polymul(const int32_t* a_small, const int32_t* b_torus, int32_t* out) {
+  rs::PrimeSpec ps;
+  if (!rs::prime_for(C::L, C::BGBIT, &ps)) return -1;
+  rs::Tables t = rs::make_tables(ps);
+  std::vector<double> buf(rs::kBufDoubles), bkd(kN);
+  emu_key_transform<C>(b_torus, bkd.data(), t, buf.data());
+  Wave w;
+  for (int l = 0; l < kLanes; ++l)
+    for (int r = 0; r < kRegs; ++r) w.x[l][r] = (double)a_small[l + 64 * r];
+  emu_forward<C>(w, t.tw.data(), buf.data(), t.f);
+  for (int l = 0; l < kLanes; ++l)
+    for (int u = 0; u < kRegs; ++u) w.x[l][u] = rs::f_mulmod(w.x[l][u], bkd[((u >> 1) * 64 + l) * 2 + (u & 1)], t.f);
+  emu_inverse<C>(w, t.tw.data() + kN, buf.data(), t.f);
+  for (int l = 0; l < kLanes; ++l)
+    for (int r = 0; r < kRegs; ++r) out[l + 64 * r] = rs::f_to_torus32(w.x[l][r]);
+  return 0;
+}
+
+// blind_rotate_kernel for one ciphertext: in0/in1 rows [n+1], bk torus [n][2l][2][N] -> u [N+1]
+template <class C>
+int emu_blind_rotate(int n, const int32_t* in0, const int32_t* in1, int32_t c0, int32_t c1, int32_t bconst, int32_t mu,
+                     const int32_t* bk, int32_t* u_out, int32_t* acc_out, int steps) {
+  rs::PrimeSpec ps;
+  if (!rs::prime_for(C::L, C::BGBIT, &ps)) return -1;
+  rs::Tables t = rs::make_tables(ps);
+  const Field f = t.f;
+  const double* tw = t.tw.data();
+  const double* twi = tw + kN;
+  std::vector<double> buf(rs::kBufDoubles);
+  constexpr int KPL = 2 * C::L;
+  std::vector<double> bk_ntt((size_t)n * KPL * 2 * kN);
+  for (size_t poly = 0; poly < (size_t)n * KPL * 2; ++poly)
+    emu_key_transform<C>(bk + poly * kN, bk_ntt.data() + poly * kN, t, buf.data());
+
+  auto word = [&](int i) -> int32_t {
+    uint32_t v = (uint32_t)c0 * (uint32_t)in0[i];
+    if (in1) v += (uint32_t)c1 * (uint32_t)in1[i];
+    return (int32_t)v;
+  };
+  std::vector<int32_t> acc0(kN), acc1(kN);
+  const int32_t barb = rs::modswitch_2N((int32_t)((uint32_t)word(n) + (uint32_t)bconst));
+  const int rot = 2 * kN - barb;
+  for (int j = 0; j < kN; ++j) { acc0[j] = 0; acc1[j] = rs::rotated_const(mu, j, rot); }
+  constexpr uint32_t offset = rs::gadget_offset<C>();
+  if (steps < 0 || steps > n) steps = n;
+  Wave s0, s1, x;
+  static int32_t d[kLanes][kRegs];
+  for (int i = 0; i < steps; ++i) {
+    const int32_t bara = rs::modswitch_2N(word(i));
+    if (bara == 0) continue;
+    std::memset(&s0, 0, sizeof s0);
+    std::memset(&s1, 0, sizeof s1);
+    const double* bk_i = bk_ntt.data() + (size_t)i * KPL * 2 * kN;
+    for (int comp = 0; comp < 2; ++comp) {
+      const int32_t* accc = comp ? acc1.data() : acc0.data();
+      for (int l = 0; l < kLanes; ++l)
+        for (int r = 0; r < kRegs; ++r) d[l][r] = rs::rotated_diff(accc, l + 64 * r, bara);
+      for (int q = 0; q < C::L; ++q) {
+        const int row = comp * C::L + q;
+        const double* bp0 = bk_i + (size_t)(row * 2) * kN;
+        const double* bp1 = bp0 + kN;
+        for (int l = 0; l < kLanes; ++l)
+          for (int r = 0; r < kRegs; ++r) x.x[l][r] = (double)rs::gadget_digit<C>(d[l][r], q, offset);
+        emu_forward<C>(x, tw, buf.data(), f);
+        for (int l = 0; l < kLanes; ++l)
+          for (int u = 0; u < kRegs; ++u) {
+            const size_t k = ((size_t)(u >> 1) * 64 + l) * 2 + (u & 1);
+            s0.x[l][u] += rs::f_mulmod(x.x[l][u], bp0[k], f);
+            s1.x[l][u] += rs::f_mulmod(x.x[l][u], bp1[k], f);
+          }
+      }
+    }
+    emu_inverse<C>(s0, twi, buf.data(), f);
+    for (int l = 0; l < kLanes; ++l)
+      for (int r = 0; r < kRegs; ++r) {
+        const int j = l + 64 * r;
+        acc0[j] = (int32_t)((uint32_t)acc0[j] + (uint32_t)rs::f_to_torus32(s0.x[l][r]));
+      }
+    emu_inverse<C>(s1, twi, buf.data(), f);
+    for (int l = 0; l < kLanes; ++l)
+      for (int r = 0; r < kRegs; ++r) {
+        const int j = l + 64 * r;
+        acc1[j] = (int32_t)((uint32_t)acc1[j] + (uint32_t)rs::f_to_torus32(s1.x[l][r]));
+      }
+  }
+  if (acc_out) {
+    std::memcpy(acc_out, acc0.data(), sizeof(int32_t) * kN);
+    std::memcpy(acc_out + kN, acc1.data(), sizeof(int32_t) * kN);
+  }
+  if (u_out) {
+    for (int j = 0; j < kN; ++j) u_out[j] = (j == 0) ? acc0[0] : (int32_t)(0u - (uint32_t)acc0[kN - j]);
+    u_out[kN] = acc1[0];
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// cfg: 0 = l=3/Bgbit=7, 1 = l=10/Bgbit=3
+int rs_emu_polymul(int cfg, const int32_t* a_small, const int32_t* b_torus, int32_t* out) {
+  return cfg == 0 ? emu_polymul<rs::CfgDefault128>(a_small, b_torus, out) : emu_polymul<rs::CfgRedsecV2>(a_small, b_torus, out);
+}
+
+int rs_emu_blind_rotate(int cfg, int n, const int32_t* in0, const int32_t* in1, int32_t c0, int32_t c1, int32_t bconst, int32_t mu,
+                        const int32_t* bk, int32_t* u_out, int32_t* acc_out, int steps) {
+  return cfg == 0 ? emu_blind_rotate<rs::CfgDefault128>(n, in0, in1, c0, c1, bconst, mu, bk, u_out, acc_out, steps)
+                  : emu_blind_rotate<rs::CfgRedsecV2>(n, in0, in1, c0, c1, bconst, mu, bk, u_out, acc_out, steps);
+}
+
+// Returns 0 if the reduction schedule of cfg is provably exact for its prime, else -1 (msg filled).
+int rs_emu_validate(int cfg, char* msg, int msg_len) {
+  rs::PrimeSpec ps;
+  const int l = cfg == 0 ? 3 : 10, bg = cfg == 0 ? 7 : 3;
+  if (!rs::prime_for(l, bg, &ps)) return -1;
+  const unsigned fm = cfg == 0 ? rs::CfgDefault128::FWD_MASK : rs::CfgRedsecV2::FWD_MASK;
+  const unsigned im = cfg == 0 ? rs::CfgDefault128::INV_MASK : rs::CfgRedsecV2::INV_MASK;
+  std::string why = rs::validate_schedule((double)ps.p, l, bg, fm, im);
+  if (msg && msg_len > 0) { std::strncpy(msg, why.c_str(), (size_t)msg_len - 1); msg[msg_len - 1] = 0; }
+  return why.empty() ? 0 : -1;
+}
+
+// Largest |intermediate| / 2^53 seen while transforming worst-case inputs is not observable from
+// outside; instead expose the raw forward transform for property tests:
+// out[16*lane+u] layout C values (doubles) of the forward transform of `poly`.
+int rs_emu_forward(int cfg, const int32_t* poly, double* out) {
+  rs::PrimeSpec ps;
+  const int l = cfg == 0 ? 3 : 10, bg = cfg == 0 ? 7 : 3;
+  if (!rs::prime_for(l, bg, &ps)) return -1;
+  rs::Tables t = rs::make_tables(ps);
+  std::vector<double> buf(rs::kBufDoubles);
+  Wave w;
+  for (int lane = 0; lane < kLanes; ++lane)
+    for (int r = 0; r < kRegs; ++r) w.x[lane][r] = (double)poly[lane + 64 * r];
+  if (cfg == 0) emu_forward<rs::CfgDefault128>(w, t.tw.data(), buf.data(), t.f);
+  else emu_forward<rs::CfgRedsecV2>(w, t.tw.data(), buf.data(), t.f);
+  for (int lane = 0; lane < kLanes; ++lane)
+    for (int u = 0; u < kRegs; ++u) out[16 * lane + u] = w.x[lane][u];
+  return 0;
+}
+
+uint64_t rs_emu_prime(int cfg) {
+  rs::PrimeSpec ps;
+  if (!rs::prime_for(cfg == 0 ? 3 : 10, cfg == 0 ? 7 : 3, &ps)) return 0;
+  return ps.p;
+}
+
+}  // extern "C"

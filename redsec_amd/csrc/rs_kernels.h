@@ -1,0 +1,57 @@
+// rs_kernels.h -- kernel argument blocks and launchers (internal; the public boundary is
+// include/redsec_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "rs_ntt.h"
+
+namespace rs {
+
+struct BlindRotateArgs {
+  const int32_t* in0;   // [B][W]
+  const int32_t* in1;   // [B][W] or nullptr
+  int32_t c0, c1;       // x = c0*in0 + c1*in1 (word-wise, wrapping)
+  int32_t bconst;       // added to the b word
+  int32_t mu;           // test-vector value
+  const double* bk_ntt; // [n][2l][2][8][64][2]
+  const double* tw;     // [2048]
+  Field f;
+  int32_t n;
+  int32_t W;            // n + 1
+  long B;
+  int32_t* u_out;       // [B][N+1] extracted samples
+};
+
+struct KeyswitchArgs {
+  const int32_t* u0;    // [B][N+1]
+  const int32_t* u1;    // optional second addend (bootsMUX)
+  int32_t bconst;       // added to the b word of u
+  const int32_t* ksk;   // [N][t][base][W]
+  int32_t W, t, basebit;
+  long B;
+  int32_t* out;         // [B][W]
+};
+
+struct ConvShape { int32_t H, Wd, Cin, Cout, fh, fw, stride_h, stride_w, off_h, off_w, Ho, Wo; };
+struct PoolShape { int32_t H, Wd, C, win_h, win_w, stride_h, stride_w, off_h, off_w, Ho, Wo; };
+
+// cfg: 0 = CfgDefault128 (l=3, Bgbit=7), 1 = CfgRedsecV2 (l=10, Bgbit=3)
+hipError_t launch_blind_rotate(int cfg, const BlindRotateArgs& a, int waves_per_block, hipStream_t st);
+hipError_t launch_bk_transform(int cfg, const int32_t* bk, double* bk_ntt, const double* tw, Field f, double ninv, long n_polys,
+                               hipStream_t st);
+hipError_t launch_keyswitch(const KeyswitchArgs& a, hipStream_t st);
+hipError_t launch_polymul(int cfg, const int32_t* a_small, const int32_t* b_torus, int32_t* out, const double* tw, Field f,
+                          double ninv, long count, hipStream_t st);
+hipError_t launch_lincomb(int32_t* out, const int32_t* x, int32_t cx, const int32_t* y, int32_t cy, int32_t bconst, int W, long B,
+                          hipStream_t st);
+hipError_t launch_linear_fc(int32_t* out, const int32_t* in, const uint8_t* sign, const uint8_t* zero, int K, int M, int W,
+                            int32_t zero_tap_b, const int32_t* bias_b, int bias_depth, hipStream_t st);
+hipError_t launch_conv_ternary(int32_t* out, const int32_t* in, const uint8_t* sign, const uint8_t* zero, const ConvShape& s, int W,
+                               int32_t zero_tap_b, int32_t pad_tap_b, const int32_t* bias_b, int bias_depth, hipStream_t st);
+hipError_t launch_sumpool(int32_t* out, const int32_t* in, const PoolShape& s, int W, const int32_t* bias_b, int bias_depth,
+                          hipStream_t st);
+
+}  // namespace rs

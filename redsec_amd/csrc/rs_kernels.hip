@@ -1,0 +1,450 @@
+// rs_kernels.hip -- gfx950 kernels of the gate-bootstrapping hot path.
+//
+//   bk_transform_kernel    bootstrapping key -> transform domain (the bkFFT analogue; once per key)
+//   blind_rotate_kernel    gate pre-combination + modswitch + n CMUX steps + sample extract
+//                          (tfhe_bootstrap_woKS_FFT; REDsec: lib/BinOps_enc.cpp:185,191)
+//   keyswitch_kernel       lweKeySwitch (N -> n)
+//   polymul_kernel         debug/parity tap through the same transform path
+//   lincomb / linear_fc / conv_ternary / sumpool   LWE word arithmetic of the layer linear stage
+//
+// One wavefront owns one ciphertext for the whole blind rotation: its TRLWE accumulator (2 x 1024
+// int32) lives in LDS, each of the (k+1) l digit polynomials is transformed in registers with two
+// LDS transposes (rs_ntt.h), multiplied against the coalesced-streamed key row and accumulated in
+// registers, and two inverse transforms update the accumulator. Waves never synchronise with each
+// other after the twiddle tables are staged, so the 2 waves per SIMD interleave freely.
+#include <hip/hip_runtime.h>
+
+#include "rs_kernels.h"
+#include "rs_ntt.h"
+
+namespace rs {
+
+// Same-wave LDS hand-off: DS operations of one wavefront execute in order, so only the compiler
+// needs to be told not to move LDS accesses across this point.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <class C>
+__device__ __forceinline__ void ntt_forward(int lane, double (&x)[kRegs], const double* tw, double* buf, const Field& f) {
+  fwd_F1<C>(lane, x, tw, buf, f);
+  wave_lds_sync();
+  fwd_F2<C>(lane, x, tw, buf, f);
+  wave_lds_sync();
+  fwd_F3(lane, x, buf);
+  wave_lds_sync();
+  fwd_F4<C>(lane, x, tw, buf, f);
+  wave_lds_sync();
+}
+
+template <class C>
+__device__ __forceinline__ void ntt_inverse(int lane, double (&x)[kRegs], const double* twi, double* buf, const Field& f) {
+  inv_I1<C>(lane, x, twi, buf, f);
+  wave_lds_sync();
+  inv_I2<C>(lane, x, twi, buf, f);
+  wave_lds_sync();
+  inv_I3(lane, x, buf);
+  wave_lds_sync();
+  inv_I4<C>(lane, x, twi, buf, f);
+  wave_lds_sync();
+}
+
+__device__ __forceinline__ void stage_tables(double* s_tw, const double* tw_g, int nthreads) {
+  for (int i = threadIdx.x; i < 2 * kN; i += nthreads) s_tw[i] = tw_g[i];
+  __syncthreads();
+}
+
+// -------------------------------------------------------------------------------------------------
+// Key transform: one wavefront per key polynomial. Output layout per polynomial: [v 0..7][lane][2]
+// doubles = transform positions 16*lane + 2v, +1, so that the blind rotation reads each row with
+// eight perfectly coalesced 16-byte-per-lane loads. Values are scaled by 1/N and fully reduced.
+// -------------------------------------------------------------------------------------------------
+template <class C, int WPB>
+__global__ __launch_bounds__(64 * WPB) void bk_transform_kernel(const int32_t* __restrict__ bk, double* __restrict__ bk_ntt,
+                                                                 const double* __restrict__ tw_g, Field f, double ninv,
+                                                                 long n_polys) {
+  __shared__ double s_tw[2 * kN];
+  __shared__ double s_buf[WPB][kBufDoubles];
+  stage_tables(s_tw, tw_g, 64 * WPB);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const long poly = (long)blockIdx.x * WPB + wave;
+  if (poly >= n_polys) return;
+  double x[kRegs];
+  const int32_t* src = bk + poly * kN;
+#pragma unroll
+  for (int r = 0; r < kRegs; ++r) x[r] = (double)src[lane + 64 * r];
+  ntt_forward<C>(lane, x, s_tw, s_buf[wave], f);
+  double2* dst = reinterpret_cast<double2*>(bk_ntt + poly * kN);
+#pragma unroll
+  for (int v = 0; v < 8; ++v) {
+    double a = f_reduce(f_mulmod(f_reduce(x[2 * v], f), ninv, f), f);
+    double b = f_reduce(f_mulmod(f_reduce(x[2 * v + 1], f), ninv, f), f);
+    dst[v * 64 + lane] = make_double2(a, b);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Blind rotation + sample extract.
+// -------------------------------------------------------------------------------------------------
+template <class C, int WPB>
+__global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs a) {
+  __shared__ double s_tw[2 * kN];
+  __shared__ double s_buf[WPB][kBufDoubles];
+  __shared__ int32_t s_acc[WPB][2][kN];
+  stage_tables(s_tw, a.tw, 64 * WPB);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const long ct = (long)blockIdx.x * WPB + wave;
+  if (ct >= a.B) return;
+
+  const Field f = a.f;
+  double* buf = s_buf[wave];
+  int32_t* acc0 = s_acc[wave][0];
+  int32_t* acc1 = s_acc[wave][1];
+  const double* tw = s_tw;
+  const double* twi = s_tw + kN;
+  const int32_t* row0 = a.in0 + ct * a.W;
+  const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
+  const int n = a.n;
+
+  // gate pre-combination (0, bconst) + c0*in0 + c1*in1, evaluated word by word as it is consumed
+  auto word = [&](int i) -> int32_t {
+    uint32_t v = (uint32_t)a.c0 * (uint32_t)row0[i];
+    if (row1) v += (uint32_t)a.c1 * (uint32_t)row1[i];
+    return (int32_t)v;
+  };
+
+  {
+    const int32_t barb = modswitch_2N((int32_t)((uint32_t)word(n) + (uint32_t)a.bconst));
+    const int rot = 2 * kN - barb;  // in (0, 2N]
+#pragma unroll
+    for (int r = 0; r < kRegs; ++r) {
+      const int j = lane + 64 * r;
+      acc0[j] = 0;
+      acc1[j] = rotated_const(a.mu, j, rot);
+    }
+  }
+  wave_lds_sync();
+
+  constexpr uint32_t offset = gadget_offset<C>();
+  constexpr int KPL = 2 * C::L;
+
+  for (int i = 0; i < n; ++i) {
+    const int32_t bara = __builtin_amdgcn_readfirstlane(modswitch_2N(word(i)));
+    if (bara == 0) continue;  // tfhe_blindRotate_FFT skips the identity CMUX
+    double s0[kRegs], s1[kRegs];
+#pragma unroll
+    for (int u = 0; u < kRegs; ++u) { s0[u] = 0.0; s1[u] = 0.0; }
+    const double* bk_i = a.bk_ntt + (size_t)i * KPL * 2 * kN;
+
+#pragma unroll 1
+    for (int comp = 0; comp < 2; ++comp) {
+      const int32_t* accc = comp ? acc1 : acc0;
+      int32_t d[kRegs];
+#pragma unroll
+      for (int r = 0; r < kRegs; ++r) d[r] = rotated_diff(accc, lane + 64 * r, bara);
+#pragma unroll 1
+      for (int q = 0; q < C::L; ++q) {
+        const int row = comp * C::L + q;
+        const double2* bp0 = reinterpret_cast<const double2*>(bk_i + (size_t)(row * 2) * kN);
+        const double2* bp1 = bp0 + kN / 2;
+        double2 w0[8], w1[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) { w0[v] = bp0[v * 64 + lane]; w1[v] = bp1[v * 64 + lane]; }
+        double x[kRegs];
+#pragma unroll
+        for (int r = 0; r < kRegs; ++r) x[r] = (double)gadget_digit<C>(d[r], q, offset);
+        ntt_forward<C>(lane, x, tw, buf, f);
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+          s0[2 * v] += f_mulmod(x[2 * v], w0[v].x, f);
+          s0[2 * v + 1] += f_mulmod(x[2 * v + 1], w0[v].y, f);
+          s1[2 * v] += f_mulmod(x[2 * v], w1[v].x, f);
+          s1[2 * v + 1] += f_mulmod(x[2 * v + 1], w1[v].y, f);
+        }
+      }
+    }
+
+    ntt_inverse<C>(lane, s0, twi, buf, f);
+#pragma unroll
+    for (int r = 0; r < kRegs; ++r) {
+      const int j = lane + 64 * r;
+      acc0[j] = (int32_t)((uint32_t)acc0[j] + (uint32_t)f_to_torus32(s0[r]));
+    }
+    ntt_inverse<C>(lane, s1, twi, buf, f);
+#pragma unroll
+    for (int r = 0; r < kRegs; ++r) {
+      const int j = lane + 64 * r;
+      acc1[j] = (int32_t)((uint32_t)acc1[j] + (uint32_t)f_to_torus32(s1[r]));
+    }
+    wave_lds_sync();
+  }
+
+  // tLweExtractLweSampleIndex(index 0): a'[0] = acc_a[0], a'[j] = -acc_a[N-j], b' = acc_b[0]
+  int32_t* out = a.u_out + ct * (kN + 1);
+#pragma unroll
+  for (int r = 0; r < kRegs; ++r) {
+    const int j = lane + 64 * r;
+    out[j] = (j == 0) ? acc0[0] : (int32_t)(0u - (uint32_t)acc0[kN - j]);
+  }
+  if (lane == 0) out[kN] = acc1[0];
+}
+
+// -------------------------------------------------------------------------------------------------
+// Keyswitch: one workgroup per ciphertext, threads over output words. The KSK (83-104 MB) stays in
+// the Infinity Cache; rows are gathered by digit. u = u0 (+ u1) (+ bconst on the b word): the sum
+// form serves bootsMUX.
+// -------------------------------------------------------------------------------------------------
+constexpr int KS_THREADS = 256;
+constexpr int KS_MAXR = 4;  // output words per thread: W <= 1024
+
+__global__ __launch_bounds__(KS_THREADS) void keyswitch_kernel(KeyswitchArgs a) {
+  const long ct = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int32_t* u0 = a.u0 + ct * (kN + 1);
+  const int32_t* u1 = a.u1 ? a.u1 + ct * (kN + 1) : nullptr;
+  uint32_t acc[KS_MAXR];
+#pragma unroll
+  for (int k = 0; k < KS_MAXR; ++k) acc[k] = 0;
+  const int W = a.W, t = a.t, basebit = a.basebit;
+  const uint32_t prec_offset = 1u << (32 - (1 + basebit * t));
+  const uint32_t mask = (1u << basebit) - 1u;
+  for (int i = 0; i < kN; ++i) {
+    uint32_t ai = (uint32_t)u0[i];
+    if (u1) ai += (uint32_t)u1[i];
+    const uint32_t aibar = ai + prec_offset;
+    for (int j = 0; j < t; ++j) {
+      const uint32_t dgt = (aibar >> (32 - (j + 1) * basebit)) & mask;
+      if (dgt == 0) continue;
+      const int32_t* row = a.ksk + ((((size_t)i * t + j) << basebit) + dgt) * (size_t)W;
+#pragma unroll
+      for (int k = 0; k < KS_MAXR; ++k) {
+        const int w = tid + k * KS_THREADS;
+        if (w < W) acc[k] += (uint32_t)row[w];
+      }
+    }
+  }
+  uint32_t bw = (uint32_t)u0[kN];
+  if (u1) bw += (uint32_t)u1[kN];
+  bw += (uint32_t)a.bconst;
+  int32_t* out = a.out + ct * W;
+#pragma unroll
+  for (int k = 0; k < KS_MAXR; ++k) {
+    const int w = tid + k * KS_THREADS;
+    if (w < W) out[w] = (int32_t)((w == W - 1 ? bw : 0u) - acc[k]);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Debug tap: out = a_small * b_torus (negacyclic, mod 2^32) through forward/pointwise/inverse.
+// -------------------------------------------------------------------------------------------------
+template <class C, int WPB>
+__global__ __launch_bounds__(64 * WPB) void polymul_kernel(const int32_t* __restrict__ a_small, const int32_t* __restrict__ b_torus,
+                                                            int32_t* __restrict__ out, const double* __restrict__ tw_g, Field f,
+                                                            double ninv, long count) {
+  __shared__ double s_tw[2 * kN];
+  __shared__ double s_buf[WPB][kBufDoubles];
+  stage_tables(s_tw, tw_g, 64 * WPB);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const long idx = (long)blockIdx.x * WPB + wave;
+  if (idx >= count) return;
+  double* buf = s_buf[wave];
+  double xa[kRegs], xb[kRegs];
+#pragma unroll
+  for (int r = 0; r < kRegs; ++r) {
+    xa[r] = (double)a_small[idx * kN + lane + 64 * r];
+    xb[r] = (double)b_torus[idx * kN + lane + 64 * r];
+  }
+  ntt_forward<C>(lane, xb, s_tw, buf, f);
+#pragma unroll
+  for (int u = 0; u < kRegs; ++u) xb[u] = f_reduce(f_mulmod(f_reduce(xb[u], f), ninv, f), f);
+  ntt_forward<C>(lane, xa, s_tw, buf, f);
+#pragma unroll
+  for (int u = 0; u < kRegs; ++u) xa[u] = f_mulmod(xa[u], xb[u], f);
+  ntt_inverse<C>(lane, xa, s_tw + kN, buf, f);
+#pragma unroll
+  for (int r = 0; r < kRegs; ++r) out[idx * kN + lane + 64 * r] = f_to_torus32(xa[r]);
+}
+
+// -------------------------------------------------------------------------------------------------
+// LWE word arithmetic
+// -------------------------------------------------------------------------------------------------
+__global__ void lincomb_kernel(int32_t* __restrict__ out, const int32_t* __restrict__ x, int32_t cx, const int32_t* __restrict__ y,
+                               int32_t cy, int32_t bconst, int W, long total) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    uint32_t v = (uint32_t)cx * (uint32_t)x[e];
+    if (y) v += (uint32_t)cy * (uint32_t)y[e];
+    if ((int)(e % W) == W - 1) v += (uint32_t)bconst;
+    out[e] = (int32_t)v;
+  }
+}
+
+// out[m][w] = sum_k s(k,m) in[k][w] (+ constants on the b word). grid (ceil(W/256), M).
+__global__ __launch_bounds__(256) void linear_fc_kernel(int32_t* __restrict__ out, const int32_t* __restrict__ in,
+                                                        const uint8_t* __restrict__ sign, const uint8_t* __restrict__ zero, int K,
+                                                        int M, int W, int32_t zero_tap_b, const int32_t* __restrict__ bias_b,
+                                                        int bias_depth) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  const int m = blockIdx.y;
+  if (w >= W) return;
+  uint32_t acc = 0;
+  uint32_t nzero = 0;
+  for (int k = 0; k < K; ++k) {
+    const size_t fi = (size_t)k * M + m;
+    if (zero && zero[fi]) { ++nzero; continue; }
+    const uint32_t v = (uint32_t)in[(size_t)k * W + w];
+    acc += sign[fi] ? v : (0u - v);
+  }
+  if (w == W - 1) {
+    acc += nzero * (uint32_t)zero_tap_b;
+    if (bias_b) acc += (uint32_t)bias_b[m % bias_depth];
+  }
+  out[(size_t)m * W + w] = (int32_t)acc;
+}
+
+// out[oh][ow][od][w]; grid (ceil(W/256), Cout, Ho*Wo)
+__global__ __launch_bounds__(256) void conv_ternary_kernel(int32_t* __restrict__ out, const int32_t* __restrict__ in,
+                                                           const uint8_t* __restrict__ sign, const uint8_t* __restrict__ zero,
+                                                           ConvShape s, int W, int32_t zero_tap_b, int32_t pad_tap_b,
+                                                           const int32_t* __restrict__ bias_b, int bias_depth) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  const int od = blockIdx.y;
+  const int pix = blockIdx.z;
+  if (w >= W) return;
+  const int oh = pix / s.Wo, ow = pix % s.Wo;
+  uint32_t acc = 0, nzero = 0, npad = 0;
+  for (int fh = 0; fh < s.fh; ++fh) {
+    const int ih = fh + oh * s.stride_h - s.off_h;
+    for (int fw = 0; fw < s.fw; ++fw) {
+      const int iw = fw + ow * s.stride_w - s.off_w;
+      const bool oob = (unsigned)ih >= (unsigned)s.H || (unsigned)iw >= (unsigned)s.Wd;
+      for (int di = 0; di < s.Cin; ++di) {
+        const size_t fi = (((size_t)fh * s.fw + fw) * s.Cin + di) * s.Cout + od;
+        if (!oob && !(zero && zero[fi])) {
+          const uint32_t v = (uint32_t)in[(((size_t)ih * s.Wd + iw) * s.Cin + di) * W + w];
+          acc += sign[fi] ? v : (0u - v);
+        } else if (zero && zero[fi]) {
+          ++nzero;  // reference order: ternary-zero test precedes the padding branch
+        } else {
+          ++npad;
+        }
+      }
+    }
+  }
+  if (w == W - 1) {
+    acc += nzero * (uint32_t)zero_tap_b + npad * (uint32_t)pad_tap_b;
+    if (bias_b) acc += (uint32_t)bias_b[od % bias_depth];
+  }
+  out[(((size_t)oh * s.Wo + ow) * s.Cout + od) * W + w] = (int32_t)acc;
+}
+
+// grid (ceil(W/256), C, Ho*Wo)
+__global__ __launch_bounds__(256) void sumpool_kernel(int32_t* __restrict__ out, const int32_t* __restrict__ in, PoolShape s, int W,
+                                                      const int32_t* __restrict__ bias_b, int bias_depth) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  const int pix = blockIdx.z;
+  if (w >= W) return;
+  const int oh = pix / s.Wo, ow = pix % s.Wo;
+  uint32_t acc = 0;
+  for (int fh = 0; fh < s.win_h; ++fh) {
+    const int ih = oh * s.stride_h - s.off_h + fh;
+    if (ih < 0 || ih >= s.H) continue;
+    for (int fw = 0; fw < s.win_w; ++fw) {
+      const int iw = ow * s.stride_w - s.off_w + fw;
+      if (iw < 0 || iw >= s.Wd) continue;
+      acc += (uint32_t)in[(((size_t)ih * s.Wd + iw) * s.C + c) * W + w];
+    }
+  }
+  if (w == W - 1 && bias_b) acc += (uint32_t)bias_b[c % bias_depth];
+  out[(((size_t)oh * s.Wo + ow) * s.C + c) * W + w] = (int32_t)acc;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Launchers
+// -------------------------------------------------------------------------------------------------
+template <class C, int WPB>
+static hipError_t launch_br(const BlindRotateArgs& a, hipStream_t st) {
+  const long blocks = (a.B + WPB - 1) / WPB;
+  hipLaunchKernelGGL((blind_rotate_kernel<C, WPB>), dim3((unsigned)blocks), dim3(64 * WPB), 0, st, a);
+  return hipGetLastError();
+}
+
+template <class C>
+static hipError_t launch_br_cfg(const BlindRotateArgs& a, int wpb, hipStream_t st) {
+  switch (wpb) {
+    case 1: return launch_br<C, 1>(a, st);
+    case 2: return launch_br<C, 2>(a, st);
+    case 4: return launch_br<C, 4>(a, st);
+    default: return launch_br<C, 8>(a, st);
+  }
+}
+
+hipError_t launch_blind_rotate(int cfg, const BlindRotateArgs& a, int wpb, hipStream_t st) {
+  if (a.B <= 0) return hipSuccess;
+  return cfg == 0 ? launch_br_cfg<CfgDefault128>(a, wpb, st) : launch_br_cfg<CfgRedsecV2>(a, wpb, st);
+}
+
+hipError_t launch_bk_transform(int cfg, const int32_t* bk, double* bk_ntt, const double* tw, Field f, double ninv, long n_polys,
+                               hipStream_t st) {
+  constexpr int WPB = 4;
+  const long blocks = (n_polys + WPB - 1) / WPB;
+  if (cfg == 0)
+    hipLaunchKernelGGL((bk_transform_kernel<CfgDefault128, WPB>), dim3((unsigned)blocks), dim3(64 * WPB), 0, st, bk, bk_ntt, tw, f, ninv, n_polys);
+  else
+    hipLaunchKernelGGL((bk_transform_kernel<CfgRedsecV2, WPB>), dim3((unsigned)blocks), dim3(64 * WPB), 0, st, bk, bk_ntt, tw, f, ninv, n_polys);
+  return hipGetLastError();
+}
+
+hipError_t launch_keyswitch(const KeyswitchArgs& a, hipStream_t st) {
+  if (a.B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(keyswitch_kernel, dim3((unsigned)a.B), dim3(KS_THREADS), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_polymul(int cfg, const int32_t* a_small, const int32_t* b_torus, int32_t* out, const double* tw, Field f,
+                          double ninv, long count, hipStream_t st) {
+  constexpr int WPB = 4;
+  const long blocks = (count + WPB - 1) / WPB;
+  if (cfg == 0)
+    hipLaunchKernelGGL((polymul_kernel<CfgDefault128, WPB>), dim3((unsigned)blocks), dim3(64 * WPB), 0, st, a_small, b_torus, out, tw, f, ninv, count);
+  else
+    hipLaunchKernelGGL((polymul_kernel<CfgRedsecV2, WPB>), dim3((unsigned)blocks), dim3(64 * WPB), 0, st, a_small, b_torus, out, tw, f, ninv, count);
+  return hipGetLastError();
+}
+
+hipError_t launch_lincomb(int32_t* out, const int32_t* x, int32_t cx, const int32_t* y, int32_t cy, int32_t bconst, int W, long B,
+                          hipStream_t st) {
+  const long total = B * W;
+  if (total <= 0) return hipSuccess;
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out, x, cx, y, cy, bconst, W, total);
+  return hipGetLastError();
+}
+
+hipError_t launch_linear_fc(int32_t* out, const int32_t* in, const uint8_t* sign, const uint8_t* zero, int K, int M, int W,
+                            int32_t zero_tap_b, const int32_t* bias_b, int bias_depth, hipStream_t st) {
+  hipLaunchKernelGGL(linear_fc_kernel, dim3((W + 255) / 256, M), dim3(256), 0, st, out, in, sign, zero, K, M, W, zero_tap_b, bias_b,
+                     bias_depth);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv_ternary(int32_t* out, const int32_t* in, const uint8_t* sign, const uint8_t* zero, const ConvShape& s, int W,
+                               int32_t zero_tap_b, int32_t pad_tap_b, const int32_t* bias_b, int bias_depth, hipStream_t st) {
+  hipLaunchKernelGGL(conv_ternary_kernel, dim3((W + 255) / 256, s.Cout, s.Ho * s.Wo), dim3(256), 0, st, out, in, sign, zero, s, W,
+                     zero_tap_b, pad_tap_b, bias_b, bias_depth);
+  return hipGetLastError();
+}
+
+hipError_t launch_sumpool(int32_t* out, const int32_t* in, const PoolShape& s, int W, const int32_t* bias_b, int bias_depth,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(sumpool_kernel, dim3((W + 255) / 256, s.C, s.Ho * s.Wo), dim3(256), 0, st, out, in, s, W, bias_b, bias_depth);
+  return hipGetLastError();
+}
+
+}  // namespace rs

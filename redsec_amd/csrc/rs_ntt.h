@@ -1,0 +1,232 @@
+// rs_ntt.h -- exact negacyclic N=1024 transform for one 64-lane wavefront, FP64 registers.
+//
+// Why FP64: measured on MI355X (profiles/valu_rates_r01.jsonl) every FP64 VALU op (fma/mul/add/rndne)
+// issues at ~4.25 cycles per wave64 per SIMD -- the same as v_mul_lo_u32 / v_mul_hi_u32 /
+// v_mad_u64_u32 -- so one modular butterfly over a ~51-bit prime costs 8 FP64 ops (34 cycles) versus
+// 74 cycles for a two-prime 32-bit RNS butterfly and 138 cycles for a 64-bit Goldilocks butterfly.
+// All values are integers held in doubles; every operation below is exact (see "Exactness").
+//
+// What it replaces: the double-precision Lagrange FFT inside TFHE's tGswFFTExternMulToTLwe, reached
+// from REDsec at /root/reference/lib/BinOps_enc.cpp:185,191 (tfhe_bootstrap_FFT) and the boots*
+// gates (BinOps_enc.cpp:49-52,104-113,153-166,205).
+//
+// Structure (one wavefront = one polynomial, 16 coefficients per lane, three register layouts):
+//   layout A: register r of lane L holds index j = L + 64 r      (index bits 9..6 in-lane)
+//   layout B: register s of lane L holds j = 64 (L>>2) + 4 s + (L&3)   (bits 5..2 in-lane)
+//   layout C: register u of lane L holds j = 16 L + u            (bits 3..0 in-lane)
+// Forward (merged-twist Cooley-Tukey, natural -> bit-reversed): stages 0-3 in A, LDS transpose,
+// stages 4-7 in B, LDS transpose, stages 8-9 in C. Inverse (Gentleman-Sande) mirrors it C -> B -> A.
+// The 1/N factor is folded into the pre-transformed bootstrapping key.
+//
+// Exactness. Let f.p = p, |w| <= p/2 for every table entry, y an integer double with |y| = c p.
+//   mulmod(y, w): h = fl(w y), l = w y - h (exact, FMA), q = rint(fl(h pinv)), r = h - q p (exact:
+//   an integer below 2^53), result r + l == w y (mod p) with |result| <= p (0.5 + 1.5 c p 2^-53).
+// Sums/differences of integers stay exact below 2^53, so a schedule of full reductions
+// (reduce(x) = x - rint(x pinv) p, |result| <= p/2 + 1) is chosen per parameter set such that no
+// intermediate exceeds 2^53; rs::validate_schedule() re-derives the chain at context creation.
+#pragma once
+
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define RS_HD __host__ __device__ __forceinline__
+#else
+#define RS_HD inline
+#endif
+
+namespace rs {
+
+constexpr int kN = 1024;      // ring degree handled by one wavefront
+constexpr int kLanes = 64;
+constexpr int kRegs = 16;     // coefficients per lane
+constexpr int kBufDoubles = 1152;  // LDS exchange buffer per wavefront (padded)
+
+struct Field {
+  double p;     // prime, p = 1 (mod 2048)
+  double pinv;  // fl(1/p)
+};
+
+RS_HD double f_reduce(double x, const Field& f) {
+  double q = __builtin_rint(x * f.pinv);
+  return __builtin_fma(-q, f.p, x);
+}
+
+// w must satisfy |w| <= p/2 (a reduced table entry / key coefficient).
+RS_HD double f_mulmod(double y, double w, const Field& f) {
+  double h = w * y;
+  double l = __builtin_fma(w, y, -h);
+  double q = __builtin_rint(h * f.pinv);
+  return __builtin_fma(-q, f.p, h) + l;
+}
+
+// LDS positions (in doubles) of coefficient j for the two transposes; the padding makes the
+// ds_read_b64 of layout B and the 16-byte reads of layout C bank-conflict free.
+RS_HD int pos_t1(int j) { return j + 4 * (j >> 6); }
+RS_HD int pos_t2(int j) { return j + 2 * (j >> 4); }
+
+// Reduction schedule: bit s of FWD_MASK = full reduction after forward stage s (0..9);
+// bit s of INV_MASK = full reduction after inverse stage s. The inverse always reduces its input
+// and its output.
+template <int L_, int BGBIT_, unsigned FWD_MASK_, unsigned INV_MASK_>
+struct Cfg {
+  static constexpr int L = L_;
+  static constexpr int BGBIT = BGBIT_;
+  static constexpr unsigned FWD_MASK = FWD_MASK_;
+  static constexpr unsigned INV_MASK = INV_MASK_;
+};
+// TFHE default-128: l=3, Bgbit=7 -> prime 2^50.61 (headroom 2^53/p = 5.2).
+using CfgDefault128 = Cfg<3, 7, (1u << 4) | (1u << 8), (1u << 2) | (1u << 5) | (1u << 8)>;
+// REDsec redsec_params_small_v2: l=10, Bgbit=3 -> prime 2^48.35 (headroom 25).
+using CfgRedsecV2 = Cfg<10, 3, 0u, (1u << 4)>;
+
+// ---------------------------------------------------------------------------------------------
+// Forward transform phases. tw = psi^bitrev(i) table (1024 centered doubles), buf = exchange buffer.
+// ---------------------------------------------------------------------------------------------
+template <class C>
+RS_HD void fwd_stage_regs(double (&x)[kRegs], int s, int half, const double* tw, int tw_base, int shift, const Field& f) {
+  // pairs (e, e+half), twiddle index tw_base + (e >> shift)
+#pragma unroll
+  for (int e = 0; e < kRegs; ++e) {
+    if (e & half) continue;
+    const double w = tw[tw_base + (e >> shift)];
+    const double v = f_mulmod(x[e + half], w, f);
+    const double u = x[e];
+    x[e] = u + v;
+    x[e + half] = u - v;
+  }
+  if (C::FWD_MASK & (1u << s)) {
+#pragma unroll
+    for (int e = 0; e < kRegs; ++e) x[e] = f_reduce(x[e], f);
+  }
+}
+
+// F1: stages 0..3 on layout A, then store for transpose 1.
+template <class C>
+RS_HD void fwd_F1(int lane, double (&x)[kRegs], const double* tw, double* buf, const Field& f) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) fwd_stage_regs<C>(x, s, 8 >> s, tw, 1 << s, 4 - s, f);
+#pragma unroll
+  for (int r = 0; r < kRegs; ++r) buf[lane + 68 * r] = x[r];
+}
+// F2: load layout B, stages 4..7.
+template <class C>
+RS_HD void fwd_F2(int lane, double (&x)[kRegs], const double* tw, const double* buf, const Field& f) {
+  const int b = lane >> 2, q = lane & 3;
+#pragma unroll
+  for (int s = 0; s < kRegs; ++s) x[s] = buf[68 * b + 4 * s + q];
+#pragma unroll
+  for (int s = 4; s < 8; ++s) fwd_stage_regs<C>(x, s, 8 >> (s - 4), tw, (1 << s) + (b << (s - 4)), 8 - s, f);
+}
+// F3: store for transpose 2.
+RS_HD void fwd_F3(int lane, const double (&x)[kRegs], double* buf) {
+  const int b = lane >> 2, q = lane & 3;
+#pragma unroll
+  for (int s = 0; s < kRegs; ++s) buf[72 * b + 4 * s + q + 2 * (s >> 2)] = x[s];
+}
+// F4: load layout C, stages 8..9. Output: x[u] = transform value at position 16*lane + u.
+template <class C>
+RS_HD void fwd_F4(int lane, double (&x)[kRegs], const double* tw, const double* buf, const Field& f) {
+#pragma unroll
+  for (int u = 0; u < kRegs; ++u) x[u] = buf[18 * lane + u];
+  fwd_stage_regs<C>(x, 8, 2, tw, 256 + 4 * lane, 2, f);
+  fwd_stage_regs<C>(x, 9, 1, tw, 512 + 8 * lane, 1, f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Inverse transform phases. twi = psi^-bitrev(i) table.
+// ---------------------------------------------------------------------------------------------
+template <class C>
+RS_HD void inv_stage_regs(double (&x)[kRegs], int s, int half, const double* twi, int tw_base, int shift, const Field& f) {
+#pragma unroll
+  for (int e = 0; e < kRegs; ++e) {
+    if (e & half) continue;
+    const double w = twi[tw_base + (e >> shift)];
+    const double u = x[e], v = x[e + half];
+    x[e] = u + v;
+    x[e + half] = f_mulmod(u - v, w, f);
+  }
+  if (C::INV_MASK & (1u << s)) {
+#pragma unroll
+    for (int e = 0; e < kRegs; ++e) x[e] = f_reduce(x[e], f);
+  }
+}
+
+// I1: reduce the pointwise sums, stages 0..1 on layout C, store (transpose 2 positions).
+template <class C>
+RS_HD void inv_I1(int lane, double (&x)[kRegs], const double* twi, double* buf, const Field& f) {
+#pragma unroll
+  for (int u = 0; u < kRegs; ++u) x[u] = f_reduce(x[u], f);
+  inv_stage_regs<C>(x, 0, 1, twi, 512 + 8 * lane, 1, f);
+  inv_stage_regs<C>(x, 1, 2, twi, 256 + 4 * lane, 2, f);
+#pragma unroll
+  for (int u = 0; u < kRegs; ++u) buf[18 * lane + u] = x[u];
+}
+// I2: load layout B, stages 2..5.
+template <class C>
+RS_HD void inv_I2(int lane, double (&x)[kRegs], const double* twi, const double* buf, const Field& f) {
+  const int b = lane >> 2, q = lane & 3;
+#pragma unroll
+  for (int s = 0; s < kRegs; ++s) x[s] = buf[72 * b + 4 * s + q + 2 * (s >> 2)];
+#pragma unroll
+  for (int s = 2; s < 6; ++s) inv_stage_regs<C>(x, s, 1 << (s - 2), twi, (512 >> s) + (b << (5 - s)), s - 1, f);
+}
+// I3: store (transpose 1 positions).
+RS_HD void inv_I3(int lane, const double (&x)[kRegs], double* buf) {
+  const int b = lane >> 2, q = lane & 3;
+#pragma unroll
+  for (int s = 0; s < kRegs; ++s) buf[68 * b + 4 * s + q] = x[s];
+}
+// I4: load layout A, stages 6..9, final reduction to the centered residue.
+template <class C>
+RS_HD void inv_I4(int lane, double (&x)[kRegs], const double* twi, const double* buf, const Field& f) {
+#pragma unroll
+  for (int r = 0; r < kRegs; ++r) x[r] = buf[lane + 68 * r];
+#pragma unroll
+  for (int s = 6; s < 10; ++s) inv_stage_regs<C>(x, s, 1 << (s - 6), twi, 512 >> s, s - 5, f);
+#pragma unroll
+  for (int r = 0; r < kRegs; ++r) x[r] = f_reduce(x[r], f);
+}
+
+// Integer-valued double with |v| < 2^51 -> v mod 2^32 (two's complement), via the 1.5*2^52 shift.
+RS_HD int32_t f_to_torus32(double v) {
+  const double t = v + 6755399441055744.0;
+  long long bits;
+  __builtin_memcpy(&bits, &t, sizeof(bits));
+  return (int32_t)(uint32_t)(unsigned long long)bits;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CMUX pieces shared by the kernel and the host emulator.
+// ---------------------------------------------------------------------------------------------
+// modSwitchFromTorus32(a, 2N) for N = 1024: ((a << 32) + 2^52) >> 53 with 64-bit wrap-around.
+RS_HD int32_t modswitch_2N(int32_t a) { return (int32_t)(((uint32_t)a + (1u << 20)) >> 21); }
+
+// d_j = ((X^a - 1) * acc)_j for 0 < a < 2N (torusPolynomialMulByXaiMinusOne).
+RS_HD int32_t rotated_diff(const int32_t* acc, int j, int a) {
+  const int aa = a & (kN - 1), nb = (a >> 10) & 1;
+  const int idx = (j - aa) & (kN - 1);
+  const int neg = (j < aa ? 1 : 0) ^ nb;
+  const uint32_t v = (uint32_t)acc[idx];
+  return (int32_t)((neg ? (0u - v) : v) - (uint32_t)acc[j]);
+}
+// j-th coefficient of X^a * (mu, mu, ..., mu) for 0 < a <= 2N (torusPolynomialMulByXai).
+RS_HD int32_t rotated_const(int32_t mu, int j, int a) {
+  const int aa = a & (kN - 1), nb = (a >> 10) & 1;
+  const int neg = (j < aa ? 1 : 0) ^ nb;
+  return neg ? (int32_t)(0u - (uint32_t)mu) : mu;
+}
+// gadget digit q (0-based) of coefficient d (tGswTorus32PolynomialDecompH).
+template <class C>
+RS_HD int32_t gadget_digit(int32_t d, int q, uint32_t offset) {
+  const uint32_t u = (uint32_t)d + offset;
+  const int decal = 32 - (q + 1) * C::BGBIT;
+  return (int32_t)((u >> decal) & ((1u << C::BGBIT) - 1u)) - (1 << (C::BGBIT - 1));
+}
+template <class C>
+constexpr uint32_t gadget_offset() {
+  uint32_t off = 0;
+  for (int i = 1; i <= C::L; ++i) off += (1u << (C::BGBIT - 1)) << (32 - i * C::BGBIT);
+  return off;
+}
+
+}  // namespace rs

@@ -1,0 +1,64 @@
+"""The C-ABI library loads on a CPU-only machine, exports every symbol include/redsec_hip.h
+declares, and refuses to compute without a GPU (no CPU fallback in the product path)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import redsec_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "redsec_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    L = redsec_amd.load_library()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(L, name), "libredsec_hip.so does not export " + name
+    assert sorted(redsec_amd.ABI_SYMBOLS) == declared
+
+
+def test_parameter_sets():
+    d = redsec_amd.params("default128")
+    assert (d.n, d.N, d.k, d.bk_l, d.bk_Bgbit, d.ks_t, d.ks_basebit) == (630, 1024, 1, 3, 7, 8, 2)
+    r = redsec_amd.params("redsec_small_v2")  # client/gen_secure_keyset.cpp:70-91
+    assert (r.n, r.N, r.k, r.bk_l, r.bk_Bgbit, r.ks_t, r.ks_basebit) == (350, 1024, 1, 10, 3, 9, 3)
+
+
+def test_rejects_unsupported_parameters():
+    L = redsec_amd.load_library()
+    p = redsec_amd.params("default128")
+    p.N = 2048
+    h = ctypes.c_void_p()
+    assert L.rs_create(ctypes.byref(h), ctypes.byref(p), 0) == -1
+    assert b"unsupported ring" in L.rs_last_error()
+    p = redsec_amd.params("default128")
+    p.bk_l = 4
+    assert L.rs_create(ctypes.byref(h), ctypes.byref(p), 0) == -1
+    assert b"unsupported gadget" in L.rs_last_error()
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(redsec_amd.RedsecHipError, match="no HIP device"):
+        redsec_amd.Backend(redsec_amd.params("default128"))
+
+
+def test_product_does_not_reference_oracle():
+    """The product package must not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "redsec_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "redsec_oracle" not in src and "oracle_lib" not in src, f

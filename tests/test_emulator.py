@@ -1,0 +1,84 @@
+"""CPU parity of the kernel logic: the HIP phase functions (redsec_amd/csrc/rs_ntt.h) executed
+lane-by-lane on the host must reproduce the oracle bit-for-bit. This checks the transform's index
+mapping, the exactness of the FP64 field arithmetic and the CMUX bookkeeping without a GPU."""
+import numpy as np
+import pytest
+
+import emu_lib
+import oracle_lib as ol
+
+ALPHA = 2.0 ** -15
+
+
+@pytest.mark.parametrize("cfg", [0, 1])
+def test_schedule_is_provably_exact(cfg):
+    rc, msg = emu_lib.validate(cfg)
+    assert rc == 0, msg
+    p = emu_lib.lib().rs_emu_prime(cfg)
+    l, bg = (3, 7) if cfg == 0 else (10, 3)
+    bound = 2 * l * 1024 * (1 << (bg - 1)) * (1 << 31)
+    assert p % 2048 == 1 and p > 2 * bound
+
+
+@pytest.mark.parametrize("cfg,half", [(0, 64), (1, 4)])
+def test_polymul_matches_schoolbook(cfg, half):
+    rng = np.random.default_rng(10 + cfg)
+    cases = []
+    for _ in range(6):
+        cases.append((rng.integers(-half, half, 1024), rng.integers(-2**31, 2**31, 1024)))
+    cases.append((np.full(1024, -half), np.full(1024, -2**31)))                      # largest magnitudes
+    cases.append((np.full(1024, half - 1), np.full(1024, 2**31 - 1)))
+    alt = np.where(np.arange(1024) % 2 == 0, -half, half - 1)
+    cases.append((alt, np.where(np.arange(1024) % 3 == 0, -2**31, 2**31 - 1)))
+    e = np.zeros(1024); e[1023] = -half
+    f = np.zeros(1024); f[1023] = -2**31
+    cases.append((e, f))
+    cases.append((np.zeros(1024), rng.integers(-2**31, 2**31, 1024)))
+    for a, b in cases:
+        a = a.astype(np.int32); b = b.astype(np.int32)
+        assert np.array_equal(emu_lib.polymul(cfg, a, b), ol.negacyclic_mul(a, b, "schoolbook"))
+
+
+@pytest.mark.parametrize("cfg", [0, 1])
+def test_forward_transform_is_linear_mod_p(cfg):
+    p = int(emu_lib.lib().rs_emu_prime(cfg))
+    rng = np.random.default_rng(cfg)
+    a = rng.integers(-2**20, 2**20, 1024).astype(np.int32)
+    b = rng.integers(-2**20, 2**20, 1024).astype(np.int32)
+    fa = emu_lib.forward(cfg, a); fb = emu_lib.forward(cfg, b); fs = emu_lib.forward(cfg, a + b)
+    for x, y, z in zip(fa[:64], fb[:64], fs[:64]):
+        assert (int(x) + int(y) - int(z)) % p == 0
+    assert np.all(np.abs(fa) < 2.0 ** 53) and np.all(fa == np.rint(fa))
+
+
+@pytest.mark.parametrize("cfg,fixture", [(0, "toy_default"), (1, "toy_redsec")])
+def test_blind_rotate_matches_oracle(cfg, fixture, request):
+    ks, ctx = request.getfixturevalue(fixture)
+    p = ks.p
+    mu = ol.to_torus(1, 8)
+    msgs = [mu, -mu, mu]
+    ca = ks.encrypt(msgs, ALPHA, 11)
+    cb = ks.encrypt(msgs[::-1], ALPHA, 12)
+    ref_u = ctx.bootstrap_wo_ks(ca, mu)
+    ref_acc = ctx.blind_rotate_acc(ca, mu, steps=5)
+    for i in range(len(msgs)):
+        u, _ = emu_lib.blind_rotate(cfg, p.n, ca[i], None, 1, 0, 0, mu, ks.bk)
+        assert np.array_equal(u, ref_u[i])
+        _, acc = emu_lib.blind_rotate(cfg, p.n, ca[i], None, 1, 0, 0, mu, ks.bk, steps=5)
+        assert np.array_equal(acc, ref_acc[i])
+    # fused gate pre-combination: XOR = (0,1/4) + 2(a+b)
+    tmp = ol.gate_precombine("XOR", ca, cb)
+    ref_u = ctx.bootstrap_wo_ks(tmp, mu)
+    for i in range(len(msgs)):
+        u, _ = emu_lib.blind_rotate(cfg, p.n, ca[i], cb[i], 2, 2, ol.to_torus(1, 4), mu, ks.bk)
+        assert np.array_equal(u, ref_u[i])
+
+
+def test_blind_rotate_sign_mu_4096(toy_redsec):
+    ks, ctx = toy_redsec
+    mu = ol.to_torus(1, 4096)
+    ct = ks.encrypt([ol.to_torus(m, 4096) for m in (-700, 3, 900)], ALPHA, 31)
+    ref = ctx.bootstrap_wo_ks(ct, mu)
+    for i in range(3):
+        u, _ = emu_lib.blind_rotate(1, ks.p.n, ct[i], None, 1, 0, 0, mu, ks.bk)
+        assert np.array_equal(u, ref[i])
