@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Gate-bootstrap microbenchmark (BASELINE.json configs[1]): 65,536 independent bootstrapped NANDs,
+N=1024, TFHE default 128-bit parameters (n=630, l=3, Bgbit=7, t=8, basebit=2), one MI355X per rank.
+
+A "step" is one pass of the hot path (gate pre-combination + blind rotation + sample extract +
+keyswitch) over one batch of 65,536 ciphertext pairs that are already resident in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--gates G] [--params default128|redsec_small_v2]
+
+N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL). The gates of a batch are
+independent, so ranks shard the work with no data-path collective ("weak": each rank runs its own
+65,536 gates); the only communication is the barrier and a MAX reduction of the elapsed time.
+
+Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel (blind rotation) against the HBM
+roofline as the contract asks; `roofline_valu` prices it against the FP64 vector-ALU issue rate,
+which is what actually bounds it. `cpu_baseline` is the exact-integer CPU
+oracle (kind "port": TFHE itself is not available) timed on the host cores on a bounded sample of
+the same inputs and keys, and doubles as the in-run parity check.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+FP64_VALU_PEAK_GOPS = 256 * 4 * 16 * 2.4   # CUs x SIMDs x fp64 lanes/clk x GHz = 39,322 G lane-ops/s
+
+
+def fp64_ops_per_bootstrap(n, l, fwd_red, inv_red):
+    """FP64 VALU lane-operations per bootstrap: per CMUX 2l forward and 2
+    inverse transforms of 5,120 butterflies x 8 ops, full reductions of 1,024 x 3 ops, the
+    pointwise stage 4l x 1,024 x 7 ops, digit conversion and output conversion."""
+    bfly = 5120 * 8
+    fwd = bfly + fwd_red * 1024 * 3 + 1024           # + int -> fp64 conversion
+    inv = bfly + (inv_red + 2) * 1024 * 3 + 1024     # + input/output reductions, + magic add
+    point = 4 * l * 1024 * 7
+    return n * (2 * l * fwd + 2 * inv + point)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--gates", type=int, default=65536, help="gates per rank per step")
+    ap.add_argument("--params", default="default128", choices=["default128", "redsec_small_v2"])
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="gates timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xC0FFEE)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import redsec_amd
+    from redsec_amd import client
+
+    # ---- keys (same on every rank: seeded) and synthetic inputs, resident in HBM before timing ----
+    t_setup = time.time()
+    sk = client.SecretKeySet(args.params, seed=args.seed)
+    be = redsec_amd.Backend(redsec_amd.params(args.params), device=local_rank)
+    be.load_keys(sk.bk, sk.ksk)
+    G = args.gates
+    rng = np.random.default_rng(args.seed + 17 * rank)
+    bits_a = rng.integers(0, 2, G)
+    bits_b = rng.integers(0, 2, G)
+    ca_h = sk.encrypt_bits(bits_a, seed=args.seed + 1000 + rank)
+    cb_h = sk.encrypt_bits(bits_b, seed=args.seed + 2000 + rank)
+    ca = torch.from_numpy(ca_h).to(dev)
+    cb = torch.from_numpy(cb_h).to(dev)
+    out = be.empty(G, be.W)
+    be.reserve(G)
+    torch.cuda.synchronize()
+    setup_s = time.time() - t_setup
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        be.gate("NAND", ca, cb, out=out)
+    torch.cuda.synchronize()
+
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides ----
+    be.set_timing(True)
+    br_ms, ks_ms = [], []
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        be.gate("NAND", ca, cb, out=out)
+        # HIP events recorded on the launch stream around each kernel; reading them waits for the
+        # step (one step is one ~second-long batch, so this costs nothing measurable)
+        b_ms, k_ms = be.last_kernel_ms()
+        br_ms.append(b_ms); ks_ms.append(k_ms)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    be.set_timing(False)
+    last_br = sum(br_ms) / len(br_ms)   # average launch duration over the timed region
+    last_ks = sum(ks_ms) / len(ks_ms)
+
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- correctness of the timed output: every gate decrypts to NAND(a, b) ----
+    got = out.cpu().numpy()
+    decrypt_ok = bool(np.array_equal(sk.decrypt_bits(got), 1 - (bits_a & bits_b)))
+
+    total_gates = G * world
+    value = total_gates * args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    if rank == 0:
+        p = be.p
+        info = be.info()
+        # ---- HBM roofline of the dominant kernel (blind rotation), per launch ----
+        # algorithmic bytes: key swept once per R resident ciphertexts
+        # (R = CUs x 8 waves), two input ciphertexts read, one extracted sample written.
+        R = info["num_cus"] * info["waves_per_block"]
+        bk_bytes = info["bk_device_bytes"]
+        per_boot = bk_bytes / R + 2 * be.W * 4 + (p.N + 1) * 4
+        alg_bytes = per_boot * G
+        achieved = alg_bytes / (last_br * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "blind_rotate_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                    "kernel_ms": round(last_br, 3), "algorithmic_bytes_per_launch": int(alg_bytes),
+                    "resident_ciphertexts_per_key_sweep": R}
+        fwd_red, inv_red = (2, 3) if p.bk_l == 3 else (0, 1)
+        ops = fp64_ops_per_bootstrap(p.n, p.bk_l, fwd_red, inv_red) * G
+        valu = ops / (last_br * 1e-3) / 1e9
+        roofline_valu = {"bound": "fp64-valu-issue", "achieved": round(valu, 1), "peak": round(FP64_VALU_PEAK_GOPS, 1),
+                         "unit": "G fp64 lane-ops/s", "frac": round(valu / FP64_VALU_PEAK_GOPS, 4),
+                         "fp64_ops_per_bootstrap": fp64_ops_per_bootstrap(p.n, p.bk_l, fwd_red, inv_red)}
+
+        # ---- CPU baseline + parity on a bounded sample of the same workload ----
+        cpu = None
+        parity = None
+        if args.cpu_sample != 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as ol
+            cores = ol.lib().ro_max_threads()
+            sample = args.cpu_sample if args.cpu_sample > 0 else max(32, 2 * cores)
+            sample = min(sample, G)
+            op = ol.params(args.params)
+
+            class _K:
+                pass
+            k = _K(); k.p = op; k.bk = sk.bk.ravel(); k.ksk = sk.ksk.ravel()
+            octx = ol.Ctx(k)
+            octx.gate_batch("NAND", ca_h[:min(cores, sample)], cb_h[:min(cores, sample)])  # warm caches / threads
+            t1 = time.perf_counter()
+            ref = octx.gate_batch("NAND", ca_h[:sample], cb_h[:sample])
+            cpu_s = time.perf_counter() - t1
+            parity = bool(np.array_equal(ref, got[:sample]))
+            cpu = {"value": round(sample / cpu_s, 3), "unit": "bootstraps/s", "cores": int(cores), "kind": "port",
+                   "sample": "%d NAND gates of the same batch (same keys, same inputs), %.1f s wall on %d OpenMP threads; "
+                             "exact-integer oracle, TFHE itself unavailable" % (sample, cpu_s, cores)}
+
+        line = {
+            "metric": "gate bootstraps/sec (N=1024)", "value": round(value, 1), "unit": "bootstraps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 torus (fp64-carried exact NTT)",
+            "data": "synthetic",
+            "config": {"workload": "%d independent bootstrapped NAND gates per GPU, %s (n=%d N=%d l=%d Bgbit=%d t=%d basebit=%d)"
+                                   % (G, args.params, p.n, p.N, p.bk_l, p.bk_Bgbit, p.ks_t, p.ks_basebit),
+                       "gates_per_gpu": G, "params": args.params, "parallelism": "gate-sharded x%d, no data-path collective" % world},
+            "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu,
+            "kernels_ms": {"blind_rotate": round(last_br, 3), "keyswitch": round(last_ks, 3)},
+            "checks": {"all_outputs_decrypt_to_nand": decrypt_ok, "bit_exact_vs_oracle_on_sample": parity},
+            "setup_s": round(setup_s, 1),
+        }
+        print(json.dumps(line), flush=True)
+    barrier()
+    be.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
