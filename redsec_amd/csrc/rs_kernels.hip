@@ -239,6 +239,105 @@ __global__ __launch_bounds__(KS_THREADS) void keyswitch_kernel(KeyswitchArgs a) 
 }
 
 // -------------------------------------------------------------------------------------------------
+// Tiled keyswitch (the production path for the shipped parameter sets).
+//
+// A workgroup of 4 waves owns 256 ciphertexts x KS_CH output words; lane = ciphertext. For a group
+// of KS_IG input coefficients the KSK slice [KS_IG][t][base][KS_CH] is staged in LDS once (row v=0
+// is a resident zero row), then every lane extracts its own digits and subtracts the LDS row they
+// select: one ds_read_b128 + four v_sub per four output words. Each KSK byte fetched from L2 thus
+// serves 256 ciphertexts instead of one, and the extracted samples are read once per word chunk.
+// Rows are padded by 16 B so that the <= 8 distinct rows a wave touches sit in distinct bank quads.
+// -------------------------------------------------------------------------------------------------
+constexpr int KS_CH = 32;            // output words per workgroup
+constexpr int KS_CHP = KS_CH + 4;    // padded row (words)
+constexpr int KS_TILE_THREADS = 256;
+
+template <int T, int BASEBIT, int KS_IG>  // KS_IG = input coefficients staged per round
+__global__ __launch_bounds__(KS_TILE_THREADS) void keyswitch_tiled_kernel(KeyswitchArgs a) {
+  constexpr int BASE = 1 << BASEBIT;
+  constexpr int ROWS = KS_IG * T * BASE;
+  __shared__ __attribute__((aligned(16))) int32_t s_ksk[2][ROWS * KS_CHP];
+  const int tid = threadIdx.x;
+  const long ct = (long)blockIdx.x * KS_TILE_THREADS + tid;
+  const bool live = ct < a.B;
+  const int w0 = blockIdx.y * KS_CH;
+  const int W = a.W;
+  const int32_t* u0 = a.u0 + (live ? ct : 0) * (kN + 1);
+  const int32_t* u1 = a.u1 ? a.u1 + (live ? ct : 0) * (kN + 1) : nullptr;
+
+  for (int e = tid; e < 2 * ROWS * KS_CHP; e += KS_TILE_THREADS) (&s_ksk[0][0])[e] = 0;
+
+  uint32_t acc[KS_CH];
+#pragma unroll
+  for (int k = 0; k < KS_CH; ++k) acc[k] = 0;
+
+  constexpr uint32_t prec_offset = 1u << (32 - (1 + BASEBIT * T));
+  constexpr uint32_t mask = (1u << BASEBIT) - 1u;
+  // staging: KS_IG * T * (BASE-1) row segments of KS_CH words; 8 threads x 16 B per segment
+  constexpr int SEGS = KS_IG * T * (BASE - 1);
+  auto stage = [&](int buf, int i0) {
+    for (int sidx = tid; sidx < SEGS * 8; sidx += KS_TILE_THREADS) {
+      const int seg = sidx >> 3, part = sidx & 7;
+      const int v = seg % (BASE - 1) + 1;
+      const int ij = seg / (BASE - 1);          // ii * T + j
+      const int wq = w0 + part * 4;
+      const int32_t* src = a.ksk + (((size_t)i0 * T + ij) * BASE + v) * (size_t)W + wq;
+      int32_t* dst = &s_ksk[buf][(ij * BASE + v) * KS_CHP + part * 4];
+      if (wq + 3 < W) {
+        // rows are only 4-byte aligned in general (W odd): assemble from scalar loads
+        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e] = (wq + e < W) ? src[e] : 0;
+      }
+    }
+  };
+
+  __syncthreads();
+  stage(0, 0);
+  __syncthreads();
+  for (int g = 0; g < kN / KS_IG; ++g) {
+    const int buf = g & 1;
+    if (g + 1 < kN / KS_IG) stage(buf ^ 1, (g + 1) * KS_IG);
+    const int i0 = g * KS_IG;
+    uint32_t ai[KS_IG];
+#pragma unroll
+    for (int ii = 0; ii < KS_IG; ++ii) {
+      uint32_t v = live ? (uint32_t)u0[i0 + ii] : 0u;
+      if (u1 && live) v += (uint32_t)u1[i0 + ii];
+      ai[ii] = live ? v + prec_offset : 0u;
+    }
+#pragma unroll
+    for (int ii = 0; ii < KS_IG; ++ii) {
+#pragma unroll
+      for (int j = 0; j < T; ++j) {
+        const uint32_t dgt = (ai[ii] >> (32 - (j + 1) * BASEBIT)) & mask;
+        const int4* row = reinterpret_cast<const int4*>(&s_ksk[buf][((ii * T + j) * BASE + (int)dgt) * KS_CHP]);
+#pragma unroll
+        for (int q = 0; q < KS_CH / 4; ++q) {
+          const int4 r = row[q];
+          acc[4 * q + 0] += (uint32_t)r.x;
+          acc[4 * q + 1] += (uint32_t)r.y;
+          acc[4 * q + 2] += (uint32_t)r.z;
+          acc[4 * q + 3] += (uint32_t)r.w;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (!live) return;
+  uint32_t bw = (uint32_t)u0[kN];
+  if (u1) bw += (uint32_t)u1[kN];
+  bw += (uint32_t)a.bconst;
+  int32_t* out = a.out + ct * W + w0;
+#pragma unroll
+  for (int k = 0; k < KS_CH; ++k) {
+    const int w = w0 + k;
+    if (w < W) out[k] = (int32_t)((w == W - 1 ? bw : 0u) - acc[k]);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
 // Debug tap: out = a_small * b_torus (negacyclic, mod 2^32) through forward/pointwise/inverse.
 // -------------------------------------------------------------------------------------------------
 template <class C, int WPB>
@@ -402,7 +501,14 @@ hipError_t launch_bk_transform(int cfg, const int32_t* bk, double* bk_ntt, const
 
 hipError_t launch_keyswitch(const KeyswitchArgs& a, hipStream_t st) {
   if (a.B <= 0) return hipSuccess;
-  hipLaunchKernelGGL(keyswitch_kernel, dim3((unsigned)a.B), dim3(KS_THREADS), 0, st, a);
+  const dim3 grid((unsigned)((a.B + KS_TILE_THREADS - 1) / KS_TILE_THREADS), (unsigned)((a.W + KS_CH - 1) / KS_CH));
+  if (a.t == 8 && a.basebit == 2) {
+    hipLaunchKernelGGL((keyswitch_tiled_kernel<8, 2, 4>), grid, dim3(KS_TILE_THREADS), 0, st, a);
+  } else if (a.t == 9 && a.basebit == 3) {
+    hipLaunchKernelGGL((keyswitch_tiled_kernel<9, 3, 2>), grid, dim3(KS_TILE_THREADS), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(keyswitch_kernel, dim3((unsigned)a.B), dim3(KS_THREADS), 0, st, a);  // generic gather form
+  }
   return hipGetLastError();
 }
 

@@ -111,6 +111,11 @@ def params(name):
         # reduced-n variant of default128 for fast tests: same ring, gadget and keyswitch shape
         lib().ro_params_default128(C.byref(p))
         p.n = 24
+    elif name == "toy_ks6":
+        # non-standard keyswitch shape: exercises the generic (gather) keyswitch kernel
+        lib().ro_params_default128(C.byref(p))
+        p.n = 24
+        p.ks_t = 6
     elif name == "toy_redsec":
         lib().ro_params_redsec_small_v2(C.byref(p))
         p.n = 20

@@ -95,6 +95,33 @@ def test_toy_all_gates_and_mux(which, fix, request):
     assert np.array_equal(got, ctx.mux_batch(ca, cb, cc))
 
 
+@pytest.mark.parametrize("which,fix", [("be_toy_default", "toy_default"), ("be_toy_redsec", "toy_redsec")])
+def test_keyswitch_tile_boundaries(which, fix, request):
+    """Tiled keyswitch: 256-ciphertext tiles, 32-word chunks (W = 25 / 21 here: one partial chunk);
+    batches straddling a tile, and the summed-input form used by bootsMUX."""
+    be = request.getfixturevalue(which)
+    ks, ctx = request.getfixturevalue(fix)
+    rng = np.random.default_rng(3)
+    for B in (255, 256, 257, 300):
+        u = rng.integers(-2**31, 2**31, (B, 1025)).astype(np.int32)
+        assert np.array_equal(be.keyswitch(_dev(u)).cpu().numpy(), ctx.keyswitch(u)), B
+
+
+def test_generic_keyswitch_shape():
+    """ks_t = 6 is not one of the tiled instantiations: the generic gather kernel must agree too."""
+    import redsec_amd
+    p = ol.params("toy_ks6")
+    ks = ol.KeySet(p, seed=9)
+    ctx = ol.Ctx(ks)
+    rp = redsec_amd.params("default128", n=p.n)
+    rp.ks_t = 6
+    be = redsec_amd.Backend(rp, device=0)
+    be.load_keys(ks.bk, ks.ksk)
+    _, ca = _bits(ks, 19, 1)
+    _, cb = _bits(ks, 19, 2)
+    assert np.array_equal(be.gate("XNOR", _dev(ca), _dev(cb)).cpu().numpy(), ctx.gate_batch("XNOR", ca, cb))
+
+
 def test_empty_batch_and_host_api(be_toy_default, toy_default):
     be = be_toy_default
     ks, ctx = toy_default
