@@ -1,0 +1,42 @@
+"""Multi-GPU sharding of an independent-ciphertext stage (one process per GPU).
+
+Every bootstrap of a layer stage is independent of every other one (the reference's loop at
+lib/BinFunc.cpp:1056-1071 has no cross-iteration dependence), so ranks take contiguous slices of the
+batch with full key replicas and no data-path collective; the only exchange is the gather of the
+slices before the next linear stage (which needs the whole bit vector) or of the logits of
+image-parallel replicas. Works on any torch.distributed backend: "nccl" (= RCCL over xGMI) on the
+GPUs, "gloo" in the CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total, rank, world):
+    """Contiguous, balanced slice [lo, hi) of `total` rows for `rank`; sizes differ by at most 1."""
+    base, rem = divmod(int(total), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_rows(local, total, group=None):
+    """Concatenate per-rank row slices (made with shard_range) into the full [total][...] tensor on
+    every rank. Ragged slices are padded to the largest one for the collective."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    sizes = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
+    width = max(sizes)
+    pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
+
+
+def sharded_stage(fn, batch, group=None):
+    """Run `fn(rows)` on this rank's slice of `batch` ([B][...]) and return the gathered [B][...]."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_range(batch.shape[0], rank, world)
+    out = fn(batch[lo:hi].contiguous())
+    return all_gather_rows(out, batch.shape[0], group) if world > 1 else out
