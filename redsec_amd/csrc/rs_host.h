@@ -42,7 +42,7 @@ inline uint32_t bitrev10(uint32_t x) {
 
 struct Tables {
   Field f;
-  std::vector<double> tw;   // [0..1023] psi^bitrev(i), [1024..2047] psi^-bitrev(i), centered
+  std::vector<double> tw;   // [tw_pos(i)] psi^bitrev(i), [1024 + tw_pos(i)] psi^-bitrev(i), centered
   double ninv;              // N^-1 mod p, centered
 };
 
@@ -54,8 +54,9 @@ inline Tables make_tables(const PrimeSpec& ps) {
   const uint64_t psi_inv = powmod_u64(ps.psi, ps.p - 2, ps.p);
   for (uint32_t i = 0; i < (uint32_t)kN; ++i) {
     const uint32_t r = bitrev10(i);
-    t.tw[i] = centered(powmod_u64(ps.psi, r, ps.p), ps.p);
-    t.tw[kN + i] = centered(powmod_u64(psi_inv, r, ps.p), ps.p);
+    const int pos = i == 0 ? 0 : tw_pos((int)i);   // stage-transposed layout (rs_ntt.h)
+    t.tw[pos] = centered(powmod_u64(ps.psi, r, ps.p), ps.p);
+    t.tw[kN + pos] = centered(powmod_u64(psi_inv, r, ps.p), ps.p);
   }
   t.ninv = centered(powmod_u64((uint64_t)kN, ps.p - 2, ps.p), ps.p);
   return t;

@@ -59,6 +59,22 @@ RS_HD double f_mulmod(double y, double w, const Field& f) {
   return __builtin_fma(-q, f.p, h) + l;
 }
 
+// Position of table entry idx (= m + i of the textbook psi_rev[m + i] indexing, m = 2^stage) in the
+// stage-transposed tables the kernels read. Stages 0-3 are wave-uniform (unchanged). In stages 4-7
+// entry m + b*E + e (b = lane>>2, E = m/16) moves to m + e*16 + b, and in stages 8-9 entry
+// m + lane*E + e (E = m/64) moves to m + e*64 + lane, so that for a fixed register index e
+// consecutive lanes read consecutive doubles: bank-conflict-free ds_read_b64 (the untransposed
+// tables cost 24 % of all LDS cycles in conflicts, profiles/r01/pmc).
+RS_HD int tw_pos(int idx) {
+  int s = 0;
+  while ((2 << s) <= idx) ++s;
+  const int m = 1 << s, off = idx - m;
+  if (s <= 3) return idx;
+  if (s <= 7) { const int E = m >> 4; return m + (off % E) * 16 + off / E; }
+  const int E = m >> 6;
+  return m + (off % E) * 64 + off / E;
+}
+
 // LDS positions (in doubles) of coefficient j for the two transposes; the padding makes the
 // ds_read_b64 of layout B and the 16-byte reads of layout C bank-conflict free.
 RS_HD int pos_t1(int j) { return j + 4 * (j >> 6); }
@@ -83,12 +99,12 @@ using CfgRedsecV2 = Cfg<10, 3, 0u, (1u << 4)>;
 // Forward transform phases. tw = psi^bitrev(i) table (1024 centered doubles), buf = exchange buffer.
 // ---------------------------------------------------------------------------------------------
 template <class C>
-RS_HD void fwd_stage_regs(double (&x)[kRegs], int s, int half, const double* tw, int tw_base, int shift, const Field& f) {
-  // pairs (e, e+half), twiddle index tw_base + (e >> shift)
+RS_HD void fwd_stage_regs(double (&x)[kRegs], int s, int half, const double* tw, int tw_base, int shift, int stride, const Field& f) {
+  // pairs (e, e+half), twiddle at tw_base + (e >> shift) * stride (stage-transposed table, see tw_pos)
 #pragma unroll
   for (int e = 0; e < kRegs; ++e) {
     if (e & half) continue;
-    const double w = tw[tw_base + (e >> shift)];
+    const double w = tw[tw_base + (e >> shift) * stride];
     const double v = f_mulmod(x[e + half], w, f);
     const double u = x[e];
     x[e] = u + v;
@@ -104,7 +120,7 @@ RS_HD void fwd_stage_regs(double (&x)[kRegs], int s, int half, const double* tw,
 template <class C>
 RS_HD void fwd_F1(int lane, double (&x)[kRegs], const double* tw, double* buf, const Field& f) {
 #pragma unroll
-  for (int s = 0; s < 4; ++s) fwd_stage_regs<C>(x, s, 8 >> s, tw, 1 << s, 4 - s, f);
+  for (int s = 0; s < 4; ++s) fwd_stage_regs<C>(x, s, 8 >> s, tw, 1 << s, 4 - s, 1, f);
 #pragma unroll
   for (int r = 0; r < kRegs; ++r) buf[lane + 68 * r] = x[r];
 }
@@ -115,7 +131,7 @@ RS_HD void fwd_F2(int lane, double (&x)[kRegs], const double* tw, const double* 
 #pragma unroll
   for (int s = 0; s < kRegs; ++s) x[s] = buf[68 * b + 4 * s + q];
 #pragma unroll
-  for (int s = 4; s < 8; ++s) fwd_stage_regs<C>(x, s, 8 >> (s - 4), tw, (1 << s) + (b << (s - 4)), 8 - s, f);
+  for (int s = 4; s < 8; ++s) fwd_stage_regs<C>(x, s, 8 >> (s - 4), tw, (1 << s) + b, 8 - s, 16, f);
 }
 // F3: store for transpose 2.
 RS_HD void fwd_F3(int lane, const double (&x)[kRegs], double* buf) {
@@ -128,19 +144,19 @@ template <class C>
 RS_HD void fwd_F4(int lane, double (&x)[kRegs], const double* tw, const double* buf, const Field& f) {
 #pragma unroll
   for (int u = 0; u < kRegs; ++u) x[u] = buf[18 * lane + u];
-  fwd_stage_regs<C>(x, 8, 2, tw, 256 + 4 * lane, 2, f);
-  fwd_stage_regs<C>(x, 9, 1, tw, 512 + 8 * lane, 1, f);
+  fwd_stage_regs<C>(x, 8, 2, tw, 256 + lane, 2, 64, f);
+  fwd_stage_regs<C>(x, 9, 1, tw, 512 + lane, 1, 64, f);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Inverse transform phases. twi = psi^-bitrev(i) table.
 // ---------------------------------------------------------------------------------------------
 template <class C>
-RS_HD void inv_stage_regs(double (&x)[kRegs], int s, int half, const double* twi, int tw_base, int shift, const Field& f) {
+RS_HD void inv_stage_regs(double (&x)[kRegs], int s, int half, const double* twi, int tw_base, int shift, int stride, const Field& f) {
 #pragma unroll
   for (int e = 0; e < kRegs; ++e) {
     if (e & half) continue;
-    const double w = twi[tw_base + (e >> shift)];
+    const double w = twi[tw_base + (e >> shift) * stride];
     const double u = x[e], v = x[e + half];
     x[e] = u + v;
     x[e + half] = f_mulmod(u - v, w, f);
@@ -156,8 +172,8 @@ template <class C>
 RS_HD void inv_I1(int lane, double (&x)[kRegs], const double* twi, double* buf, const Field& f) {
 #pragma unroll
   for (int u = 0; u < kRegs; ++u) x[u] = f_reduce(x[u], f);
-  inv_stage_regs<C>(x, 0, 1, twi, 512 + 8 * lane, 1, f);
-  inv_stage_regs<C>(x, 1, 2, twi, 256 + 4 * lane, 2, f);
+  inv_stage_regs<C>(x, 0, 1, twi, 512 + lane, 1, 64, f);
+  inv_stage_regs<C>(x, 1, 2, twi, 256 + lane, 2, 64, f);
 #pragma unroll
   for (int u = 0; u < kRegs; ++u) buf[18 * lane + u] = x[u];
 }
@@ -168,7 +184,7 @@ RS_HD void inv_I2(int lane, double (&x)[kRegs], const double* twi, const double*
 #pragma unroll
   for (int s = 0; s < kRegs; ++s) x[s] = buf[72 * b + 4 * s + q + 2 * (s >> 2)];
 #pragma unroll
-  for (int s = 2; s < 6; ++s) inv_stage_regs<C>(x, s, 1 << (s - 2), twi, (512 >> s) + (b << (5 - s)), s - 1, f);
+  for (int s = 2; s < 6; ++s) inv_stage_regs<C>(x, s, 1 << (s - 2), twi, (512 >> s) + b, s - 1, 16, f);
 }
 // I3: store (transpose 1 positions).
 RS_HD void inv_I3(int lane, const double (&x)[kRegs], double* buf) {
@@ -182,7 +198,7 @@ RS_HD void inv_I4(int lane, double (&x)[kRegs], const double* twi, const double*
 #pragma unroll
   for (int r = 0; r < kRegs; ++r) x[r] = buf[lane + 68 * r];
 #pragma unroll
-  for (int s = 6; s < 10; ++s) inv_stage_regs<C>(x, s, 1 << (s - 6), twi, 512 >> s, s - 5, f);
+  for (int s = 6; s < 10; ++s) inv_stage_regs<C>(x, s, 1 << (s - 6), twi, 512 >> s, s - 5, 1, f);
 #pragma unroll
   for (int r = 0; r < kRegs; ++r) x[r] = f_reduce(x[r], f);
 }

@@ -1,0 +1,118 @@
+"""BASELINE configs[2]: nets/mnist/sign1024x1 encrypted inference on one MI355X, device-resident.
+
+Kernel-level parity is exact (test_gpu_parity.py). Network-level parity is statistical by
+construction of the reference (SURVEY.md hard part 7: 4096 message levels through a 2N = 2048
+mod-switch flip ~20 % of the weak-margin hidden units in the reference too), so this test pins what
+IS deterministic: every linear stage equals the plaintext stage applied to the bits that were
+actually produced, within fresh-noise rounding; no sign with |pre-activation| >= 32 ever flips; and
+the logits are exactly the final layer of the produced bits."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import plain_model as pm
+
+pytestmark = pytest.mark.gpu
+
+
+def _w(s, z):
+    return np.where(z == 1, 0, np.where(s == 1, 1, -1)).astype(np.int64)
+
+
+def test_sign1024x1_encrypted_inference_layerwise():
+    import torch
+    import redsec_amd
+    from redsec_amd import client, nets
+
+    sk = client.SecretKeySet("redsec_small_v2", seed=7)       # client/gen_secure_keyset.cpp:70-97
+    be = redsec_amd.Backend(redsec_amd.params("redsec_small_v2"), 0)
+    be.load_keys(sk.bk, sk.ksk)
+    net = pm.load_net("sign1024x1")
+    enc = nets.EncryptedMnist(be, net)
+    labels, pixels = pm.load_images()
+    agree = 0
+    for i in range(6):
+        ct = torch.from_numpy(sk.encrypt_image(pixels[i], seed=100 + i)).cuda()
+        taps, ptaps = {}, {}
+        out = enc.run(ct, taps)
+        plain_logits = pm.forward(net, pixels[i], ptaps)
+        assert out.shape == (10, be.W)
+        # layer 0: sum-pool + bias is exact up to the fresh encryption noise of 4 pixels
+        pre0 = sk.decrypt_ints(taps["pre0"].cpu().numpy())
+        assert np.abs(pre0 - ptaps["pre0"]).max() <= 2
+        bits0 = np.where(sk.phase(taps["bits0"].cpu().numpy()) > 0, 1, -1)
+        strong = np.abs(ptaps["pre0"]) >= 32
+        assert np.array_equal(bits0[strong], ptaps["bits0"][strong])
+        # layer 1 given the bits actually produced
+        s, z, b = net.fc[0]
+        expect1 = bits0 @ _w(s, z) + b
+        pre1 = sk.decrypt_ints(taps["pre1"].cpu().numpy())
+        assert np.abs(pre1 - expect1).max() <= 2
+        bits1 = np.where(sk.phase(taps["bits1"].cpu().numpy()) > 0, 1, -1)
+        strong = np.abs(expect1) >= 32
+        assert np.array_equal(bits1[strong], np.where(expect1 >= 0, 1, -1)[strong])
+        # bootstrapped outputs are clean +-1/4096 encodings
+        ph = sk.phase(taps["bits1"].cpu().numpy()).astype(np.float64) / (1 << 20)
+        assert np.all(np.abs(np.abs(ph) - 1.0) < 0.25)
+        # logits = final layer of the produced bits (no bootstrap after it)
+        s, z, b = net.final
+        logits = sk.decrypt_ints(out.cpu().numpy())
+        assert np.abs(logits - (bits1 @ _w(s, z) + b)).max() <= 3
+        agree += int(np.argmax(logits) == np.argmax(plain_logits))
+    assert agree >= 2      # statistical; the reference itself is not deterministic here
+
+
+def test_linear_kernels_against_numpy():
+    """sumpool / conv_ternary index math (get_input_i / get_filter_i / get_output_i of
+    lib/BinFunc.cpp:373-402) on random words, incl. same-padding, stride 2 and the IntFunc constants."""
+    import torch
+    import redsec_amd
+    be = redsec_amd.Backend(redsec_amd.params("redsec_small_v2", n=12), 0)
+    W = be.W
+    rng = np.random.default_rng(4)
+    H, Wd, Cin, Cout, fh, fw = 7, 6, 3, 5, 3, 3
+    x = rng.integers(-2**31, 2**31, (H, Wd, Cin, W)).astype(np.int32)
+    sign = rng.integers(0, 2, (fh, fw, Cin, Cout)).astype(np.uint8)
+    zero = (rng.random((fh, fw, Cin, Cout)) < 0.2).astype(np.uint8)
+    bias = rng.integers(-2**31, 2**31, Cout).astype(np.int32)
+    for stride, zb, pb in ((1, 0, 0), (2, -(1 << 20), -(1 << 20))):
+        Ho, Wo = (H - 1) // stride + 1, (Wd - 1) // stride + 1
+        off_h = (fh - 1) // 2 if stride == 1 else (Ho * stride - H) // 2     # Convolution::prep, BinFunc.cpp:86-94
+        off_w = (fw - 1) // 2 if stride == 1 else (Wo * stride - Wd) // 2
+        shape = dict(H=H, Wd=Wd, Cin=Cin, Cout=Cout, fh=fh, fw=fw, stride_h=stride, stride_w=stride,
+                     off_h=off_h, off_w=off_w, Ho=Ho, Wo=Wo)
+        got = be.conv_ternary(torch.from_numpy(x).cuda(), torch.from_numpy(sign).cuda(), torch.from_numpy(zero).cuda(),
+                              shape, zero_tap_b=zb, pad_tap_b=pb, bias_b=torch.from_numpy(bias).cuda()).cpu().numpy()
+        ref = np.zeros((Ho, Wo, Cout, W), np.int64)
+        for oh in range(Ho):
+            for ow in range(Wo):
+                for od in range(Cout):
+                    acc = np.zeros(W, np.int64)
+                    for a in range(fh):
+                        for c in range(fw):
+                            ih, iw = a + oh * stride - off_h, c + ow * stride - off_w
+                            for di in range(Cin):
+                                if zero[a, c, di, od]:
+                                    acc[-1] += zb
+                                elif not (0 <= ih < H and 0 <= iw < Wd):
+                                    acc[-1] += pb
+                                else:
+                                    acc += (1 if sign[a, c, di, od] else -1) * x[ih, iw, di].astype(np.int64)
+                    acc[-1] += int(bias[od])
+                    ref[oh, ow, od] = acc
+        assert np.array_equal(got, (ref & 0xFFFFFFFF).astype(np.uint32).view(np.int32)), stride
+    # sum pooling 2x2 stride 2 (valid) and 3x3 stride 1 same-pad
+    for win, stride, off, Ho, Wo in ((2, 2, 0, 3, 3), (3, 1, 1, 7, 6)):
+        shape = dict(H=H, Wd=Wd, C=Cin, win_h=win, win_w=win, stride_h=stride, stride_w=stride, off_h=off, off_w=off, Ho=Ho, Wo=Wo)
+        got = be.sumpool(torch.from_numpy(x).cuda(), shape).cpu().numpy()
+        ref = np.zeros((Ho, Wo, Cin, W), np.int64)
+        for oh in range(Ho):
+            for ow in range(Wo):
+                for a in range(win):
+                    for c in range(win):
+                        ih, iw = oh * stride - off + a, ow * stride - off + c
+                        if 0 <= ih < H and 0 <= iw < Wd:
+                            ref[oh, ow] += x[ih, iw].astype(np.int64)
+        assert np.array_equal(got, (ref & 0xFFFFFFFF).astype(np.uint32).view(np.int32)), win
