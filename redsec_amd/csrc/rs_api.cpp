@@ -189,10 +189,12 @@ int rs_create(rs_ctx** out, const rs_params* p, int device) {
   c->p = *p;
   c->device = device;
   c->cfg = (p->bk_l == 3) ? 0 : 1;
-  c->tables = rs::make_tables(ps);
   const unsigned fwd_mask = c->cfg == 0 ? rs::CfgDefault128::FWD_MASK : rs::CfgRedsecV2::FWD_MASK;
   const unsigned inv_mask = c->cfg == 0 ? rs::CfgDefault128::INV_MASK : rs::CfgRedsecV2::INV_MASK;
-  const std::string why = rs::validate_schedule(c->tables.f.p, p->bk_l, p->bk_Bgbit, fwd_mask, inv_mask);
+  const int fuse = c->cfg == 0 ? rs::CfgDefault128::FUSE : rs::CfgRedsecV2::FUSE;
+  const bool mid = c->cfg == 0 ? rs::CfgDefault128::MID_REDUCE : rs::CfgRedsecV2::MID_REDUCE;
+  c->tables = rs::make_tables(ps, fuse);
+  const std::string why = rs::validate_schedule(c->tables.f.p, p->bk_l, p->bk_Bgbit, fwd_mask, inv_mask, fuse, mid);
   if (!why.empty()) { delete c; return fail(RS_ERR_INVALID, "transform schedule not exact: %s", why.c_str()); }
   if (hipSetDevice(device) != hipSuccess) { delete c; return fail(RS_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device); }
   hipDeviceProp_t prop;
@@ -203,8 +205,8 @@ int rs_create(rs_ctx** out, const rs_params* p, int device) {
       return fail(RS_ERR_NO_DEVICE, "device %d is %s; this library ships gfx950 code only", device, prop.gcnArchName);
     }
   }
-  if (hipMalloc(&c->d_tw, sizeof(double) * 2 * rs::kN) != hipSuccess ||
-      hipMemcpy(c->d_tw, c->tables.tw.data(), sizeof(double) * 2 * rs::kN, hipMemcpyHostToDevice) != hipSuccess) {
+  if (hipMalloc(&c->d_tw, sizeof(double) * rs::kTwTotal) != hipSuccess ||
+      hipMemcpy(c->d_tw, c->tables.tw.data(), sizeof(double) * rs::kTwTotal, hipMemcpyHostToDevice) != hipSuccess) {
     delete c;
     return fail(RS_ERR_HIP, "twiddle table upload failed");
   }

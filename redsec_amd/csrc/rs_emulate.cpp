@@ -31,6 +31,13 @@ void emu_forward(Wave& w, const double* tw, double* buf, const Field& f) {
   for (int l = 0; l < kLanes; ++l) rs::fwd_F4<C>(l, w.x[l], tw, buf, f);
 }
 template <class C>
+void emu_forward_digits(Wave& w, const int32_t (*d)[kRegs], int q, uint32_t offset, const double* tw, double* buf, const Field& f) {
+  for (int l = 0; l < kLanes; ++l) rs::fwd_F1_digits<C>(l, w.x[l], d[l], q, offset, tw, buf, f);
+  for (int l = 0; l < kLanes; ++l) rs::fwd_F2<C>(l, w.x[l], tw, buf, f);
+  for (int l = 0; l < kLanes; ++l) rs::fwd_F3(l, w.x[l], buf);
+  for (int l = 0; l < kLanes; ++l) rs::fwd_F4<C>(l, w.x[l], tw, buf, f);
+}
+template <class C>
 void emu_inverse(Wave& w, const double* twi, double* buf, const Field& f) {
   for (int l = 0; l < kLanes; ++l) rs::inv_I1<C>(l, w.x[l], twi, buf, f);
   for (int l = 0; l < kLanes; ++l) rs::inv_I2<C>(l, w.x[l], twi, buf, f);
@@ -57,7 +64,7 @@ template <class C>
 int emu_polymul(const int32_t* a_small, const int32_t* b_torus, int32_t* out) {
   rs::PrimeSpec ps;
   if (!rs::prime_for(C::L, C::BGBIT, &ps)) return -1;
-  rs::Tables t = rs::make_tables(ps);
+  rs::Tables t = rs::make_tables(ps, C::FUSE);
   std::vector<double> buf(rs::kBufDoubles), bkd(kN);
   emu_key_transform<C>(b_torus, bkd.data(), t, buf.data());
   Wave w;
@@ -78,7 +85,7 @@ int emu_blind_rotate(int n, const int32_t* in0, const int32_t* in1, int32_t c0, 
                      const int32_t* bk, int32_t* u_out, int32_t* acc_out, int steps) {
   rs::PrimeSpec ps;
   if (!rs::prime_for(C::L, C::BGBIT, &ps)) return -1;
-  rs::Tables t = rs::make_tables(ps);
+  rs::Tables t = rs::make_tables(ps, C::FUSE);
   const Field f = t.f;
   const double* tw = t.tw.data();
   const double* twi = tw + kN;
@@ -115,9 +122,7 @@ int emu_blind_rotate(int n, const int32_t* in0, const int32_t* in1, int32_t c0, 
         const int row = comp * C::L + q;
         const double* bp0 = bk_i + (size_t)(row * 2) * kN;
         const double* bp1 = bp0 + kN;
-        for (int l = 0; l < kLanes; ++l)
-          for (int r = 0; r < kRegs; ++r) x.x[l][r] = (double)rs::gadget_digit<C>(d[l][r], q, offset);
-        emu_forward<C>(x, tw, buf.data(), f);
+        emu_forward_digits<C>(x, d, q, offset, tw, buf.data(), f);
         for (int l = 0; l < kLanes; ++l)
           for (int u = 0; u < kRegs; ++u) {
             const size_t k = ((size_t)(u >> 1) * 64 + l) * 2 + (u & 1);
@@ -125,6 +130,9 @@ int emu_blind_rotate(int n, const int32_t* in0, const int32_t* in1, int32_t c0, 
             s1.x[l][u] += rs::f_mulmod(x.x[l][u], bp1[k], f);
           }
       }
+      if (C::MID_REDUCE && comp == 0)
+        for (int l = 0; l < kLanes; ++l)
+          for (int u = 0; u < kRegs; ++u) { s0.x[l][u] = rs::f_reduce(s0.x[l][u], f); s1.x[l][u] = rs::f_reduce(s1.x[l][u], f); }
     }
     emu_inverse<C>(s0, twi, buf.data(), f);
     for (int l = 0; l < kLanes; ++l)
@@ -172,7 +180,9 @@ int rs_emu_validate(int cfg, char* msg, int msg_len) {
   if (!rs::prime_for(l, bg, &ps)) return -1;
   const unsigned fm = cfg == 0 ? rs::CfgDefault128::FWD_MASK : rs::CfgRedsecV2::FWD_MASK;
   const unsigned im = cfg == 0 ? rs::CfgDefault128::INV_MASK : rs::CfgRedsecV2::INV_MASK;
-  std::string why = rs::validate_schedule((double)ps.p, l, bg, fm, im);
+  const int fuse = cfg == 0 ? rs::CfgDefault128::FUSE : rs::CfgRedsecV2::FUSE;
+  const bool mid = cfg == 0 ? rs::CfgDefault128::MID_REDUCE : rs::CfgRedsecV2::MID_REDUCE;
+  std::string why = rs::validate_schedule((double)ps.p, l, bg, fm, im, fuse, mid);
   if (msg && msg_len > 0) { std::strncpy(msg, why.c_str(), (size_t)msg_len - 1); msg[msg_len - 1] = 0; }
   return why.empty() ? 0 : -1;
 }
@@ -184,13 +194,32 @@ int rs_emu_forward(int cfg, const int32_t* poly, double* out) {
   rs::PrimeSpec ps;
   const int l = cfg == 0 ? 3 : 10, bg = cfg == 0 ? 7 : 3;
   if (!rs::prime_for(l, bg, &ps)) return -1;
-  rs::Tables t = rs::make_tables(ps);
+  rs::Tables t = rs::make_tables(ps, cfg == 0 ? rs::CfgDefault128::FUSE : rs::CfgRedsecV2::FUSE);
   std::vector<double> buf(rs::kBufDoubles);
   Wave w;
   for (int lane = 0; lane < kLanes; ++lane)
     for (int r = 0; r < kRegs; ++r) w.x[lane][r] = (double)poly[lane + 64 * r];
   if (cfg == 0) emu_forward<rs::CfgDefault128>(w, t.tw.data(), buf.data(), t.f);
   else emu_forward<rs::CfgRedsecV2>(w, t.tw.data(), buf.data(), t.f);
+  for (int lane = 0; lane < kLanes; ++lane)
+    for (int u = 0; u < kRegs; ++u) out[16 * lane + u] = w.x[lane][u];
+  return 0;
+}
+
+// Fused-digit forward transform (fwd_F1_digits path) of gadget digit q of the coefficients `coef`;
+// out as rs_emu_forward. Must agree mod p with the generic transform of the digit polynomial.
+int rs_emu_forward_digits(int cfg, const int32_t* coef, int q, double* out) {
+  rs::PrimeSpec ps;
+  const int l = cfg == 0 ? 3 : 10, bg = cfg == 0 ? 7 : 3;
+  if (!rs::prime_for(l, bg, &ps)) return -1;
+  rs::Tables t = rs::make_tables(ps, cfg == 0 ? rs::CfgDefault128::FUSE : rs::CfgRedsecV2::FUSE);
+  std::vector<double> buf(rs::kBufDoubles);
+  Wave w;
+  static int32_t d[kLanes][kRegs];
+  for (int lane = 0; lane < kLanes; ++lane)
+    for (int r = 0; r < kRegs; ++r) d[lane][r] = coef[lane + 64 * r];
+  if (cfg == 0) emu_forward_digits<rs::CfgDefault128>(w, d, q, rs::gadget_offset<rs::CfgDefault128>(), t.tw.data(), buf.data(), t.f);
+  else emu_forward_digits<rs::CfgRedsecV2>(w, d, q, rs::gadget_offset<rs::CfgRedsecV2>(), t.tw.data(), buf.data(), t.f);
   for (int lane = 0; lane < kLanes; ++lane)
     for (int u = 0; u < kRegs; ++u) out[16 * lane + u] = w.x[lane][u];
   return 0;

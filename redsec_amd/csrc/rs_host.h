@@ -42,15 +42,15 @@ inline uint32_t bitrev10(uint32_t x) {
 
 struct Tables {
   Field f;
-  std::vector<double> tw;   // [tw_pos(i)] psi^bitrev(i), [1024 + tw_pos(i)] psi^-bitrev(i), centered
+  std::vector<double> tw;   // kTwTotal doubles: forward, inverse (stage-transposed, tw_pos), fused-stage constants
   double ninv;              // N^-1 mod p, centered
 };
 
-inline Tables make_tables(const PrimeSpec& ps) {
+inline Tables make_tables(const PrimeSpec& ps, int fuse) {
   Tables t;
   t.f.p = (double)ps.p;
   t.f.pinv = 1.0 / (double)ps.p;
-  t.tw.resize(2 * kN);
+  t.tw.assign(kTwTotal, 0.0);
   const uint64_t psi_inv = powmod_u64(ps.psi, ps.p - 2, ps.p);
   for (uint32_t i = 0; i < (uint32_t)kN; ++i) {
     const uint32_t r = bitrev10(i);
@@ -59,39 +59,74 @@ inline Tables make_tables(const PrimeSpec& ps) {
     t.tw[kN + pos] = centered(powmod_u64(psi_inv, r, ps.p), ps.p);
   }
   t.ninv = centered(powmod_u64((uint64_t)kN, ps.p - 2, ps.p), ps.p);
+  // constants of the fused forward stages 0-1 (rs_ntt.h fwd_F1_digits)
+  const uint64_t I = powmod_u64(ps.psi, bitrev10(1), ps.p), w1 = powmod_u64(ps.psi, bitrev10(2), ps.p),
+                 w2 = powmod_u64(ps.psi, bitrev10(3), ps.p);
+  const uint64_t w1I = mulmod_u64(w1, I, ps.p), w2I = mulmod_u64(w2, I, ps.p);
+  double* sm = t.tw.data() + 2 * kN;
+  if (fuse == 2) {
+    sm[0] = centered(w1I, ps.p);
+    sm[1] = centered(w2I, ps.p);
+  } else if (fuse == 1) {
+    const uint64_t c[5] = {I, w1, w1I, w2, w2I};
+    for (int k = 0; k < 5; ++k)
+      for (int tt = 0; tt < 128; ++tt) {
+        const int64_t dgt = tt - 64;
+        const uint64_t du = dgt >= 0 ? (uint64_t)dgt : ps.p - (uint64_t)(-dgt);
+        sm[k * 128 + tt] = centered(mulmod_u64(c[k], du, ps.p), ps.p);
+      }
+  }
   return t;
 }
 
 // Re-derives the magnitude chain of rs_ntt.h ("Exactness") for a schedule; returns "" if every
 // intermediate stays below 2^53 and the final lift is unambiguous, else a description.
-inline std::string validate_schedule(double p, int l, int bgbit, unsigned fwd_mask, unsigned inv_mask) {
+// Two forward entry points are checked: the generic one (key polynomials, |x| <= 2^31, all ten
+// stages) and the fused-digit one (stages 0-1 evaluated exactly, starting bound 1.5 p / 6 p).
+inline std::string validate_schedule(double p, int l, int bgbit, unsigned fwd_mask, unsigned inv_mask, int fuse, bool mid_reduce) {
   const double lim = 9007199254740992.0;  // 2^53
   const double unit = p / lim;            // p * 2^-53
   auto V = [&](double c) { return 0.5 + 1.5 * c * unit + 2.0 / p; };  // mulmod output bound / p
   const double red = 0.5 + 2.0 / p;                                    // reduce() output bound / p
   char msg[256];
-  // exact integer result must lift uniquely
-  const double true_bound = 2.0 * l * kN * std::ldexp(1.0, bgbit - 1) * 2147483648.0;
+  const double half_bg = std::ldexp(1.0, bgbit - 1);
+  const double true_bound = 2.0 * l * kN * half_bg * 2147483648.0;
   if (true_bound >= 0.5 * p) return "prime too small for the external-product bound";
-  // forward: digits (|d| <= Bg/2) or key words (|x| <= 2^31)
-  double a = 2147483648.0 / p;
-  for (int s = 0; s < 10; ++s) {
-    const double v = V(a);
-    a = a + v;
-    if (a * p >= lim) { snprintf(msg, sizeof msg, "forward stage %d reaches %.3f p", s, a); return msg; }
-    if (fwd_mask & (1u << s)) a = red;
+  auto forward = [&](double a, int first_stage, const char* what, double* out) -> std::string {
+    for (int s = first_stage; s < 10; ++s) {
+      a = a + V(a);
+      if (a * p >= lim) { snprintf(msg, sizeof msg, "%s forward stage %d reaches %.3f p", what, s, a); return msg; }
+      if (fwd_mask & (1u << s)) a = red;
+    }
+    *out = a;
+    return "";
+  };
+  double x_key = 0, x_dig = 0;
+  std::string why = forward(2147483648.0 / p, 0, "generic", &x_key);
+  if (!why.empty()) return why;
+  if (fuse == 1) {
+    why = forward(1.5 + half_bg / p, 2, "table-fused", &x_dig);      // |d0| + 3 table entries of <= p/2
+  } else if (fuse == 2) {
+    if (half_bg * 0.5 * p * 3.0 + half_bg >= lim) return "fused FMA stage inexact";
+    why = forward(3.0 * half_bg * 0.5 + half_bg / p, 2, "fma-fused", &x_dig);  // d0 + 3 * (p/2) * Bg/2
+  } else {
+    x_dig = x_key;
   }
-  const double x_bound = a;
-  // pointwise: 2 l products per column, key entries reduced
-  const double acc = 2.0 * l * V(x_bound);
+  if (!why.empty()) return why;
+  // pointwise: 2 l products per column, key entries reduced; optional reduction after l products
+  const double prod = V(x_dig);
+  double acc = l * prod;
+  if (acc * p >= lim) { snprintf(msg, sizeof msg, "pointwise half-sum reaches %.3f p", acc); return msg; }
+  if (mid_reduce) acc = red;
+  acc += l * prod;
   if (acc * p >= lim) { snprintf(msg, sizeof msg, "pointwise sum reaches %.3f p", acc); return msg; }
   // inverse
-  a = red;
+  double a = red;
   for (int s = 0; s < 10; ++s) {
     const double sum = 2.0 * a;
     if (sum * p >= lim) { snprintf(msg, sizeof msg, "inverse stage %d reaches %.3f p", s, sum); return msg; }
-    const double prod = V(sum);
-    a = sum > prod ? sum : prod;
+    const double pr = V(sum);
+    a = sum > pr ? sum : pr;
     if (inv_mask & (1u << s)) a = red;
   }
   return "";

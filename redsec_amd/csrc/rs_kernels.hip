@@ -39,6 +39,20 @@ __device__ __forceinline__ void ntt_forward(int lane, double (&x)[kRegs], const 
   wave_lds_sync();
 }
 
+// forward transform of gadget digit q of the coefficients d (fused stages 0-1, rs_ntt.h)
+template <class C>
+__device__ __forceinline__ void ntt_forward_digits(int lane, double (&x)[kRegs], const int32_t (&d)[kRegs], int q, uint32_t offset,
+                                                   const double* tw, double* buf, const Field& f) {
+  fwd_F1_digits<C>(lane, x, d, q, offset, tw, buf, f);
+  wave_lds_sync();
+  fwd_F2<C>(lane, x, tw, buf, f);
+  wave_lds_sync();
+  fwd_F3(lane, x, buf);
+  wave_lds_sync();
+  fwd_F4<C>(lane, x, tw, buf, f);
+  wave_lds_sync();
+}
+
 template <class C>
 __device__ __forceinline__ void ntt_inverse(int lane, double (&x)[kRegs], const double* twi, double* buf, const Field& f) {
   inv_I1<C>(lane, x, twi, buf, f);
@@ -51,8 +65,8 @@ __device__ __forceinline__ void ntt_inverse(int lane, double (&x)[kRegs], const 
   wave_lds_sync();
 }
 
-__device__ __forceinline__ void stage_tables(double* s_tw, const double* tw_g, int nthreads) {
-  for (int i = threadIdx.x; i < 2 * kN; i += nthreads) s_tw[i] = tw_g[i];
+__device__ __forceinline__ void stage_tables(double* s_tw, const double* tw_g, int nthreads, int count = 2 * kN) {
+  for (int i = threadIdx.x; i < count; i += nthreads) s_tw[i] = tw_g[i];
   __syncthreads();
 }
 
@@ -91,10 +105,10 @@ __global__ __launch_bounds__(64 * WPB) void bk_transform_kernel(const int32_t* _
 // -------------------------------------------------------------------------------------------------
 template <class C, int WPB>
 __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs a) {
-  __shared__ double s_tw[2 * kN];
+  __shared__ double s_tw[kTwTotal];
   __shared__ double s_buf[WPB][kBufDoubles];
   __shared__ int32_t s_acc[WPB][2][kN];
-  stage_tables(s_tw, a.tw, 64 * WPB);
+  stage_tables(s_tw, a.tw, 64 * WPB, kTwTotal);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const long ct = (long)blockIdx.x * WPB + wave;
@@ -155,9 +169,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs 
 #pragma unroll
         for (int v = 0; v < 8; ++v) { w0[v] = bp0[v * 64 + lane]; w1[v] = bp1[v * 64 + lane]; }
         double x[kRegs];
-#pragma unroll
-        for (int r = 0; r < kRegs; ++r) x[r] = (double)gadget_digit<C>(d[r], q, offset);
-        ntt_forward<C>(lane, x, tw, buf, f);
+        ntt_forward_digits<C>(lane, x, d, q, offset, tw, buf, f);
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
           s0[2 * v] += f_mulmod(x[2 * v], w0[v].x, f);
@@ -165,6 +177,10 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs 
           s1[2 * v] += f_mulmod(x[2 * v], w1[v].x, f);
           s1[2 * v + 1] += f_mulmod(x[2 * v + 1], w1[v].y, f);
         }
+      }
+      if (C::MID_REDUCE && comp == 0) {
+#pragma unroll
+        for (int u = 0; u < kRegs; ++u) { s0[u] = f_reduce(s0[u], f); s1[u] = f_reduce(s1[u], f); }
       }
     }
 

@@ -82,18 +82,30 @@ RS_HD int pos_t2(int j) { return j + 2 * (j >> 4); }
 
 // Reduction schedule: bit s of FWD_MASK = full reduction after forward stage s (0..9);
 // bit s of INV_MASK = full reduction after inverse stage s. The inverse always reduces its input
-// and its output.
-template <int L_, int BGBIT_, unsigned FWD_MASK_, unsigned INV_MASK_>
+// and its output. FUSE selects how forward stages 0-1 are evaluated for gadget-digit inputs
+// (fwd_F1_digits): 1 = LDS product tables (7-bit digits: w*d does not fit 53 bits), 2 = exact FMAs
+// (3-bit digits: |w*d| <= 2p < 2^53). MID_REDUCE = reduce the pointwise partial sums once, after
+// the first accumulator component, which is what lets the forward outputs stay un-reduced.
+template <int L_, int BGBIT_, unsigned FWD_MASK_, unsigned INV_MASK_, int FUSE_, bool MID_REDUCE_>
 struct Cfg {
   static constexpr int L = L_;
   static constexpr int BGBIT = BGBIT_;
   static constexpr unsigned FWD_MASK = FWD_MASK_;
   static constexpr unsigned INV_MASK = INV_MASK_;
+  static constexpr int FUSE = FUSE_;
+  static constexpr bool MID_REDUCE = MID_REDUCE_;
 };
 // TFHE default-128: l=3, Bgbit=7 -> prime 2^50.61 (headroom 2^53/p = 5.2).
-using CfgDefault128 = Cfg<3, 7, (1u << 4) | (1u << 8), (1u << 2) | (1u << 5) | (1u << 8)>;
+using CfgDefault128 = Cfg<3, 7, (1u << 3) | (1u << 7), (1u << 2) | (1u << 5) | (1u << 8), 1, true>;
 // REDsec redsec_params_small_v2: l=10, Bgbit=3 -> prime 2^48.35 (headroom 25).
-using CfgRedsecV2 = Cfg<10, 3, 0u, (1u << 4)>;
+using CfgRedsecV2 = Cfg<10, 3, 0u, (1u << 4), 2, true>;
+
+// Table block handed to the kernels: [0,1024) forward twiddles, [1024,2048) inverse twiddles,
+// [2048, 2048+kSmall) constants of the fused stages 0-1:
+//   FUSE 2: sm[0] = w1*I, sm[1] = w2*I                      (I = tw[1], w1 = tw[2], w2 = tw[3])
+//   FUSE 1: sm[k*128 + t] = c_k * (t - 64) mod p, c = (I, w1, w1*I, w2, w2*I), t = digit + 64
+constexpr int kSmall = 5 * 128;
+constexpr int kTwTotal = 2 * kN + kSmall;
 
 // ---------------------------------------------------------------------------------------------
 // Forward transform phases. tw = psi^bitrev(i) table (1024 centered doubles), buf = exchange buffer.
@@ -121,6 +133,54 @@ template <class C>
 RS_HD void fwd_F1(int lane, double (&x)[kRegs], const double* tw, double* buf, const Field& f) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) fwd_stage_regs<C>(x, s, 8 >> s, tw, 1 << s, 4 - s, 1, f);
+#pragma unroll
+  for (int r = 0; r < kRegs; ++r) buf[lane + 68 * r] = x[r];
+}
+// gadget digit q (0-based) of coefficient d, biased by Bg/2: ((d + offset) >> decal) & (Bg-1)
+// (tGswTorus32PolynomialDecompH; the signed digit is this minus Bg/2).
+template <class C>
+RS_HD int32_t gadget_digit_biased(int32_t d, int q, uint32_t offset) {
+  const uint32_t u = (uint32_t)d + offset;
+  const int decal = 32 - (q + 1) * C::BGBIT;
+  return (int32_t)((u >> decal) & ((1u << C::BGBIT) - 1u));
+}
+
+// F1 for gadget digits: stages 0-1 fused over the register quadruples (g, g+4, g+8, g+12):
+//   out[g]    = a + c,  out[g+4]  = a - c,   a = d0 + I d2,  c = w1 d1 + (w1 I) d3
+//   out[g+8]  = b + e,  out[g+12] = b - e,   b = d0 - I d2,  e = w2 d1 - (w2 I) d3
+// then stages 2-3 and the transpose-1 store. Bounds after stage 1: 1.5 p (tables) / 6 p (FMA).
+template <class C>
+RS_HD void fwd_F1_digits(int lane, double (&x)[kRegs], const int32_t (&d)[kRegs], int q, uint32_t offset, const double* tw,
+                         double* buf, const Field& f) {
+  const double* sm = tw + 2 * kN;
+  constexpr int HALF = 1 << (C::BGBIT - 1);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int32_t t0 = gadget_digit_biased<C>(d[g], q, offset), t1 = gadget_digit_biased<C>(d[g + 4], q, offset);
+    const int32_t t2 = gadget_digit_biased<C>(d[g + 8], q, offset), t3 = gadget_digit_biased<C>(d[g + 12], q, offset);
+    double a, b, c, e;
+    if (C::FUSE == 1) {
+      const double d0 = (double)(t0 - HALF);
+      const double id2 = sm[0 * 128 + t2];
+      a = d0 + id2;
+      b = d0 - id2;
+      c = sm[1 * 128 + t1] + sm[2 * 128 + t3];
+      e = sm[3 * 128 + t1] - sm[4 * 128 + t3];
+    } else {
+      const double d0 = (double)(t0 - HALF), d1 = (double)(t1 - HALF), d2 = (double)(t2 - HALF), d3 = (double)(t3 - HALF);
+      const double I = tw[1], w1 = tw[2], w2 = tw[3], w1I = sm[0], w2I = sm[1];
+      a = __builtin_fma(I, d2, d0);
+      b = __builtin_fma(-I, d2, d0);
+      c = __builtin_fma(w1I, d3, w1 * d1);
+      e = __builtin_fma(-w2I, d3, w2 * d1);
+    }
+    x[g] = a + c;
+    x[g + 4] = a - c;
+    x[g + 8] = b + e;
+    x[g + 12] = b - e;
+  }
+#pragma unroll
+  for (int s = 2; s < 4; ++s) fwd_stage_regs<C>(x, s, 8 >> s, tw, 1 << s, 4 - s, 1, f);
 #pragma unroll
   for (int r = 0; r < kRegs; ++r) buf[lane + 68 * r] = x[r];
 }

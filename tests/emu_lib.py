@@ -46,6 +46,13 @@ def forward(cfg, poly):
     return out
 
 
+def forward_digits(cfg, coef, q):
+    coef = np.ascontiguousarray(coef, np.int32)
+    out = np.zeros(1024, np.float64)
+    assert lib().rs_emu_forward_digits(cfg, _p(coef), int(q), out.ctypes.data_as(C.POINTER(C.c_double))) == 0
+    return out
+
+
 def validate(cfg):
     msg = C.create_string_buffer(256)
     rc = lib().rs_emu_validate(cfg, msg, 256)

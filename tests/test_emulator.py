@@ -51,6 +51,28 @@ def test_forward_transform_is_linear_mod_p(cfg):
     assert np.all(np.abs(fa) < 2.0 ** 53) and np.all(fa == np.rint(fa))
 
 
+@pytest.mark.parametrize("cfg,l,bg", [(0, 3, 7), (1, 10, 3)])
+def test_fused_digit_stages_equal_generic_transform(cfg, l, bg):
+    """fwd_F1_digits (table / exact-FMA stages 0-1) == generic transform of the digit polynomial
+    (mod p), for random coefficients and for coefficients whose digits are all extreme."""
+    p = int(emu_lib.lib().rs_emu_prime(cfg))
+    offset = sum((1 << (bg - 1)) << (32 - i * bg) for i in range(1, l + 1)) & 0xFFFFFFFF
+    rng = np.random.default_rng(cfg)
+    lo_digits = np.uint32((0 - offset) & 0xFFFFFFFF)                       # every digit = -Bg/2
+    hi_digits = np.uint32((((1 << (bg * l)) - 1) << (32 - bg * l)) - offset & 0xFFFFFFFF)   # every digit = Bg/2-1
+    cases = [rng.integers(-2**31, 2**31, 1024).astype(np.int32),
+             np.full(1024, lo_digits, np.uint32).view(np.int32), np.full(1024, hi_digits, np.uint32).view(np.int32),
+             np.where(np.arange(1024) % 2 == 0, lo_digits, hi_digits).astype(np.uint32).view(np.int32)]
+    for coef in cases:
+        for q in (0, l - 1):
+            u = (coef.view(np.uint32).astype(np.uint64) + offset) & 0xFFFFFFFF
+            digit = ((u >> (32 - (q + 1) * bg)) & ((1 << bg) - 1)).astype(np.int64) - (1 << (bg - 1))
+            fused = emu_lib.forward_digits(cfg, coef, q)
+            generic = emu_lib.forward(cfg, digit.astype(np.int32))
+            assert np.all(np.abs(fused) < 2.0 ** 53)
+            assert all((int(a) - int(b)) % p == 0 for a, b in zip(fused, generic))
+
+
 @pytest.mark.parametrize("cfg,fixture", [(0, "toy_default"), (1, "toy_redsec")])
 def test_blind_rotate_matches_oracle(cfg, fixture, request):
     ks, ctx = request.getfixturevalue(fixture)
