@@ -53,6 +53,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
+    path = path or os.environ.get("REDSEC_HIP_LIB")   # timing experiments may point at a variant build
     so = path or _build.build_hip()
     if not os.path.exists(so):
         raise RedsecHipError("libredsec_hip.so is missing: run `python -m redsec_amd.build`")

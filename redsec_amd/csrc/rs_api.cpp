@@ -9,9 +9,11 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "rs_host.h"
 #include "rs_kernels.h"
@@ -50,6 +52,7 @@ struct rs_ctx {
   bool keys = false;
   int32_t* d_u0 = nullptr;
   int32_t* d_u1 = nullptr;
+  unsigned int* d_counter = nullptr;  // work counters of the persistent blind-rotate launches
   size_t ws_batch = 0;
   int32_t* d_io[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t io_batch = 0;
@@ -57,6 +60,10 @@ struct rs_ctx {
   bool timing = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool ev_valid = false;
+  int stagger = 0;  // tuning knobs (env RS_STAGGER / RS_PRIO), see blind_rotate_kernel
+  int prio = 0;
+  unsigned long long* dbg = nullptr;  // RS_STAMPS builds only
+  size_t dbg_B = 0;
 };
 
 namespace {
@@ -130,6 +137,16 @@ rs::BlindRotateArgs br_args(rs_ctx* c, const int32_t* in0, const int32_t* in1, i
   a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.bconst = bconst; a.mu = mu;
   a.bk_ntt = c->d_bk_ntt; a.tw = c->d_tw; a.f = c->tables.f;
   a.n = c->p.n; a.W = c->p.n + 1; a.B = (long)B; a.u_out = u;
+  a.stagger = c->stagger; a.prio = c->prio;
+  a.counter = c->d_counter;
+  a.debug = nullptr;
+#if defined(RS_STAMPS)
+  {  // diagnostic build: cycle stamps land in a buffer of their own, dumped by rs_destroy
+    static unsigned long long* dbg = nullptr; static size_t cap = 0;
+    if (B > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc(&dbg, B * 12 * sizeof(unsigned long long)); cap = B; }
+    a.debug = dbg; c->dbg = dbg; c->dbg_B = B;
+  }
+#endif
   return a;
 }
 
@@ -147,7 +164,7 @@ int run_bootstrap(rs_ctx* c, int32_t* out, const int32_t* in0, const int32_t* in
   if (rc) return rc;
   const int wpb = pick_wpb(c, B);
   if (c->timing) RS_HIP(hipEventRecord(c->ev[0], st));
-  RS_HIP(rs::launch_blind_rotate(c->cfg, br_args(c, in0, in1, c0, c1, bconst, mu, B, c->d_u0), wpb, st));
+  RS_HIP(rs::launch_blind_rotate(c->cfg, br_args(c, in0, in1, c0, c1, bconst, mu, B, c->d_u0), wpb, c->num_cus, st));
   if (c->timing) RS_HIP(hipEventRecord(c->ev[1], st));
   RS_HIP(rs::launch_keyswitch(ks_args(c, c->d_u0, nullptr, 0, B, out), st));
   if (c->timing) { RS_HIP(hipEventRecord(c->ev[2], st)); c->ev_valid = true; }
@@ -211,6 +228,10 @@ int rs_create(rs_ctx** out, const rs_params* p, int device) {
     return fail(RS_ERR_HIP, "twiddle table upload failed");
   }
   for (auto& e : c->ev) (void)hipEventCreate(&e);
+  if (hipMalloc(&c->d_counter, 256) != hipSuccess) { delete c; return fail(RS_ERR_HIP, "counter allocation failed"); }
+  if (getenv("RS_NO_PERSIST")) { (void)hipFree(c->d_counter); c->d_counter = nullptr; }
+  if (const char* s = getenv("RS_STAGGER")) c->stagger = atoi(s);
+  if (const char* s = getenv("RS_PRIO")) c->prio = atoi(s);
   *out = c;
   return RS_OK;
 }
@@ -219,8 +240,19 @@ int rs_destroy(rs_ctx* c) {
   if (!c) return RS_OK;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
+#if defined(RS_STAMPS)
+  if (c->dbg && c->dbg_B) {
+    std::vector<unsigned long long> h(c->dbg_B * 12);
+    (void)hipMemcpy(h.data(), c->dbg, h.size() * 8, hipMemcpyDeviceToHost);
+    double sum[12] = {0};
+    for (size_t b = 0; b < c->dbg_B; ++b) for (int k = 0; k < 12; ++k) sum[k] += (double)h[b * 12 + k];
+    fprintf(stderr, "RS_STAMPS mean cycles per wave per bootstrap:");
+    for (int k = 0; k < 12; ++k) fprintf(stderr, " [%d]=%.0f", k, sum[k] / c->dbg_B);
+    fprintf(stderr, "\n");
+  }
+#endif
   (void)hipFree(c->d_tw); (void)hipFree(c->d_bk_ntt); (void)hipFree(c->d_ksk);
-  (void)hipFree(c->d_u0); (void)hipFree(c->d_u1);
+  (void)hipFree(c->d_u0); (void)hipFree(c->d_u1); (void)hipFree(c->d_counter);
   for (auto& p : c->d_io) (void)hipFree(p);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   delete c;
@@ -289,8 +321,8 @@ int rs_mux_dev(rs_ctx* c, int32_t* out, const int32_t* a, const int32_t* b, cons
   const int32_t e8 = 1 << 29;
   if (c->timing) RS_HIP(hipEventRecord(c->ev[0], st));
   // u1 = woKS(AND(a,b)), u2 = woKS(ANDNY(a,c)); out = KS((0,1/8) + u1 + u2)
-  RS_HIP(rs::launch_blind_rotate(c->cfg, br_args(c, a, b, 1, 1, -e8, e8, B, c->d_u0), wpb, st));
-  RS_HIP(rs::launch_blind_rotate(c->cfg, br_args(c, a, cc, -1, 1, -e8, e8, B, c->d_u1), wpb, st));
+  RS_HIP(rs::launch_blind_rotate(c->cfg, br_args(c, a, b, 1, 1, -e8, e8, B, c->d_u0), wpb, c->num_cus, st));
+  RS_HIP(rs::launch_blind_rotate(c->cfg, br_args(c, a, cc, -1, 1, -e8, e8, B, c->d_u1), wpb, c->num_cus, st));
   if (c->timing) RS_HIP(hipEventRecord(c->ev[1], st));
   RS_HIP(rs::launch_keyswitch(ks_args(c, c->d_u0, c->d_u1, e8, B, out), st));
   if (c->timing) { RS_HIP(hipEventRecord(c->ev[2], st)); c->ev_valid = true; }
@@ -302,7 +334,7 @@ int rs_bootstrap_wo_ks_dev(rs_ctx* c, int32_t* u, const int32_t* in, int32_t mu,
   if (rc) return rc;
   if (B == 0) return RS_OK;
   if (!u || !in) return fail(RS_ERR_INVALID, "null ciphertext pointer");
-  RS_HIP(rs::launch_blind_rotate(c->cfg, br_args(c, in, nullptr, 1, 0, 0, mu, B, u), pick_wpb(c, B), (hipStream_t)stream));
+  RS_HIP(rs::launch_blind_rotate(c->cfg, br_args(c, in, nullptr, 1, 0, 0, mu, B, u), pick_wpb(c, B), c->num_cus, (hipStream_t)stream));
   return RS_OK;
 }
 

@@ -23,6 +23,10 @@ struct BlindRotateArgs {
   int32_t W;            // n + 1
   long B;
   int32_t* u_out;       // [B][N+1] extracted samples
+  int32_t stagger;      // start delay of waves 4-7, units of s_sleep(8) = 512 cycles
+  int32_t prio;         // 1: waves 4-7 run at s_setprio 1
+  unsigned int* counter;  // persistent-wave work counter (device), or nullptr
+  unsigned long long* debug;  // diagnostic builds only (RS_STAMPS): [B][12] cycle sums, else unused
 };
 
 struct KeyswitchArgs {
@@ -39,7 +43,7 @@ struct ConvShape { int32_t H, Wd, Cin, Cout, fh, fw, stride_h, stride_w, off_h, 
 struct PoolShape { int32_t H, Wd, C, win_h, win_w, stride_h, stride_w, off_h, off_w, Ho, Wo; };
 
 // cfg: 0 = CfgDefault128 (l=3, Bgbit=7), 1 = CfgRedsecV2 (l=10, Bgbit=3)
-hipError_t launch_blind_rotate(int cfg, const BlindRotateArgs& a, int waves_per_block, hipStream_t st);
+hipError_t launch_blind_rotate(int cfg, const BlindRotateArgs& a, int waves_per_block, int num_cus, hipStream_t st);
 hipError_t launch_bk_transform(int cfg, const int32_t* bk, double* bk_ntt, const double* tw, Field f, double ninv, long n_polys,
                                hipStream_t st);
 hipError_t launch_keyswitch(const KeyswitchArgs& a, hipStream_t st);

@@ -22,10 +22,35 @@ namespace rs {
 // Same-wave LDS hand-off: DS operations of one wavefront execute in order, so only the compiler
 // needs to be told not to move LDS accesses across this point.
 __device__ __forceinline__ void wave_lds_sync() {
+#if defined(RS_EXP_NOSYNC)  // timing experiment: let the compiler reorder/merge across LDS hand-offs
+  return;
+#endif
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// Diagnostic build only (-DRS_STAMPS): per-phase cycle stamps, accumulated per wave and written to
+// a debug buffer nothing else reads. Never enabled in the product build.
+#if defined(RS_STAMPS)
+#define RS_NSTAMP 12
+struct Stamps { unsigned long long t, acc[RS_NSTAMP]; };
+__device__ __forceinline__ void stamp_start(Stamps& s) {
+  __builtin_amdgcn_sched_barrier(0);
+  s.t = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void stamp(Stamps& s, int k) {
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long now = __builtin_amdgcn_s_memtime();
+  s.acc[k] += now - s.t;
+  s.t = now;
+  __builtin_amdgcn_sched_barrier(0);
+}
+#define RS_STAMP(k) stamp(st, k)
+#else
+#define RS_STAMP(k)
+#endif
 
 template <class C>
 __device__ __forceinline__ void ntt_forward(int lane, double (&x)[kRegs], const double* tw, double* buf, const Field& f) {
@@ -42,15 +67,23 @@ __device__ __forceinline__ void ntt_forward(int lane, double (&x)[kRegs], const 
 // forward transform of gadget digit q of the coefficients d (fused stages 0-1, rs_ntt.h)
 template <class C>
 __device__ __forceinline__ void ntt_forward_digits(int lane, double (&x)[kRegs], const int32_t (&d)[kRegs], int q, uint32_t offset,
-                                                   const double* tw, double* buf, const Field& f) {
+                                                   const double* tw, double* buf, const Field& f
+#if defined(RS_STAMPS)
+                                                   , Stamps& st
+#endif
+) {
   fwd_F1_digits<C>(lane, x, d, q, offset, tw, buf, f);
   wave_lds_sync();
+  RS_STAMP(1);
   fwd_F2<C>(lane, x, tw, buf, f);
   wave_lds_sync();
+  RS_STAMP(2);
   fwd_F3(lane, x, buf);
   wave_lds_sync();
+  RS_STAMP(3);
   fwd_F4<C>(lane, x, tw, buf, f);
   wave_lds_sync();
+  RS_STAMP(4);
 }
 
 template <class C>
@@ -111,7 +144,19 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs 
   stage_tables(s_tw, a.tw, 64 * WPB, kTwTotal);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
-  const long ct = (long)blockIdx.x * WPB + wave;
+  // De-phase knobs (measured: no effect, kept for experiments): waves 4-7 start late / higher prio.
+  if (WPB >= 8 && wave >= 4) {
+    for (int k = 0; k < a.stagger; ++k) __builtin_amdgcn_s_sleep(8);
+    if (a.prio) __builtin_amdgcn_s_setprio(1);
+  }
+  // Persistent waves: the first ciphertext is assigned statically, further ones are pulled from a
+  // device counter (zeroed by the launcher on the same stream). A 152 KB-LDS workgroup cannot be
+  // replaced until its LAST wave exits, and waves sharing a SIMD finish up to 20 % apart (issue
+  // arbitration favours the older wave), which left 18 % of the wave slots idle with one
+  // ciphertext per wave (profiles/r01: stamps build). Every wave leaves the loop as soon as the
+  // counter passes B, so the grid always drains.
+  long ct = (long)blockIdx.x * WPB + wave;
+  const long first_dynamic = (long)gridDim.x * WPB;
   if (ct >= a.B) return;
 
   const Field f = a.f;
@@ -120,6 +165,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs 
   int32_t* acc1 = s_acc[wave][1];
   const double* tw = s_tw;
   const double* twi = s_tw + kN;
+ for (;;) {
   const int32_t* row0 = a.in0 + ct * a.W;
   const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
   const int n = a.n;
@@ -145,6 +191,12 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs 
 
   constexpr uint32_t offset = gadget_offset<C>();
   constexpr int KPL = 2 * C::L;
+#if defined(RS_STAMPS)
+  Stamps st;
+  for (int k = 0; k < RS_NSTAMP; ++k) st.acc[k] = 0;
+  const unsigned long long real0 = __builtin_amdgcn_s_memrealtime();
+  stamp_start(st);
+#endif
 
   for (int i = 0; i < n; ++i) {
     const int32_t bara = __builtin_amdgcn_readfirstlane(modswitch_2N(word(i)));
@@ -160,16 +212,27 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs 
       int32_t d[kRegs];
 #pragma unroll
       for (int r = 0; r < kRegs; ++r) d[r] = rotated_diff(accc, lane + 64 * r, bara);
+      RS_STAMP(0);
 #pragma unroll 1
       for (int q = 0; q < C::L; ++q) {
         const int row = comp * C::L + q;
         const double2* bp0 = reinterpret_cast<const double2*>(bk_i + (size_t)(row * 2) * kN);
         const double2* bp1 = bp0 + kN / 2;
         double2 w0[8], w1[8];
+#if defined(RS_EXP_NOBK)   // timing experiment: no key-row loads
+#pragma unroll
+        for (int v = 0; v < 8; ++v) { w0[v] = make_double2(1.0 + lane + q, 2.0 + v); w1[v] = make_double2(3.0 + v, 5.0 + lane); }
+#else
 #pragma unroll
         for (int v = 0; v < 8; ++v) { w0[v] = bp0[v * 64 + lane]; w1[v] = bp1[v * 64 + lane]; }
+#endif
         double x[kRegs];
+#if defined(RS_STAMPS)
+        RS_STAMP(5);
+        ntt_forward_digits<C>(lane, x, d, q, offset, tw, buf, f, st);
+#else
         ntt_forward_digits<C>(lane, x, d, q, offset, tw, buf, f);
+#endif
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
           s0[2 * v] += f_mulmod(x[2 * v], w0[v].x, f);
@@ -177,6 +240,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs 
           s1[2 * v] += f_mulmod(x[2 * v], w1[v].x, f);
           s1[2 * v + 1] += f_mulmod(x[2 * v + 1], w1[v].y, f);
         }
+        RS_STAMP(6);
       }
       if (C::MID_REDUCE && comp == 0) {
 #pragma unroll
@@ -184,13 +248,17 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs 
       }
     }
 
+    RS_STAMP(7);
     ntt_inverse<C>(lane, s0, twi, buf, f);
+    RS_STAMP(8);
 #pragma unroll
     for (int r = 0; r < kRegs; ++r) {
       const int j = lane + 64 * r;
       acc0[j] = (int32_t)((uint32_t)acc0[j] + (uint32_t)f_to_torus32(s0[r]));
     }
+    RS_STAMP(9);
     ntt_inverse<C>(lane, s1, twi, buf, f);
+    RS_STAMP(10);
 #pragma unroll
     for (int r = 0; r < kRegs; ++r) {
       const int j = lane + 64 * r;
@@ -199,6 +267,12 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs 
     wave_lds_sync();
   }
 
+#if defined(RS_STAMPS)
+  RS_STAMP(11);
+  st.acc[11] = __builtin_amdgcn_s_memrealtime() - real0;   // 100 MHz ticks for the whole rotation
+  if (lane == 0 && a.debug)
+    for (int k = 0; k < RS_NSTAMP; ++k) a.debug[ct * RS_NSTAMP + k] = st.acc[k];
+#endif
   // tLweExtractLweSampleIndex(index 0): a'[0] = acc_a[0], a'[j] = -acc_a[N-j], b' = acc_b[0]
   int32_t* out = a.u_out + ct * (kN + 1);
 #pragma unroll
@@ -207,6 +281,15 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs 
     out[j] = (j == 0) ? acc0[0] : (int32_t)(0u - (uint32_t)acc0[kN - j]);
   }
   if (lane == 0) out[kN] = acc1[0];
+
+  if (!a.counter) break;
+  unsigned int nxt = 0;
+  if (lane == 0) nxt = atomicAdd(a.counter, 1u);
+  nxt = (unsigned int)__builtin_amdgcn_readfirstlane((int)nxt);
+  ct = first_dynamic + (long)nxt;
+  if (ct >= a.B) break;
+  wave_lds_sync();
+ }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -483,25 +566,33 @@ __global__ __launch_bounds__(256) void sumpool_kernel(int32_t* __restrict__ out,
 // Launchers
 // -------------------------------------------------------------------------------------------------
 template <class C, int WPB>
-static hipError_t launch_br(const BlindRotateArgs& a, hipStream_t st) {
-  const long blocks = (a.B + WPB - 1) / WPB;
-  hipLaunchKernelGGL((blind_rotate_kernel<C, WPB>), dim3((unsigned)blocks), dim3(64 * WPB), 0, st, a);
+static hipError_t launch_br(const BlindRotateArgs& a, long max_blocks, hipStream_t st) {
+  long blocks = (a.B + WPB - 1) / WPB;
+  BlindRotateArgs args = a;
+  if (a.counter && blocks > max_blocks) {
+    blocks = max_blocks;                       // persistent: one workgroup per CU, waves pull work
+    hipError_t e = hipMemsetAsync(a.counter, 0, sizeof(unsigned int), st);
+    if (e != hipSuccess) return e;
+  } else {
+    args.counter = nullptr;                    // every wave has exactly one ciphertext
+  }
+  hipLaunchKernelGGL((blind_rotate_kernel<C, WPB>), dim3((unsigned)blocks), dim3(64 * WPB), 0, st, args);
   return hipGetLastError();
 }
 
 template <class C>
-static hipError_t launch_br_cfg(const BlindRotateArgs& a, int wpb, hipStream_t st) {
+static hipError_t launch_br_cfg(const BlindRotateArgs& a, int wpb, long num_cus, hipStream_t st) {
   switch (wpb) {
-    case 1: return launch_br<C, 1>(a, st);
-    case 2: return launch_br<C, 2>(a, st);
-    case 4: return launch_br<C, 4>(a, st);
-    default: return launch_br<C, 8>(a, st);
+    case 1: return launch_br<C, 1>(a, 1L << 40, st);
+    case 2: return launch_br<C, 2>(a, 1L << 40, st);
+    case 4: return launch_br<C, 4>(a, 1L << 40, st);
+    default: return launch_br<C, 8>(a, num_cus, st);   // 152 KB LDS: exactly one workgroup per CU
   }
 }
 
-hipError_t launch_blind_rotate(int cfg, const BlindRotateArgs& a, int wpb, hipStream_t st) {
+hipError_t launch_blind_rotate(int cfg, const BlindRotateArgs& a, int wpb, int num_cus, hipStream_t st) {
   if (a.B <= 0) return hipSuccess;
-  return cfg == 0 ? launch_br_cfg<CfgDefault128>(a, wpb, st) : launch_br_cfg<CfgRedsecV2>(a, wpb, st);
+  return cfg == 0 ? launch_br_cfg<CfgDefault128>(a, wpb, num_cus, st) : launch_br_cfg<CfgRedsecV2>(a, wpb, num_cus, st);
 }
 
 hipError_t launch_bk_transform(int cfg, const int32_t* bk, double* bk_ntt, const double* tw, Field f, double ninv, long n_polys,
