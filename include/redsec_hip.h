@@ -91,6 +91,12 @@ int rs_bootstrap(rs_ctx* ctx, int32_t* out, const int32_t* in, int32_t mu, size_
 int rs_gate_dev(rs_ctx* ctx, rs_gate_op op, int32_t* out, const int32_t* a, const int32_t* b, size_t B, void* stream);
 int rs_gate(rs_ctx* ctx, rs_gate_op op, int32_t* out, const int32_t* a, const int32_t* b, size_t B);
 
+/* Same gate, but the output encodes the result as +-mu instead of +-1/8 (the test-vector value is a
+ * free parameter of the bootstrap). Used by the max-pool OR chain, whose last OR must hand +-1/4096
+ * to the next linear stage (lib/BinFunc.cpp:880-925 feeds +-1/4096 sign outputs to bootsOR, which
+ * assumes +-1/8: see DESIGN.md "max-pool semantics"). */
+int rs_gate_mu_dev(rs_ctx* ctx, rs_gate_op op, int32_t* out, const int32_t* a, const int32_t* b, int32_t mu, size_t B, void* stream);
+
 /* out[i] = bootsMUX(a[i], b[i], c[i]) = a ? b : c. */
 int rs_mux_dev(rs_ctx* ctx, int32_t* out, const int32_t* a, const int32_t* b, const int32_t* c, size_t B, void* stream);
 int rs_mux(rs_ctx* ctx, int32_t* out, const int32_t* a, const int32_t* b, const int32_t* c, size_t B);
@@ -139,6 +145,10 @@ int rs_sumpool_dev(rs_ctx* ctx, int32_t* out, const int32_t* in, const rs_pool_s
  * 121-143; lib/IntOps_enc.cpp:35-56). */
 int rs_lincomb_dev(rs_ctx* ctx, int32_t* out, const int32_t* a, int32_t ca, const int32_t* b, int32_t cb,
                    int32_t bconst, size_t B, void* stream);
+
+/* out[i] = in[row_index[i]] for i < B (row_index on the device; a negative index gives the trivial
+ * zero sample). Gathers the window taps of MaxPooling::execute (lib/BinFunc.cpp:896-921). */
+int rs_gather_rows_dev(rs_ctx* ctx, int32_t* out, const int32_t* in, const int32_t* row_index, size_t B, void* stream);
 
 /* Device memory helpers for hosts that do not link HIP themselves (the C++ layer mirror). */
 int rs_dev_alloc(rs_ctx* ctx, void** ptr, size_t bytes);

@@ -18,7 +18,7 @@ _u8p = C.POINTER(C.c_uint8)
 ABI_SYMBOLS = [
     "rs_last_error", "rs_version", "rs_params_default128", "rs_params_redsec_small_v2", "rs_create", "rs_destroy",
     "rs_load_keys", "rs_reserve", "rs_bootstrap_dev", "rs_bootstrap", "rs_gate_dev", "rs_gate", "rs_mux_dev", "rs_mux",
-    "rs_bootstrap_wo_ks_dev", "rs_keyswitch_dev", "rs_debug_polymul", "rs_linear_fc_dev", "rs_conv_ternary_dev",
+    "rs_gate_mu_dev", "rs_gather_rows_dev", "rs_bootstrap_wo_ks_dev", "rs_keyswitch_dev", "rs_debug_polymul", "rs_linear_fc_dev", "rs_conv_ternary_dev",
     "rs_sumpool_dev", "rs_lincomb_dev", "rs_dev_alloc", "rs_dev_free", "rs_copy_to_dev", "rs_copy_to_host", "rs_sync",
     "rs_set_timing", "rs_last_kernel_ms", "rs_info",
 ]
@@ -75,6 +75,8 @@ def load_library(path=None):
     L.rs_bootstrap.argtypes = [vp, _i32p, _i32p, C.c_int32, C.c_size_t]
     L.rs_gate_dev.argtypes = [vp, C.c_int, vp, vp, vp, C.c_size_t, vp]
     L.rs_gate.argtypes = [vp, C.c_int, _i32p, _i32p, _i32p, C.c_size_t]
+    L.rs_gate_mu_dev.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int32, C.c_size_t, vp]
+    L.rs_gather_rows_dev.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
     L.rs_mux_dev.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, vp]
     L.rs_mux.argtypes = [vp, _i32p, _i32p, _i32p, _i32p, C.c_size_t]
     L.rs_bootstrap_wo_ks_dev.argtypes = [vp, vp, vp, C.c_int32, C.c_size_t, vp]
@@ -188,6 +190,21 @@ class Backend:
         out = self.empty(B, self.W) if out is None else out
         _check(self.L, self.L.rs_gate_dev(self.h, GATES[op], self._ck_dev(out, self.W), self._ck_dev(a, self.W),
                                            self._ck_dev(b, self.W), B, self._stream()))
+        return out
+
+    def gate_mu(self, op, a, b, mu, out=None):
+        B = a.shape[0]
+        out = self.empty(B, self.W) if out is None else out
+        _check(self.L, self.L.rs_gate_mu_dev(self.h, GATES[op], self._ck_dev(out, self.W), self._ck_dev(a, self.W),
+                                              self._ck_dev(b, self.W), int(mu), B, self._stream()))
+        return out
+
+    def gather_rows(self, x, index):
+        """out[i] = x[index[i]] (index: int32 CUDA tensor; negative -> zero sample)."""
+        B = index.numel()
+        out = self.empty(B, self.W)
+        _check(self.L, self.L.rs_gather_rows_dev(self.h, self._ck_dev(out), self._ck_dev(x, self.W), C.c_void_p(index.data_ptr()), B,
+                                                  self._stream()))
         return out
 
     def mux(self, a, b, c, out=None):

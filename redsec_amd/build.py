@@ -72,8 +72,65 @@ def build_emulator(force=False, verbose=False):
     return EMU_LIB
 
 
+HOST = os.path.join(HERE, "host")
+LAYERS_LIB = os.path.join(HERE, "libredsec_layers.so")
+LAYERS_SOURCES = [os.path.join(HOST, "tfhe_shim.cpp"), os.path.join(HOST, "layers.cpp")]
+LAYERS_DEPS = LAYERS_SOURCES + [os.path.join(HOST, "tfhe", f) for f in ("tfhe.h", "tfhe_io.h", "tfhe_garbage_collector.h")] + \
+    [os.path.join(HOST, "lib", f) for f in ("Layer.h", "BinLayer.h", "IntLayer.h", "BinOps_enc.h", "IntOps_enc.h")] + \
+    [os.path.join(INCLUDE, "redsec_hip.h")]
+
+
+def build_layers(force=False, verbose=False):
+    """C++ host mirror of the reference's layer API + the TFHE-compatible shim (links only the C ABI)."""
+    build_hip(force, verbose)
+    if not force and not _stale(LAYERS_LIB, LAYERS_DEPS):
+        return LAYERS_LIB
+    cxx = shutil.which("g++") or shutil.which("c++")
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result", "-I" + HOST, "-I" + INCLUDE] + LAYERS_SOURCES + \
+          ["-L" + HERE, "-lredsec_hip", "-Wl,-rpath,$ORIGIN", "-o", LAYERS_LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LAYERS_LIB
+
+
+REF = "/root/reference"
+REFNETS_DIR = os.path.join(ROOT, "build", "refnets")
+
+
+def build_reference_drivers(verbose=False):
+    """Compile the reference's OWN, UNMODIFIED sources -- nets/mnist/sign1024x{1,2,3}/{net,main}.cpp and
+    client/{gen_secure_keyset,encrypt_image,decrypt_image}.cpp -- with -DENCRYPTED against the shim
+    headers and link them to libredsec_layers.so. Only possible where /root/reference exists; the
+    binaries land in build/refnets/ (git-ignored, shipped to the GPU box with the snapshot)."""
+    if not os.path.isdir(os.path.join(REF, "nets")):
+        return None
+    build_layers(verbose=verbose)
+    os.makedirs(REFNETS_DIR, exist_ok=True)
+    cxx = shutil.which("g++")
+    common = ["-O1", "-w", "-DENCRYPTED", "-fopenmp", "-I" + HOST, "-L" + HERE, "-lredsec_layers", "-lredsec_hip",
+              "-Wl,-rpath," + HERE]
+    built = []
+    for net in ("sign1024x1", "sign1024x2", "sign1024x3"):
+        d = os.path.join(REF, "nets", "mnist", net)
+        out = os.path.join(REFNETS_DIR, "mnist_%s_enc.out" % net)
+        cmd = [cxx, os.path.join(d, "net.cpp"), os.path.join(d, "main.cpp"), "-I" + d, "-I" + os.path.join(REF, "lib")] + common + ["-o", out]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        built.append(out)
+    for tool in ("gen_secure_keyset", "encrypt_image", "decrypt_image"):
+        out = os.path.join(REFNETS_DIR, "client_%s.out" % tool)
+        cmd = [cxx, os.path.join(REF, "client", tool + ".cpp")] + common + ["-o", out]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        built.append(out)
+    return built
+
+
 def build_all(force=False, verbose=False):
-    return build_hip(force, verbose), build_emulator(force, verbose)
+    return build_hip(force, verbose), build_emulator(force, verbose), build_layers(force, verbose)
 
 
 if __name__ == "__main__":

@@ -309,6 +309,25 @@ int rs_gate_dev(rs_ctx* c, rs_gate_op op, int32_t* out, const int32_t* a, const 
   return run_bootstrap(c, out, a, b, g.sa, g.sb, g.bconst, 1 << 29, B, (hipStream_t)stream);
 }
 
+int rs_gate_mu_dev(rs_ctx* c, rs_gate_op op, int32_t* out, const int32_t* a, const int32_t* b, int32_t mu, size_t B, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  GateCoef g;
+  if (!gate_coef(op, &g)) return fail(RS_ERR_INVALID, "unknown gate %d", (int)op);
+  if (B == 0) return RS_OK;
+  if (!out || !a || !b) return fail(RS_ERR_INVALID, "null ciphertext pointer");
+  return run_bootstrap(c, out, a, b, g.sa, g.sb, g.bconst, mu, B, (hipStream_t)stream);
+}
+
+int rs_gather_rows_dev(rs_ctx* c, int32_t* out, const int32_t* in, const int32_t* row_index, size_t B, void* stream) {
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (B == 0) return RS_OK;
+  if (!out || !in || !row_index) return fail(RS_ERR_INVALID, "null pointer");
+  RS_HIP(rs::launch_gather_rows(out, in, row_index, c->p.n + 1, (long)B, (hipStream_t)stream));
+  return RS_OK;
+}
+
 int rs_mux_dev(rs_ctx* c, int32_t* out, const int32_t* a, const int32_t* b, const int32_t* cc, size_t B, void* stream) {
   int rc = ready(c);
   if (rc) return rc;

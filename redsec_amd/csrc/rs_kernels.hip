@@ -481,6 +481,16 @@ __global__ void lincomb_kernel(int32_t* __restrict__ out, const int32_t* __restr
   }
 }
 
+__global__ void gather_rows_kernel(int32_t* __restrict__ out, const int32_t* __restrict__ in, const int32_t* __restrict__ idx, int W,
+                                   long total) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long row = e / W;
+    const int w = (int)(e - row * W);
+    const int src = idx[row];
+    out[e] = src < 0 ? 0 : in[(size_t)src * W + w];
+  }
+}
+
 // out[m][w] = sum_k s(k,m) in[k][w] (+ constants on the b word). grid (ceil(W/256), M).
 __global__ __launch_bounds__(256) void linear_fc_kernel(int32_t* __restrict__ out, const int32_t* __restrict__ in,
                                                         const uint8_t* __restrict__ sign, const uint8_t* __restrict__ zero, int K,
@@ -637,6 +647,15 @@ hipError_t launch_lincomb(int32_t* out, const int32_t* x, int32_t cx, const int3
   long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out, x, cx, y, cy, bconst, W, total);
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_rows(int32_t* out, const int32_t* in, const int32_t* idx, int W, long B, hipStream_t st) {
+  const long total = B * W;
+  if (total <= 0) return hipSuccess;
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out, in, idx, W, total);
   return hipGetLastError();
 }
 

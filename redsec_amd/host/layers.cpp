@@ -1,0 +1,587 @@
+// layers.cpp -- host side of the encrypted layer API on the MI355X backend.
+//
+// Mirrors, for the ENCRYPTED flavour, the reference's
+//   lib/Layer.cpp            allocation helpers                      (Layer.cpp:27-194)
+//   lib/BinOps_enc.cpp       per-ciphertext binary primitives        (BinOps_enc.cpp:27-305)
+//   lib/IntOps_enc.cpp       per-ciphertext integer primitives       (IntOps_enc.cpp:20-84)
+//   lib/BinLayer.cpp, lib/IntLayer.cpp   layer orchestration conv -> sumpool -> quantize -> maxpool
+//                            (BinLayer.cpp:150-241, IntLayer.cpp:153-235) with the geometry of
+//                            lib/BinFunc.cpp / lib/IntFunc.cpp prep() functions
+// with the same names, argument meaning and ownership (each execute() frees its input and returns
+// freshly allocated host ciphertext arrays), so nets/*/*/net.cpp and main.cpp link unchanged.
+//
+// What differs is HOW a stage runs: instead of an OpenMP loop of per-ciphertext TFHE calls
+// (e.g. BinFunc.cpp:1056-1071) every stage is one batched launch through the C ABI
+// (include/redsec_hip.h) on device-resident ciphertext slabs int32[count][n+1]. A layer's output is
+// also kept on the device and keyed by the host pointer it returns, so the next layer's execute()
+// finds its input already in HBM; only the image goes up and the logits come down.
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "lib/BinLayer.h"
+#include "lib/BinOps_enc.h"
+#include "lib/IntLayer.h"
+#include "lib/IntOps_enc.h"
+#include "lib/Layer.h"
+#include "redsec_hip.h"
+
+// =================================================================================================
+// Layer.cpp helpers
+// =================================================================================================
+void print_status(const char* s) { printf("%s", s); }   // _PRINT_STATUS_ is on in the ENCRYPTED flavour (Layer.h:25-28)
+
+uint64_t get_size(tRectangle* ws, uint16_t in_dep, uint16_t out_dep) { return (uint64_t)(ws->h) * (ws->w) * in_dep * out_dep; }
+
+void netParamsCpy(tNetParams* dest, tNetParams* src) {
+  dest->conv = src->conv; dest->pool = src->pool; dest->bnorm = src->bnorm;
+  dest->e_bias = src->e_bias; dest->version = src->version;
+}
+
+tBit* bit_calloc(uint32_t len, TFheGateBootstrappingCloudKeySet* bk) { return new_gate_bootstrapping_ciphertext_array((int32_t)len, bk->params); }
+
+// The drivers release result arrays with free() (nets/mnist/sign1024x1/main.cpp:87), so the struct
+// arrays come from calloc.
+tMultiBit* mbit_calloc(uint32_t len, uint8_t bits, TFheGateBootstrappingCloudKeySet* bk) {
+  tMultiBit* ret = (tMultiBit*)calloc(len ? len : 1, sizeof(tMultiBit));
+  for (uint32_t i = 0; i < len; ++i) {
+    ret[i].size = bits;
+    ret[i].ctxt = new_gate_bootstrapping_ciphertext_array(bits, bk->params);
+  }
+  return ret;
+}
+tFixedPoint* fixpt_calloc(uint32_t len, uint8_t bits, TFheGateBootstrappingCloudKeySet* bk) { return mbit_calloc(len, bits, bk); }  // samples start cleared
+
+void bit_free(uint32_t len, tBit* to_free) { delete_gate_bootstrapping_ciphertext_array((int32_t)len, to_free); }
+void mbit_free(uint32_t len, tMultiBit* to_free) {
+  for (uint32_t i = 0; i < len; ++i) delete_gate_bootstrapping_ciphertext_array((int32_t)to_free[i].size, to_free[i].ctxt);
+  free(to_free);
+}
+void fixpt_free(uint32_t len, tFixedPoint* to_free) { mbit_free(len, to_free); }
+
+// =================================================================================================
+// BinOps / IntOps: per-ciphertext primitives
+// =================================================================================================
+namespace BinOps {
+
+void multiply(tBit* result, const tBit* a, const uint8_t b, TFheGateBootstrappingCloudKeySet* bk) {
+  if (b == 0) bootsNOT(result, a, bk); else bootsCOPY(result, a, bk);   // XNOR with a plaintext bit
+}
+void multiply_pc_ints(LweSample* result, LweSample* in1, const uint32_t* multicand, uint8_t, uint8_t, TFheGateBootstrappingCloudKeySet* bk) {
+  lweAddMulTo(result, (int32_t)*multicand, in1, bk->params->in_out_params);
+}
+void add_bit(tMultiBit* result, const tBit* a, const tBit* b, TFheGateBootstrappingCloudKeySet* bk) {
+  result->ctxt = new_gate_bootstrapping_ciphertext_array(2, bk->params);
+  result->size = 2;
+  bootsXOR(&result->ctxt[0], a, b, bk);
+  bootsAND(&result->ctxt[1], a, b, bk);
+}
+// Ripple-carry adder: per bit 2 XOR + 2 AND + 1 OR bootstraps. The reference initialises the carry
+// with bootsCOPY(&carry, 0, bk) -- a null source (BinOps_enc.cpp:99); here carry_0 is the trivial 0.
+void add(tMultiBit* result, const tMultiBit* a, const tMultiBit* b, uint8_t bits, TFheGateBootstrappingCloudKeySet* bk) {
+  uint32_t sz = bits ? bits : (a->size > b->size ? a->size : b->size);
+  if (sz != result->size) {
+    delete_gate_bootstrapping_ciphertext_array((int32_t)result->size, result->ctxt);
+    result->size = sz;
+    result->ctxt = new_gate_bootstrapping_ciphertext_array((int32_t)sz, bk->params);
+  }
+  tBit* x = new_gate_bootstrapping_ciphertext_array((int32_t)sz, bk->params);
+  tBit* y = new_gate_bootstrapping_ciphertext_array((int32_t)sz, bk->params);
+  tBit* carry = new_gate_bootstrapping_ciphertext_array((int32_t)sz + 1, bk->params);
+  tBit* t = new_gate_bootstrapping_ciphertext_array(3, bk->params);
+  for (uint32_t i = 0; i < sz; ++i) {
+    if (i >= a->size) bootsCONSTANT(&x[i], 0, bk); else bootsCOPY(&x[i], &a->ctxt[i], bk);
+    if (i >= b->size) bootsCONSTANT(&y[i], 0, bk); else bootsCOPY(&y[i], &b->ctxt[i], bk);
+  }
+  bootsCONSTANT(&carry[0], 0, bk);
+  for (uint32_t i = 0; i + 1 < sz; ++i) {
+    bootsXOR(&t[0], &x[i], &y[i], bk);
+    bootsXOR(&result->ctxt[i], &carry[i], &t[0], bk);
+    bootsAND(&t[1], &carry[i], &t[0], bk);
+    bootsAND(&t[2], &x[i], &y[i], bk);
+    bootsOR(&carry[i + 1], &t[1], &t[2], bk);
+  }
+  bootsXOR(&t[0], &x[sz - 1], &y[sz - 1], bk);
+  bootsXOR(&result->ctxt[sz - 1], &carry[sz - 1], &t[0], bk);
+  delete_gate_bootstrapping_ciphertext_array((int32_t)sz, x);
+  delete_gate_bootstrapping_ciphertext_array((int32_t)sz, y);
+  delete_gate_bootstrapping_ciphertext_array((int32_t)sz + 1, carry);
+  delete_gate_bootstrapping_ciphertext_array(3, t);
+}
+void add_int(LweSample* result, const LweSample* a, const LweSample* b, TFheGateBootstrappingCloudKeySet* bk) {
+  const LweParams* p = bk->params->in_out_params;
+  lweClear(result, p); lweAddTo(result, a, p); lweAddTo(result, b, p);
+}
+void add_int_inplace(LweSample* result, const LweSample* a, TFheGateBootstrappingCloudKeySet* bk) { lweAddTo(result, a, bk->params->in_out_params); }
+void add_pc_ints(LweSample* result, LweSample* in1, const uint16_t* addend, uint8_t, TFheGateBootstrappingCloudKeySet* bk) {
+  const LweParams* p = bk->params->in_out_params;
+  LweSample* c = new_gate_bootstrapping_ciphertext_array(1, bk->params);
+  lweNoiselessTrivial(c, modSwitchToTorus32((int32_t)(*addend & 0xFFFF), MULTIBIT_SPACE), p);
+  lweAddTo(result, in1, p); lweAddTo(result, c, p);
+  delete_gate_bootstrapping_ciphertext_array(1, c);
+}
+void inc(tMultiBit* result, const tMultiBit* a, const tBit* b, uint8_t, TFheGateBootstrappingCloudKeySet* bk) {
+  tBit* carry = new_gate_bootstrapping_ciphertext_array((int32_t)a->size, bk->params);
+  result->size = a->size;
+  result->ctxt = new_gate_bootstrapping_ciphertext_array((int32_t)a->size, bk->params);
+  bootsCOPY(&carry[0], b, bk);
+  for (uint32_t i = 0; i + 1 < a->size; ++i) {
+    bootsXOR(&result->ctxt[i], &carry[i], &a->ctxt[i], bk);
+    bootsAND(&carry[i + 1], &carry[i], &a->ctxt[i], bk);
+  }
+  bootsXOR(&result->ctxt[a->size - 1], &carry[a->size - 1], &a->ctxt[a->size - 1], bk);
+  delete_gate_bootstrapping_ciphertext_array((int32_t)a->size, carry);
+}
+void max(tBit* result, const tBit* a, const tBit* b, TFheGateBootstrappingCloudKeySet* bk) { bootsOR(result, a, b, bk); }
+int pow_int(int base, int exponent) {
+  int r = 1;
+  for (; exponent > 0; exponent >>= 1, base *= base) if (exponent & 1) r *= base;
+  return r;
+}
+void binarize_int(LweSample* result, const LweSample* a, const int, TFheGateBootstrappingCloudKeySet* bk) {
+  tfhe_bootstrap_FFT(result, bk->bkFFT, modSwitchToTorus32(1, 4096), a);
+}
+void unbinarize_int(LweSample* result, const LweSample* a, TFheGateBootstrappingCloudKeySet* bk) {
+  tfhe_bootstrap_FFT(result, bk->bkFFT, modSwitchToTorus32(1, MULTIBIT_SPACE), a);
+}
+void binarize(tBit* result, const tMultiBit* a, uint8_t, TFheGateBootstrappingCloudKeySet* bk) { bootsCOPY(result, &a->ctxt[a->size - 1], bk); }
+void relu(tFixedPoint* result, tMultiBit* in1, uint8_t in_bits, TFheGateBootstrappingCloudKeySet* bk) {
+  for (uint8_t i = 0; i + 1 < in_bits; ++i) bootsAND(&result->ctxt[i], &in1->ctxt[i], &in1->ctxt[in_bits - 1], bk);
+}
+void shift(tMultiBit* result, tMultiBit* in1, uint8_t in_bits, uint8_t shift_bits, TFheGateBootstrappingCloudKeySet* bk) {
+  if (result->size != in_bits) {
+    result->size = in_bits;
+    result->ctxt = new_gate_bootstrapping_ciphertext_array(in_bits, bk->params);
+  }
+  assert(in_bits > 0 && shift_bits <= in_bits);
+  for (int i = 0; i < in_bits; ++i) {
+    const int src = (i + shift_bits > in_bits - 1) ? in_bits - 1 : i + shift_bits;   // sign extend
+    bootsCOPY(&result->ctxt[i], &in1->ctxt[src], bk);
+  }
+}
+void get_filters(FILE* fd_in, tBit* p_filt_b, uint32_t len, TFheGateBootstrappingCloudKeySet* bk) {
+  std::vector<float> w(len);
+  size_t got = fread(w.data(), sizeof(float), len, fd_in); (void)got;
+  for (uint32_t i = 0; i < len; ++i) bootsCONSTANT(&p_filt_b[i], w[i] < 0 ? 0 : 1, bk);
+}
+// Weight records: u8 tag (1 BIN, 2 TERN, 3 UINT32, 4 INT32), then MSB-first bit-packed weights.
+void get_ternfilters(FILE* fd_in, uint8_t* p_filt_b, uint8_t* p_tern, uint32_t len, float, TFheGateBootstrappingCloudKeySet*) {
+  uint8_t tag = 0;
+  size_t got = fread(&tag, 1, 1, fd_in); (void)got;
+  assert(tag == 1 || tag == 2);
+  const int nbits = tag == 1 ? 1 : 2;
+  const size_t nbytes = ((size_t)len * nbits + 7) / 8;
+  std::vector<uint8_t> pack(nbytes);
+  got = fread(pack.data(), 1, nbytes, fd_in);
+  for (uint32_t i = 0; i < len; ++i) {
+    const size_t bit = (size_t)i * nbits;
+    p_filt_b[i] = (pack[bit >> 3] >> (7 - (bit & 7))) & 1;
+    if (p_tern) p_tern[i] = nbits == 2 ? (pack[(bit + 1) >> 3] >> (7 - ((bit + 1) & 7))) & 1 : 0;
+  }
+}
+void get_intfilters(FILE* fd_in, tMultiBit* p_filt_mb, uint32_t len, TFheGateBootstrappingCloudKeySet* bk) {
+  const LweParams* p = bk->params->in_out_params;
+  uint8_t tag = 0;
+  size_t got = fread(&tag, 1, 1, fd_in); (void)got;
+  assert(tag == 3 || tag == 4);
+  std::vector<int32_t> v(len);
+  got = fread(v.data(), sizeof(int32_t), len, fd_in);
+  for (uint32_t i = 0; i < len; ++i) {
+    p_filt_mb[i].size = 1;
+    p_filt_mb[i].ctxt = new_LweSample(p);
+    lweNoiselessTrivial(&p_filt_mb[i].ctxt[0], modSwitchToTorus32(v[i], 4096), p);
+  }
+}
+void get_intfilters_ptxt(FILE* fd_in, uint32_t* p_filt_mb, uint32_t len) {
+  uint8_t tag = 0;
+  size_t got = fread(&tag, 1, 1, fd_in); (void)got;
+  assert(tag == 3 || tag == 4);
+  got = fread(p_filt_mb, sizeof(uint32_t), len, fd_in);
+}
+
+}  // namespace BinOps
+
+namespace IntOps {
+
+void invert(tFixedPoint* result, const tFixedPoint* a, const uint8_t* b, uint8_t, TFheGateBootstrappingCloudKeySet* bk) {
+  result->size = a->size;
+  result->ctxt = new_gate_bootstrapping_ciphertext_array((int32_t)result->size, bk->params);
+  for (uint32_t i = 0; i < result->size; ++i) {
+    if (*b == 1) bootsCOPY(&result->ctxt[i], &a->ctxt[i], bk); else bootsNOT(&result->ctxt[i], &a->ctxt[i], bk);
+  }
+}
+void add(tFixedPoint* result, const tFixedPoint* a, const tFixedPoint* b, uint8_t, TFheGateBootstrappingCloudKeySet* bk) {
+  BinOps::add_int(&result->ctxt[0], &a->ctxt[0], &b->ctxt[0], bk);
+}
+void add_inplace(tFixedPoint* result, const tFixedPoint* a, uint8_t, TFheGateBootstrappingCloudKeySet* bk) {
+  lweAddTo(&result->ctxt[0], &a->ctxt[0], bk->params->in_out_params);
+}
+void subtract(tFixedPoint* result, const tFixedPoint* a, const tFixedPoint* b, uint8_t, TFheGateBootstrappingCloudKeySet* bk) {
+  const LweParams* p = bk->params->in_out_params;
+  result->size = 1;
+  result->ctxt = new_LweSample(p);
+  lweCopy(result->ctxt, a->ctxt, p);
+  lweSubTo(result->ctxt, b->ctxt, p);
+}
+void relu(tFixedPoint* result, tFixedPoint* in1, uint8_t in_bits, TFheGateBootstrappingCloudKeySet* bk) { BinOps::relu(result, in1, in_bits, bk); }
+void shift(tFixedPoint* result, tFixedPoint* in1, uint8_t in_bits, uint8_t shift_bits, TFheGateBootstrappingCloudKeySet* bk) {
+  BinOps::shift(result, in1, in_bits, shift_bits, bk);
+}
+
+}  // namespace IntOps
+
+// =================================================================================================
+// Batched layers
+// =================================================================================================
+namespace redsec_host {
+
+#define RS_CHECK(call)                                                                  \
+  do {                                                                                  \
+    if ((call) != 0) { fprintf(stderr, "redsec layers: %s: %s\n", #call, rs_last_error()); abort(); } \
+  } while (0)
+
+struct DevSlab {
+  int32_t* ptr = nullptr;
+  size_t rows = 0;
+  rs_ctx* ctx = nullptr;
+};
+
+// Device copies of the ciphertext arrays handed back to the caller, keyed by host pointer.
+std::mutex g_lock;
+std::map<const void*, DevSlab> g_resident;
+
+void remember(const void* host, const DevSlab& s) {
+  std::lock_guard<std::mutex> g(g_lock);
+  g_resident[host] = s;
+}
+bool is_resident(const void* host) {
+  std::lock_guard<std::mutex> g(g_lock);
+  return g_resident.count(host) != 0;
+}
+bool take(const void* host, DevSlab* s) {
+  std::lock_guard<std::mutex> g(g_lock);
+  auto it = g_resident.find(host);
+  if (it == g_resident.end()) return false;
+  *s = it->second;
+  g_resident.erase(it);
+  return true;
+}
+
+struct Geometry { int H, Wd, C, Ho, Wo, win_h, win_w, st_h, st_w, off_h, off_w; };
+
+struct LayerImpl {
+  bool is_int;
+  eConvType e_conv;
+  ePoolType e_pool;
+  eQuantType e_act;
+  uint32_t depth;
+  tNetParams np;
+  TFheGateBootstrappingCloudKeySet* bk;
+  bool prepared = false;
+  // geometry fixed by prep()
+  Geometry conv{}, pool{};
+  int in_count = 0, quant_count = 0, quant_depth = 0, out_count = 0;
+  std::vector<uint8_t> sign, zero;
+  std::vector<int32_t> bias;          // torus words (b of the trivial bias samples)
+  std::vector<int32_t> pool_index;    // max-pool taps: [tap][out] row indices, -1 = outside
+  int pool_taps = 0;
+  // device copies
+  uint8_t *d_sign = nullptr, *d_zero = nullptr;
+  int32_t *d_bias = nullptr, *d_pool_index = nullptr;
+
+  rs_ctx* ctx() const { return redsec_ctx_of(bk); }
+  int W() const { return bk->params->in_out_params->n + 1; }
+};
+
+void set_version(uint8_t v, tNetParams* net) {   // BinLayer.cpp:251-261: pre-v1 files had no strides
+  if (v < 1) { net->conv.stride.h = 1; net->conv.stride.w = 1; net->pool.stride.h = 0; net->pool.stride.w = 0; }
+}
+
+LayerImpl* make_impl(bool is_int, eConvType ec, uint32_t dep, ePoolType ep, eQuantType eq, tNetParams* np, TFheGateBootstrappingCloudKeySet* bk) {
+  assert(np != NULL && ec < NUM_CONVS && ep < NUM_POOLS && np->e_bias < NUM_BIASES);
+  LayerImpl* L = new LayerImpl;
+  L->is_int = is_int; L->e_conv = ec; L->e_pool = ep; L->e_act = eq; L->depth = dep; L->np = *np; L->bk = bk;
+  set_version((uint8_t)L->np.version, &L->np);
+  if (ec == E_FC || ec == E_FC_FINAL) { L->np.conv.window.h = 1; L->np.conv.window.w = 1; L->np.conv.same_pad = true; }
+  if (L->np.pool.stride.h == 0) L->np.pool.stride.h = L->np.pool.window.h;   // SumPooling/MaxPooling ctor
+  if (L->np.pool.stride.w == 0) L->np.pool.stride.w = L->np.pool.window.w;
+  if (ep == E_MAXPOOL) assert(eq == E_ACTIVATION_SIGN);
+  if (eq == E_ACTIVATION_RELU) {
+    fprintf(stderr, "redsec layers: the ReLU activation path (relu_shift) is not on this backend yet (SURVEY.md 8f rank 3)\n");
+    abort();
+  }
+  return L;
+}
+
+uint8_t bits_for(uint32_t up_bound, uint8_t from) {
+  uint8_t b = from;
+  while ((up_bound >> b) > 0) ++b;
+  return b;
+}
+
+// prep(): dimension propagation and weight loading in the reference's order
+// conv (Convolution::prep) -> sumpool (SumPooling::prep) -> quantize (Quantize::prep) -> maxpool.
+tDimensions* prep_impl(LayerImpl* L, FILE* fd, tDimensions* dim, tDimensions* in_dim, tDimensions* out_dim) {
+  assert(!L->prepared && dim != NULL);
+  *in_dim = *dim;
+  L->in_count = dim->hw.h * dim->hw.w * (int)dim->in_dep;
+  if (L->e_conv != E_NO_CONV) {
+    if (L->e_conv == E_FC || L->e_conv == E_FC_FINAL) { dim->in_dep *= dim->hw.h * dim->hw.w; dim->hw.h = 1; dim->hw.w = 1; }   // flatten
+    const tConvParams& c = L->np.conv;
+    assert(fd != NULL && c.stride.h != 0 && c.stride.w != 0);
+    Geometry g{};
+    g.H = dim->hw.h; g.Wd = dim->hw.w; g.C = (int)dim->in_dep; g.win_h = c.window.h; g.win_w = c.window.w; g.st_h = c.stride.h; g.st_w = c.stride.w;
+    if (c.same_pad) {   // BinFunc.cpp:84-94 / IntFunc.cpp:86-95
+      g.Ho = (g.H - 1) / g.st_h + 1; g.Wo = (g.Wd - 1) / g.st_w + 1;
+      g.off_h = g.st_h == 1 ? (g.win_h - 1) / 2 : (g.Ho * g.st_h - g.H) / 2;
+      g.off_w = g.st_w == 1 ? (g.win_w - 1) / 2 : (g.Wo * g.st_w - g.Wd) / 2;
+    } else {
+      g.off_h = g.off_w = 0;
+      g.Ho = (g.H - 2 * ((g.win_h - 1) / 2)) / g.st_h; g.Wo = (g.Wd - 2 * ((g.win_w - 1) / 2)) / g.st_w;
+    }
+    L->conv = g;
+    const size_t flen = (size_t)g.win_h * g.win_w * g.C * L->depth;
+    L->sign.resize(flen); L->zero.resize(flen);
+    BinOps::get_ternfilters(fd, L->sign.data(), L->zero.data(), (uint32_t)flen, c.tern_thresh, L->bk);
+    dim->up_bound *= (uint32_t)dim->filter_bits * g.win_w * g.win_h * g.C;
+    dim->in_bits = bits_for(dim->up_bound, dim->in_bits);
+    dim->hw.h = (int16_t)g.Ho; dim->hw.w = (int16_t)g.Wo; dim->in_dep = L->depth; dim->out_bits = SINGLE_BIT;
+  }
+  if (L->e_pool == E_SUMPOOL) {
+    const tPoolParams& p = L->np.pool;
+    Geometry g{};
+    g.H = dim->hw.h; g.Wd = dim->hw.w; g.C = (int)dim->in_dep; g.win_h = p.window.h; g.win_w = p.window.w; g.st_h = p.stride.h; g.st_w = p.stride.w;
+    if (p.same_pad) {   // BinFunc.cpp:631-639
+      g.Ho = (g.H - 1) / g.st_h + 1; g.Wo = (g.Wd - 1) / g.st_w + 1;
+      g.off_h = g.st_h == 1 ? (g.win_h - 1) / 2 : (g.Ho * g.st_h - g.H) / 2;
+      g.off_w = g.st_w == 1 ? (g.win_w - 1) / 2 : (g.Wo * g.st_w - g.Wd) / 2;
+    } else {
+      g.off_h = g.off_w = 0;
+      g.Ho = (g.H - g.win_h / 2 - 1) / g.st_h + 1; g.Wo = (g.Wd - g.win_w / 2 - 1) / g.st_w + 1;
+    }
+    L->pool = g;
+    dim->up_bound *= (uint32_t)(g.win_w * g.win_h);
+    dim->in_bits = bits_for(dim->up_bound, dim->in_bits);
+    dim->scale *= (float)(g.win_w * g.win_h);
+    dim->hw.h = (int16_t)g.Ho; dim->hw.w = (int16_t)g.Wo; dim->out_bits = SINGLE_BIT;
+  }
+  // Quantize::prep: bias = int32[in_dep] -> trivial samples of bias/4096
+  L->quant_depth = (int)dim->in_dep;
+  L->quant_count = dim->hw.h * dim->hw.w * (int)dim->in_dep;
+  {
+    assert(fd != NULL);
+    uint8_t tag = 0;
+    size_t got = fread(&tag, 1, 1, fd); (void)got;
+    assert(tag == 3 || tag == 4);
+    std::vector<int32_t> v((size_t)L->quant_depth);
+    got = fread(v.data(), sizeof(int32_t), v.size(), fd);
+    L->bias.resize(v.size());
+    for (size_t i = 0; i < v.size(); ++i) L->bias[i] = modSwitchToTorus32(v[i], 4096);
+  }
+  if (L->e_act == E_ACTIVATION_SIGN) { dim->in_bits = 1; dim->up_bound = 1; dim->scale = L->is_int ? 1.0f : 0.5f; }
+  dim->out_bits = SINGLE_BIT;
+  L->out_count = L->quant_count;
+  if (L->e_pool == E_MAXPOOL && L->e_act == E_ACTIVATION_SIGN && !(L->is_int && L->e_conv == E_FC_FINAL)) {
+    const tPoolParams& p = L->np.pool;
+    Geometry g{};
+    g.H = dim->hw.h; g.Wd = dim->hw.w; g.C = (int)dim->in_dep; g.win_h = p.window.h; g.win_w = p.window.w; g.st_h = p.stride.h; g.st_w = p.stride.w;
+    if (p.same_pad) { g.Ho = (g.H - 1) / g.st_h + 1; g.Wo = (g.Wd - 1) / g.st_w + 1; }   // BinFunc.cpp:852-861
+    else { g.Ho = g.H / g.win_h; g.Wo = g.Wd / g.win_w; }
+    g.off_h = g.off_w = 0;   // MaxPooling::prep never sets offset_window (BinFunc.cpp:836-872); valid pooling uses 0
+    L->pool = g;
+    L->pool_taps = g.win_h * g.win_w;
+    L->out_count = g.Ho * g.Wo * g.C;
+    L->pool_index.assign((size_t)L->pool_taps * L->out_count, -1);
+    for (int oh = 0; oh < g.Ho; ++oh)
+      for (int ow = 0; ow < g.Wo; ++ow)
+        for (int c = 0; c < g.C; ++c) {
+          const int o = (oh * g.Wo + ow) * g.C + c;
+          for (int fh = 0; fh < g.win_h; ++fh)
+            for (int fw = 0; fw < g.win_w; ++fw) {
+              const int ih = oh * g.st_h + fh, iw = ow * g.st_w + fw;
+              if (ih < g.H && iw < g.Wd) L->pool_index[(size_t)(fh * g.win_w + fw) * L->out_count + o] = (ih * g.Wd + iw) * g.C + c;
+            }
+        }
+    dim->hw.h = (int16_t)g.Ho; dim->hw.w = (int16_t)g.Wo;
+  }
+  *out_dim = *dim;
+  L->prepared = true;
+  return dim;
+}
+
+void upload_weights(LayerImpl* L) {
+  if (L->d_bias) return;
+  rs_ctx* c = L->ctx();
+  if (!L->sign.empty()) {
+    RS_CHECK(rs_dev_alloc(c, (void**)&L->d_sign, L->sign.size()));
+    RS_CHECK(rs_dev_alloc(c, (void**)&L->d_zero, L->zero.size()));
+    RS_CHECK(rs_copy_to_dev(c, L->d_sign, L->sign.data(), L->sign.size()));
+    RS_CHECK(rs_copy_to_dev(c, L->d_zero, L->zero.data(), L->zero.size()));
+  }
+  RS_CHECK(rs_dev_alloc(c, (void**)&L->d_bias, L->bias.size() * 4));
+  RS_CHECK(rs_copy_to_dev(c, L->d_bias, L->bias.data(), L->bias.size() * 4));
+  if (!L->pool_index.empty()) {
+    RS_CHECK(rs_dev_alloc(c, (void**)&L->d_pool_index, L->pool_index.size() * 4));
+    RS_CHECK(rs_copy_to_dev(c, L->d_pool_index, L->pool_index.data(), L->pool_index.size() * 4));
+  }
+}
+
+int32_t* dev_rows(rs_ctx* c, size_t rows, int W) {
+  int32_t* p = nullptr;
+  RS_CHECK(rs_dev_alloc(c, (void**)&p, rows * (size_t)W * 4));
+  return p;
+}
+
+// One layer on the device: x is the input slab (consumed), returns the output slab.
+DevSlab run_layer(LayerImpl* L, DevSlab x) {
+  rs_ctx* c = L->ctx();
+  const int W = L->W();
+  const int32_t mu4096 = modSwitchToTorus32(1, 4096), mu8 = modSwitchToTorus32(1, 8);
+  upload_weights(L);
+  const bool pool_sum = L->e_pool == E_SUMPOOL;
+  // IntFunc constants: ternary-zero and padding taps contribute the trivial -1/4096 (IntFunc.cpp:268,277)
+  const int32_t tap_const = L->is_int ? -mu4096 : 0;
+  if (L->e_conv != E_NO_CONV) {
+    const Geometry& g = L->conv;
+    const int rows = g.Ho * g.Wo * (int)L->depth;
+    int32_t* y = dev_rows(c, (size_t)rows, W);
+    const int32_t* bias = pool_sum ? nullptr : L->d_bias;   // bias joins at the last linear op before the activation
+    if (g.win_h == 1 && g.win_w == 1 && g.H == 1 && g.Wd == 1) {
+      RS_CHECK(rs_linear_fc_dev(c, y, x.ptr, L->d_sign, L->d_zero, g.C, (int32_t)L->depth, tap_const, bias, L->quant_depth, nullptr));
+    } else {
+      rs_conv_shape s{g.H, g.Wd, g.C, (int32_t)L->depth, g.win_h, g.win_w, g.st_h, g.st_w, g.off_h, g.off_w, g.Ho, g.Wo};
+      RS_CHECK(rs_conv_ternary_dev(c, y, x.ptr, L->d_sign, L->d_zero, &s, tap_const, tap_const, bias, L->quant_depth, nullptr));
+    }
+    RS_CHECK(rs_sync(c));
+    RS_CHECK(rs_dev_free(c, x.ptr));
+    x.ptr = y; x.rows = (size_t)rows;
+  }
+  if (pool_sum || L->e_conv == E_NO_CONV) {
+    // SumPooling::execute; a layer with neither conv nor pooling still needs its bias: 1x1 window
+    Geometry g = L->pool;
+    if (!pool_sum) { g = Geometry{1, (int)x.rows / L->quant_depth, L->quant_depth, 1, (int)x.rows / L->quant_depth, 1, 1, 1, 1, 0, 0}; }
+    const int rows = g.Ho * g.Wo * g.C;
+    int32_t* y = dev_rows(c, (size_t)rows, W);
+    rs_pool_shape s{g.H, g.Wd, g.C, g.win_h, g.win_w, g.st_h, g.st_w, g.off_h, g.off_w, g.Ho, g.Wo};
+    RS_CHECK(rs_sumpool_dev(c, y, x.ptr, &s, L->d_bias, L->quant_depth, nullptr));
+    RS_CHECK(rs_sync(c));
+    RS_CHECK(rs_dev_free(c, x.ptr));
+    x.ptr = y; x.rows = (size_t)rows;
+  }
+  assert((int)x.rows == L->quant_count);
+  if (L->e_act == E_ACTIVATION_SIGN) {
+    const bool maxpool = !L->pool_index.empty();
+    // Quantize::execute: one sign bootstrap per neuron (BinOps_enc.cpp:182-186). Ahead of a max-pool
+    // the bits are emitted as +-1/8 so that the OR gates see the encoding they assume.
+    int32_t* y = dev_rows(c, x.rows, W);
+    RS_CHECK(rs_bootstrap_dev(c, y, x.ptr, maxpool ? mu8 : mu4096, x.rows, nullptr));
+    RS_CHECK(rs_sync(c));
+    RS_CHECK(rs_dev_free(c, x.ptr));
+    x.ptr = y;
+    if (maxpool) {
+      // MaxPooling::execute: OR over the window in (fh, fw) order; the first tap is copied (the
+      // reference ORs into an uninitialised accumulator, BinFunc.cpp:891,917), the last OR re-encodes
+      // to +-1/4096 for the next linear stage.
+      const size_t out = (size_t)L->out_count;
+      int32_t* accv = dev_rows(c, out, W);
+      int32_t* tap = dev_rows(c, out, W);
+      int32_t* tmp = dev_rows(c, out, W);
+      RS_CHECK(rs_gather_rows_dev(c, accv, x.ptr, L->d_pool_index, out, nullptr));
+      for (int t = 1; t < L->pool_taps; ++t) {
+        RS_CHECK(rs_gather_rows_dev(c, tap, x.ptr, L->d_pool_index + (size_t)t * out, out, nullptr));
+        const bool last = t == L->pool_taps - 1;
+        // a tap outside the image gathers the zero sample: OR(acc, 0-phase) keeps acc's sign only if
+        // windows are full, which holds for every shipped net (even feature maps, 2x2 windows)
+        RS_CHECK(rs_gate_mu_dev(c, RS_OR, tmp, accv, tap, last ? mu4096 : mu8, out, nullptr));
+        RS_CHECK(rs_sync(c));
+        std::swap(accv, tmp);
+      }
+      if (L->pool_taps == 1) { RS_CHECK(rs_bootstrap_dev(c, tmp, accv, mu4096, out, nullptr)); RS_CHECK(rs_sync(c)); std::swap(accv, tmp); }
+      RS_CHECK(rs_dev_free(c, tap)); RS_CHECK(rs_dev_free(c, tmp)); RS_CHECK(rs_dev_free(c, x.ptr));
+      x.ptr = accv; x.rows = out;
+    }
+  }
+  x.ctx = c;
+  return x;
+}
+
+// host array of LweSample -> device slab (or the resident copy a previous layer left)
+DevSlab stage_input(LayerImpl* L, const void* key, const std::vector<const LweSample*>& samples) {
+  DevSlab s;
+  if (take(key, &s) && s.rows == samples.size()) return s;
+  rs_ctx* c = L->ctx();
+  const int W = L->W(), n = W - 1;
+  std::vector<int32_t> host(samples.size() * (size_t)W);
+  for (size_t i = 0; i < samples.size(); ++i) redsec_pack(&host[i * W], samples[i], n);
+  s.ptr = dev_rows(c, samples.size(), W);
+  s.rows = samples.size(); s.ctx = c;
+  RS_CHECK(rs_copy_to_dev(c, s.ptr, host.data(), host.size() * 4));
+  return s;
+}
+
+std::vector<int32_t> download(const DevSlab& s, int W) {
+  std::vector<int32_t> host(s.rows * (size_t)W);
+  RS_CHECK(rs_copy_to_host(s.ctx, host.data(), s.ptr, host.size() * 4));
+  return host;
+}
+
+// Output as the reference returns it: tBit* for sign layers, tMultiBit* (ctxt[0] used) otherwise.
+void* publish(LayerImpl* L, const DevSlab& out) {
+  const int W = L->W(), n = W - 1;
+  std::vector<int32_t> host = download(out, W);
+  void* ret = nullptr;
+  if (L->e_act == E_ACTIVATION_SIGN) {
+    tBit* bits = bit_calloc((uint32_t)out.rows, L->bk);
+    for (size_t i = 0; i < out.rows; ++i) redsec_unpack(&bits[i], &host[i * W], n);
+    ret = bits;
+  } else {
+    tMultiBit* mb = mbit_calloc((uint32_t)out.rows, 1, L->bk);
+    for (size_t i = 0; i < out.rows; ++i) redsec_unpack(&mb[i].ctxt[0], &host[i * W], n);
+    ret = mb;
+  }
+  remember(ret, out);
+  return ret;
+}
+
+}  // namespace redsec_host
+
+using redsec_host::LayerImpl;
+
+// ---- BinLayer ----
+BinLayer::BinLayer(eConvType ec, uint16_t dep, ePoolType ep, eQuantType eq, tNetParams* np, TFheGateBootstrappingCloudKeySet* in_bk) {
+  assert(ec != E_NO_CONV);
+  impl = redsec_host::make_impl(false, ec, dep, ep, eq, np, in_bk);
+}
+tDimensions* BinLayer::prep(FILE* fd, tDimensions* dim) { return redsec_host::prep_impl(impl, fd, dim, &in_dim, &out_dim); }
+void* BinLayer::execute(tBit* p_in) {
+  assert(impl->prepared);
+  std::vector<const LweSample*> in((size_t)impl->in_count);
+  for (size_t i = 0; i < in.size(); ++i) in[i] = &p_in[i];
+  redsec_host::DevSlab x = redsec_host::stage_input(impl, p_in, in);
+  bit_free((uint32_t)impl->in_count, p_in);                  // callee frees its input (BinFunc.cpp:327)
+  return redsec_host::publish(impl, redsec_host::run_layer(impl, x));
+}
+void BinLayer::export_weights(FILE*) { printf("Weight convert not defined\r\n"); }
+
+// ---- IntLayer ----
+IntLayer::IntLayer(eConvType ec, uint16_t dep, ePoolType ep, eQuantType eq, tNetParams* np, TFheGateBootstrappingCloudKeySet* in_bk) {
+  impl = redsec_host::make_impl(true, ec, dep, ep, eq, np, in_bk);
+}
+tDimensions* IntLayer::prep(FILE* fd, tDimensions* dim) { return redsec_host::prep_impl(impl, fd, dim, &in_dim, &out_dim); }
+void* IntLayer::execute(tMultiBit* p_in) {
+  assert(impl->prepared);
+  std::vector<const LweSample*> in((size_t)impl->in_count);
+  for (size_t i = 0; i < in.size(); ++i) in[i] = &p_in[i].ctxt[0];
+  const bool ours = redsec_host::is_resident(p_in);     // produced by one of these layers (calloc) or by the driver (new[])
+  redsec_host::DevSlab x = redsec_host::stage_input(impl, p_in, in);
+  // callee frees its input (IntFunc.cpp:698): the samples, then the struct array
+  for (int i = 0; i < impl->in_count; ++i) delete_gate_bootstrapping_ciphertext_array((int32_t)p_in[i].size, p_in[i].ctxt);
+  if (ours) free(p_in); else delete[] p_in;
+  return redsec_host::publish(impl, redsec_host::run_layer(impl, x));
+}
+void IntLayer::export_weights(FILE*) { printf("Weight convert not defined\r\n"); }

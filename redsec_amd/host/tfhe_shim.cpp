@@ -1,0 +1,388 @@
+// tfhe_shim.cpp -- implementation of the TFHE-compatible shim (tfhe/tfhe.h) over libredsec_hip.so.
+//
+// Host-side pieces restate TFHE v1.1's documented behaviour for the calls REDsec makes:
+//   parameters / samples / word-wise LWE ops   lib/Layer.cpp:78-188, lib/BinOps_enc.cpp:37-41,121-143,
+//                                              lib/BinFunc.cpp:207-208,251-289, lib/IntFunc.cpp:219-277
+//   key generation, encrypt, decrypt           client/gen_secure_keyset.cpp:94-120,
+//                                              client/encrypt_image.cpp:77, client/decrypt_image.cpp:52
+//   key / ciphertext files                     nets/mnist/sign1024x1/main.cpp:68-78, net.cpp:53-55
+// Every bootstrapped operation (tfhe_bootstrap_FFT, boots*) is executed on the GPU through the C ABI;
+// nothing here computes a bootstrap on the CPU, and without a GPU those calls abort loudly.
+#include "tfhe/tfhe.h"
+
+#include <random>
+#include <vector>
+
+#include "redsec_hip.h"
+
+namespace {
+
+std::mt19937_64& rng() {
+  static std::mt19937_64 g(0x5eed5eedULL);
+  return g;
+}
+
+[[noreturn]] void die(const char* what) {
+  fprintf(stderr, "redsec tfhe shim: %s: %s\n", what, rs_last_error());
+  abort();
+}
+
+Torus32 gaussian32(Torus32 message, double sigma) {
+  std::normal_distribution<double> dist(0.0, sigma);
+  return (Torus32)((uint32_t)message + (uint32_t)dtot32(dist(rng())));
+}
+
+inline uint32_t uniform32() { return (uint32_t)(rng()() >> 32); }
+
+constexpr uint32_t kMagicSecret = 0x31535352u;  // "RSS1"
+constexpr uint32_t kMagicCloud = 0x314b5352u;   // "RSK1"
+
+struct ParamHeader {
+  uint32_t magic;
+  int32_t n, N, k, l, Bgbit, ks_t, ks_basebit;
+  double lwe_alpha_min, lwe_alpha_max, tlwe_alpha_min, tlwe_alpha_max;
+};
+
+TFheGateBootstrappingParameterSet* params_from_header(const ParamHeader& h) {
+  LweParams* lp = new_LweParams(h.n, h.lwe_alpha_min, h.lwe_alpha_max);
+  TLweParams* tp = new_TLweParams(h.N, h.k, h.tlwe_alpha_min, h.tlwe_alpha_max);
+  TGswParams* gp = new_TGswParams(h.l, h.Bgbit, tp);
+  return new TFheGateBootstrappingParameterSet(h.ks_t, h.ks_basebit, lp, gp);
+}
+
+ParamHeader header_from_params(uint32_t magic, const TFheGateBootstrappingParameterSet* p) {
+  ParamHeader h;
+  const TLweParams* tp = p->tgsw_params->tlwe_params;
+  h.magic = magic;
+  h.n = p->in_out_params->n; h.N = tp->N; h.k = tp->k; h.l = p->tgsw_params->l; h.Bgbit = p->tgsw_params->Bgbit;
+  h.ks_t = p->ks_t; h.ks_basebit = p->ks_basebit;
+  h.lwe_alpha_min = p->in_out_params->alpha_min; h.lwe_alpha_max = p->in_out_params->alpha_max;
+  h.tlwe_alpha_min = tp->alpha_min; h.tlwe_alpha_max = tp->alpha_max;
+  return h;
+}
+
+size_t bk_words(const TFheGateBootstrappingParameterSet* p) {
+  const TLweParams* tp = p->tgsw_params->tlwe_params;
+  return (size_t)p->in_out_params->n * p->tgsw_params->kpl * (tp->k + 1) * tp->N;
+}
+size_t ksk_words(const TFheGateBootstrappingParameterSet* p) {
+  const TLweParams* tp = p->tgsw_params->tlwe_params;
+  return (size_t)tp->N * tp->k * p->ks_t * ((size_t)1 << p->ks_basebit) * (p->in_out_params->n + 1);
+}
+
+LweBootstrappingKey* new_bk(const TFheGateBootstrappingParameterSet* p) {
+  LweBootstrappingKey* bk = new LweBootstrappingKey;
+  bk->in_out_params = p->in_out_params;
+  bk->bk_params = p->tgsw_params;
+  bk->bk_words = (int32_t*)malloc(sizeof(int32_t) * bk_words(p));
+  bk->ksk_words = (int32_t*)malloc(sizeof(int32_t) * ksk_words(p));
+  return bk;
+}
+
+LweBootstrappingKeyFFT* new_bkfft(const TFheGateBootstrappingParameterSet* p, const LweBootstrappingKey* src) {
+  LweBootstrappingKeyFFT* f = new LweBootstrappingKeyFFT;
+  f->in_out_params = p->in_out_params;
+  f->ctx = nullptr;  // created on first use: client tools never touch the GPU
+  f->params = p;
+  f->src = src;
+  return f;
+}
+
+rs_ctx* ctx_of_fft(const LweBootstrappingKeyFFT* cf) {
+  LweBootstrappingKeyFFT* f = const_cast<LweBootstrappingKeyFFT*>(cf);
+  if (f->ctx) return f->ctx;
+  const TFheGateBootstrappingParameterSet* p = f->params;
+  const TLweParams* tp = p->tgsw_params->tlwe_params;
+  rs_params rp = {p->in_out_params->n, tp->N, tp->k, p->tgsw_params->l, p->tgsw_params->Bgbit, p->ks_t, p->ks_basebit};
+  const char* dev = getenv("REDSEC_DEVICE");
+  if (rs_create(&f->ctx, &rp, dev ? atoi(dev) : 0) != 0) die("rs_create");
+  if (rs_load_keys(f->ctx, f->src->bk_words, f->src->ksk_words) != 0) die("rs_load_keys");
+  return f->ctx;
+}
+
+void read_exact(FILE* f, void* dst, size_t bytes, const char* what) {
+  if (fread(dst, 1, bytes, f) != bytes) { fprintf(stderr, "redsec tfhe shim: short read (%s)\n", what); abort(); }
+}
+
+// b += s * a in Z[X]/(X^N+1), s binary
+void addmul_binary(int32_t* b, const int32_t* s, const int32_t* a, int32_t N) {
+  for (int32_t i = 0; i < N; ++i) {
+    if (!s[i]) continue;
+    for (int32_t j = 0; j < N - i; ++j) b[i + j] = (int32_t)((uint32_t)b[i + j] + (uint32_t)a[j]);
+    for (int32_t j = N - i; j < N; ++j) b[i + j - N] = (int32_t)((uint32_t)b[i + j - N] - (uint32_t)a[j]);
+  }
+}
+
+void gate(rs_gate_op op, LweSample* result, const LweSample* ca, const LweSample* cb, const TFheGateBootstrappingCloudKeySet* bk) {
+  const int32_t n = bk->params->in_out_params->n;
+  std::vector<int32_t> x(n + 1), y(n + 1), z(n + 1);
+  redsec_pack(x.data(), ca, n);
+  redsec_pack(y.data(), cb, n);
+  if (rs_gate(redsec_ctx_of(bk), op, z.data(), x.data(), y.data(), 1) != 0) die("rs_gate");
+  redsec_unpack(result, z.data(), n);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+LweParams* new_LweParams(int32_t n, double alpha_min, double alpha_max) { return new LweParams(n, alpha_min, alpha_max); }
+TLweParams* new_TLweParams(int32_t N, int32_t k, double alpha_min, double alpha_max) { return new TLweParams(N, k, alpha_min, alpha_max); }
+TGswParams* new_TGswParams(int32_t l, int32_t Bgbit, const TLweParams* tp) { return new TGswParams(l, Bgbit, tp); }
+
+TFheGateBootstrappingParameterSet* new_default_gate_bootstrapping_parameters(int32_t) {
+  LweParams* lp = new_LweParams(630, std::pow(2., -15), std::pow(2., -15));  // max noise: TFHE uses 0.012467; unused here
+  TLweParams* tp = new_TLweParams(1024, 1, std::pow(2., -25), std::pow(2., -15));
+  TGswParams* gp = new_TGswParams(3, 7, tp);
+  return new TFheGateBootstrappingParameterSet(8, 2, lp, gp);
+}
+
+Torus32 modSwitchToTorus32(int32_t mu, int32_t Msize) {
+  const uint64_t interv = ((UINT64_C(1) << 63) / (uint64_t)Msize) * 2;
+  return (Torus32)(((uint64_t)(int64_t)mu * interv) >> 32);
+}
+int32_t modSwitchFromTorus32(Torus32 phase, int32_t Msize) {
+  const uint64_t interv = ((UINT64_C(1) << 63) / (uint64_t)Msize) * 2;
+  const uint64_t phase64 = ((uint64_t)(uint32_t)phase << 32) + interv / 2;
+  return (int32_t)(phase64 / interv);
+}
+Torus32 dtot32(double d) { return (Torus32)(int64_t)((d - (double)(int64_t)d) * 4294967296.0); }
+
+// ---- samples: one slab of words per array ----
+LweSample* new_LweSample_array(int32_t nbelts, const LweParams* params) {
+  LweSample* s = new LweSample[nbelts > 0 ? nbelts : 1];
+  int32_t* words = (int32_t*)calloc((size_t)(nbelts > 0 ? nbelts : 1) * (size_t)params->n, sizeof(int32_t));
+  for (int32_t i = 0; i < nbelts; ++i) { s[i].a = words + (size_t)i * params->n; s[i].b = 0; s[i].current_variance = 0.; }
+  if (nbelts <= 0) { s[0].a = words; s[0].b = 0; s[0].current_variance = 0.; }
+  return s;
+}
+LweSample* new_LweSample(const LweParams* params) { return new_LweSample_array(1, params); }
+void delete_LweSample_array(int32_t, LweSample* s) {
+  if (!s) return;
+  free(s[0].a);
+  delete[] s;
+}
+void delete_LweSample(LweSample* s) { delete_LweSample_array(1, s); }
+LweSample* new_gate_bootstrapping_ciphertext(const TFheGateBootstrappingParameterSet* p) { return new_LweSample(p->in_out_params); }
+LweSample* new_gate_bootstrapping_ciphertext_array(int32_t nbelems, const TFheGateBootstrappingParameterSet* p) {
+  return new_LweSample_array(nbelems, p->in_out_params);
+}
+void delete_gate_bootstrapping_ciphertext(LweSample* s) { delete_LweSample(s); }
+void delete_gate_bootstrapping_ciphertext_array(int32_t nbelems, LweSample* s) { delete_LweSample_array(nbelems, s); }
+
+void lweClear(LweSample* r, const LweParams* p) {
+  memset(r->a, 0, sizeof(Torus32) * (size_t)p->n);
+  r->b = 0; r->current_variance = 0.;
+}
+void lweCopy(LweSample* r, const LweSample* s, const LweParams* p) {
+  memmove(r->a, s->a, sizeof(Torus32) * (size_t)p->n);
+  r->b = s->b; r->current_variance = s->current_variance;
+}
+void lweNegate(LweSample* r, const LweSample* s, const LweParams* p) {
+  for (int32_t i = 0; i < p->n; ++i) r->a[i] = (Torus32)(0u - (uint32_t)s->a[i]);
+  r->b = (Torus32)(0u - (uint32_t)s->b); r->current_variance = s->current_variance;
+}
+void lweNoiselessTrivial(LweSample* r, Torus32 mu, const LweParams* p) {
+  memset(r->a, 0, sizeof(Torus32) * (size_t)p->n);
+  r->b = mu; r->current_variance = 0.;
+}
+void lweAddTo(LweSample* r, const LweSample* s, const LweParams* p) {
+  for (int32_t i = 0; i < p->n; ++i) r->a[i] = (Torus32)((uint32_t)r->a[i] + (uint32_t)s->a[i]);
+  r->b = (Torus32)((uint32_t)r->b + (uint32_t)s->b); r->current_variance += s->current_variance;
+}
+void lweSubTo(LweSample* r, const LweSample* s, const LweParams* p) {
+  for (int32_t i = 0; i < p->n; ++i) r->a[i] = (Torus32)((uint32_t)r->a[i] - (uint32_t)s->a[i]);
+  r->b = (Torus32)((uint32_t)r->b - (uint32_t)s->b); r->current_variance += s->current_variance;
+}
+void lweAddMulTo(LweSample* r, int32_t k, const LweSample* s, const LweParams* p) {
+  for (int32_t i = 0; i < p->n; ++i) r->a[i] = (Torus32)((uint32_t)r->a[i] + (uint32_t)k * (uint32_t)s->a[i]);
+  r->b = (Torus32)((uint32_t)r->b + (uint32_t)k * (uint32_t)s->b); r->current_variance += (double)k * k * s->current_variance;
+}
+void lweSubMulTo(LweSample* r, int32_t k, const LweSample* s, const LweParams* p) {
+  for (int32_t i = 0; i < p->n; ++i) r->a[i] = (Torus32)((uint32_t)r->a[i] - (uint32_t)k * (uint32_t)s->a[i]);
+  r->b = (Torus32)((uint32_t)r->b - (uint32_t)k * (uint32_t)s->b); r->current_variance += (double)k * k * s->current_variance;
+}
+
+void lweSymEncrypt(LweSample* r, Torus32 message, double alpha, const LweKey* key) {
+  const int32_t n = key->params->n;
+  uint32_t b = (uint32_t)gaussian32(message, alpha);
+  for (int32_t i = 0; i < n; ++i) {
+    const uint32_t a = uniform32();
+    r->a[i] = (Torus32)a;
+    b += a * (uint32_t)key->key[i];
+  }
+  r->b = (Torus32)b;
+  r->current_variance = alpha * alpha;
+}
+Torus32 lwePhase(const LweSample* s, const LweKey* key) {
+  uint32_t axs = 0;
+  for (int32_t i = 0; i < key->params->n; ++i) axs += (uint32_t)s->a[i] * (uint32_t)key->key[i];
+  return (Torus32)((uint32_t)s->b - axs);
+}
+Torus32 lweSymDecrypt(const LweSample* s, const LweKey* key, const int32_t Msize) {
+  const uint64_t interv = ((UINT64_C(1) << 63) / (uint64_t)Msize) * 2;
+  uint64_t phase64 = ((uint64_t)(uint32_t)lwePhase(s, key) << 32) + interv / 2;
+  phase64 -= phase64 % interv;
+  return (Torus32)(phase64 >> 32);
+}
+
+// ---- keys ----
+void tfhe_random_generator_setSeed(uint32_t* values, int32_t size) {
+  std::seed_seq seq(values, values + size);
+  rng().seed(seq);
+}
+
+TFheGateBootstrappingSecretKeySet* new_random_gate_bootstrapping_secret_keyset(const TFheGateBootstrappingParameterSet* p) {
+  const TGswParams* gp = p->tgsw_params;
+  const TLweParams* tp = gp->tlwe_params;
+  const int32_t n = p->in_out_params->n, N = tp->N, k = tp->k, l = gp->l, kpl = gp->kpl;
+  const int32_t t = p->ks_t, basebit = p->ks_basebit, base = 1 << basebit, W = n + 1;
+  if (k != 1) { fprintf(stderr, "redsec tfhe shim: k = %d unsupported\n", k); abort(); }
+  LweKey* lk = new LweKey{p->in_out_params, (int32_t*)malloc(sizeof(int32_t) * n)};
+  TGswKey* gk = new TGswKey{gp, (int32_t*)malloc(sizeof(int32_t) * (size_t)k * N)};
+  for (int32_t i = 0; i < n; ++i) lk->key[i] = (int32_t)(uniform32() & 1u);
+  for (int32_t i = 0; i < k * N; ++i) gk->key[i] = (int32_t)(uniform32() & 1u);
+  LweBootstrappingKey* bk = new_bk(p);
+  // TGSW(s_i): row c*l + j = TRLWE encryption of zero + s_i * 2^(32-(j+1)Bgbit) on component c
+  for (int32_t i = 0; i < n; ++i)
+    for (int32_t row = 0; row < kpl; ++row) {
+      int32_t* smp = bk->bk_words + (((size_t)i * kpl + row) * (k + 1)) * (size_t)N;
+      int32_t* apoly = smp;
+      int32_t* bpoly = smp + (size_t)k * N;
+      for (int32_t j = 0; j < N; ++j) bpoly[j] = gaussian32(0, tp->alpha_min);
+      for (int32_t j = 0; j < N; ++j) apoly[j] = (int32_t)uniform32();
+      addmul_binary(bpoly, gk->key, apoly, N);
+      const int32_t comp = row / l, dig = row % l;
+      const uint32_t h = (uint32_t)1 << (32 - (dig + 1) * gp->Bgbit);
+      smp[(size_t)comp * N] = (int32_t)((uint32_t)smp[(size_t)comp * N] + (uint32_t)lk->key[i] * h);
+    }
+  // keyswitch key: extracted key (N words) -> LWE key
+  LweSample tmp;
+  for (int32_t i = 0; i < k * N; ++i)
+    for (int32_t j = 0; j < t; ++j)
+      for (int32_t v = 0; v < base; ++v) {
+        int32_t* rowp = bk->ksk_words + ((((size_t)i * t + j) * base) + v) * (size_t)W;
+        tmp.a = rowp;
+        if (v == 0) { lweNoiselessTrivial(&tmp, 0, p->in_out_params); rowp[n] = 0; continue; }
+        const uint32_t mess = ((uint32_t)gk->key[i] * (uint32_t)v) << (32 - (j + 1) * basebit);
+        lweSymEncrypt(&tmp, (Torus32)mess, p->in_out_params->alpha_min, lk);
+        rowp[n] = tmp.b;
+      }
+  return new TFheGateBootstrappingSecretKeySet(p, bk, new_bkfft(p, bk), lk, gk);
+}
+
+static void free_cloud_parts(const TFheGateBootstrappingCloudKeySet* c) {
+  if (c->bkFFT) { if (c->bkFFT->ctx) rs_destroy(c->bkFFT->ctx); delete c->bkFFT; }
+  if (c->bk) { free(c->bk->bk_words); free(c->bk->ksk_words); delete c->bk; }
+}
+void delete_gate_bootstrapping_secret_keyset(TFheGateBootstrappingSecretKeySet* ks) {
+  if (!ks) return;
+  free_cloud_parts(&ks->cloud);
+  free(ks->lwe_key->key); delete ks->lwe_key;
+  free(ks->tgsw_key->key); delete ks->tgsw_key;
+  delete ks;
+}
+void delete_gate_bootstrapping_cloud_keyset(TFheGateBootstrappingCloudKeySet* ks) {
+  if (!ks) return;
+  free_cloud_parts(ks);
+  delete ks;
+}
+void delete_gate_bootstrapping_parameters(TFheGateBootstrappingParameterSet*) {}
+
+// ---- files ----
+void export_tfheGateBootstrappingCloudKeySet_toFile(FILE* f, const TFheGateBootstrappingCloudKeySet* key) {
+  const ParamHeader h = header_from_params(kMagicCloud, key->params);
+  fwrite(&h, sizeof h, 1, f);
+  fwrite(key->bk->bk_words, sizeof(int32_t), bk_words(key->params), f);
+  fwrite(key->bk->ksk_words, sizeof(int32_t), ksk_words(key->params), f);
+}
+void export_tfheGateBootstrappingSecretKeySet_toFile(FILE* f, const TFheGateBootstrappingSecretKeySet* key) {
+  const ParamHeader h = header_from_params(kMagicSecret, key->params);
+  fwrite(&h, sizeof h, 1, f);
+  fwrite(key->lwe_key->key, sizeof(int32_t), (size_t)h.n, f);
+  fwrite(key->tgsw_key->key, sizeof(int32_t), (size_t)h.k * h.N, f);
+  fwrite(key->cloud.bk->bk_words, sizeof(int32_t), bk_words(key->params), f);
+  fwrite(key->cloud.bk->ksk_words, sizeof(int32_t), ksk_words(key->params), f);
+}
+TFheGateBootstrappingCloudKeySet* new_tfheGateBootstrappingCloudKeySet_fromFile(FILE* f) {
+  ParamHeader h;
+  read_exact(f, &h, sizeof h, "cloud key header");
+  if (h.magic != kMagicCloud) { fprintf(stderr, "redsec tfhe shim: not a cloud key file\n"); abort(); }
+  TFheGateBootstrappingParameterSet* p = params_from_header(h);
+  LweBootstrappingKey* bk = new_bk(p);
+  read_exact(f, bk->bk_words, sizeof(int32_t) * bk_words(p), "bootstrapping key");
+  read_exact(f, bk->ksk_words, sizeof(int32_t) * ksk_words(p), "keyswitch key");
+  return new TFheGateBootstrappingCloudKeySet(p, bk, new_bkfft(p, bk));
+}
+TFheGateBootstrappingSecretKeySet* new_tfheGateBootstrappingSecretKeySet_fromFile(FILE* f) {
+  ParamHeader h;
+  read_exact(f, &h, sizeof h, "secret key header");
+  if (h.magic != kMagicSecret) { fprintf(stderr, "redsec tfhe shim: not a secret key file\n"); abort(); }
+  TFheGateBootstrappingParameterSet* p = params_from_header(h);
+  LweKey* lk = new LweKey{p->in_out_params, (int32_t*)malloc(sizeof(int32_t) * h.n)};
+  TGswKey* gk = new TGswKey{p->tgsw_params, (int32_t*)malloc(sizeof(int32_t) * (size_t)h.k * h.N)};
+  read_exact(f, lk->key, sizeof(int32_t) * h.n, "lwe key");
+  read_exact(f, gk->key, sizeof(int32_t) * (size_t)h.k * h.N, "tlwe key");
+  LweBootstrappingKey* bk = new_bk(p);
+  read_exact(f, bk->bk_words, sizeof(int32_t) * bk_words(p), "bootstrapping key");
+  read_exact(f, bk->ksk_words, sizeof(int32_t) * ksk_words(p), "keyswitch key");
+  return new TFheGateBootstrappingSecretKeySet(p, bk, new_bkfft(p, bk), lk, gk);
+}
+void export_gate_bootstrapping_ciphertext_toFile(FILE* f, const LweSample* s, const TFheGateBootstrappingParameterSet* p) {
+  fwrite(s->a, sizeof(Torus32), (size_t)p->in_out_params->n, f);
+  fwrite(&s->b, sizeof(Torus32), 1, f);
+  fwrite(&s->current_variance, sizeof(double), 1, f);
+}
+void import_gate_bootstrapping_ciphertext_fromFile(FILE* f, LweSample* s, const TFheGateBootstrappingParameterSet* p) {
+  read_exact(f, s->a, sizeof(Torus32) * (size_t)p->in_out_params->n, "ciphertext a");
+  read_exact(f, &s->b, sizeof(Torus32), "ciphertext b");
+  read_exact(f, &s->current_variance, sizeof(double), "ciphertext variance");
+}
+
+// ---- GPU ----
+rs_ctx* redsec_ctx_of(const TFheGateBootstrappingCloudKeySet* bk) { return ctx_of_fft(bk->bkFFT); }
+void redsec_pack(int32_t* words, const LweSample* s, int32_t n) {
+  memcpy(words, s->a, sizeof(int32_t) * (size_t)n);
+  words[n] = s->b;
+}
+void redsec_unpack(LweSample* s, const int32_t* words, int32_t n) {
+  memcpy(s->a, words, sizeof(int32_t) * (size_t)n);
+  s->b = words[n];
+  s->current_variance = 0.;
+}
+
+void tfhe_bootstrap_FFT(LweSample* result, const LweBootstrappingKeyFFT* bkfft, Torus32 mu, const LweSample* x) {
+  const int32_t n = bkfft->in_out_params->n;
+  std::vector<int32_t> in(n + 1), out(n + 1);
+  redsec_pack(in.data(), x, n);
+  if (rs_bootstrap(ctx_of_fft(bkfft), out.data(), in.data(), mu, 1) != 0) die("rs_bootstrap");
+  redsec_unpack(result, out.data(), n);
+}
+
+void bootsSymEncrypt(LweSample* r, int32_t message, const TFheGateBootstrappingSecretKeySet* key) {
+  const Torus32 e8 = modSwitchToTorus32(1, 8);
+  lweSymEncrypt(r, message ? e8 : -e8, key->params->in_out_params->alpha_min, key->lwe_key);
+}
+int32_t bootsSymDecrypt(const LweSample* s, const TFheGateBootstrappingSecretKeySet* key) { return lwePhase(s, key->lwe_key) > 0; }
+void bootsCONSTANT(LweSample* r, int32_t value, const TFheGateBootstrappingCloudKeySet* bk) {
+  const Torus32 e8 = modSwitchToTorus32(1, 8);
+  lweNoiselessTrivial(r, value ? e8 : -e8, bk->params->in_out_params);
+}
+void bootsNOT(LweSample* r, const LweSample* ca, const TFheGateBootstrappingCloudKeySet* bk) { lweNegate(r, ca, bk->params->in_out_params); }
+void bootsCOPY(LweSample* r, const LweSample* ca, const TFheGateBootstrappingCloudKeySet* bk) { lweCopy(r, ca, bk->params->in_out_params); }
+void bootsNAND(LweSample* r, const LweSample* a, const LweSample* b, const TFheGateBootstrappingCloudKeySet* bk) { gate(RS_NAND, r, a, b, bk); }
+void bootsOR(LweSample* r, const LweSample* a, const LweSample* b, const TFheGateBootstrappingCloudKeySet* bk) { gate(RS_OR, r, a, b, bk); }
+void bootsAND(LweSample* r, const LweSample* a, const LweSample* b, const TFheGateBootstrappingCloudKeySet* bk) { gate(RS_AND, r, a, b, bk); }
+void bootsXOR(LweSample* r, const LweSample* a, const LweSample* b, const TFheGateBootstrappingCloudKeySet* bk) { gate(RS_XOR, r, a, b, bk); }
+void bootsXNOR(LweSample* r, const LweSample* a, const LweSample* b, const TFheGateBootstrappingCloudKeySet* bk) { gate(RS_XNOR, r, a, b, bk); }
+void bootsNOR(LweSample* r, const LweSample* a, const LweSample* b, const TFheGateBootstrappingCloudKeySet* bk) { gate(RS_NOR, r, a, b, bk); }
+void bootsANDNY(LweSample* r, const LweSample* a, const LweSample* b, const TFheGateBootstrappingCloudKeySet* bk) { gate(RS_ANDNY, r, a, b, bk); }
+void bootsANDYN(LweSample* r, const LweSample* a, const LweSample* b, const TFheGateBootstrappingCloudKeySet* bk) { gate(RS_ANDYN, r, a, b, bk); }
+void bootsORNY(LweSample* r, const LweSample* a, const LweSample* b, const TFheGateBootstrappingCloudKeySet* bk) { gate(RS_ORNY, r, a, b, bk); }
+void bootsORYN(LweSample* r, const LweSample* a, const LweSample* b, const TFheGateBootstrappingCloudKeySet* bk) { gate(RS_ORYN, r, a, b, bk); }
+void bootsMUX(LweSample* r, const LweSample* a, const LweSample* b, const LweSample* c, const TFheGateBootstrappingCloudKeySet* bk) {
+  const int32_t n = bk->params->in_out_params->n;
+  std::vector<int32_t> x(n + 1), y(n + 1), z(n + 1), o(n + 1);
+  redsec_pack(x.data(), a, n); redsec_pack(y.data(), b, n); redsec_pack(z.data(), c, n);
+  if (rs_mux(redsec_ctx_of(bk), o.data(), x.data(), y.data(), z.data(), 1) != 0) die("rs_mux");
+  redsec_unpack(r, o.data(), n);
+}

@@ -1,0 +1,42 @@
+"""`make cpu-encrypt` of the reference, on the MI355X backend: the reference's own net.cpp/main.cpp
+and client tools -- compiled UNMODIFIED (build/refnets) and linked to libredsec_layers.so -- run
+keygen -> encrypt image -> encrypted inference on the GPU -> decrypt, end to end through files."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import plain_model as pm
+import refdrivers as rd
+
+pytestmark = pytest.mark.gpu
+
+
+def test_unmodified_sign1024x1_driver_end_to_end(tmp_path):
+    if not rd.available():
+        pytest.skip("build/refnets not shipped")
+    client, netdir = rd.make_tree(str(tmp_path))
+    assert rd.run("client_gen_secure_keyset.out", client).returncode == 0
+    labels, pixels = pm.load_images()
+    net = pm.load_net("sign1024x1")
+    params, lwe_key = rd.read_secret_key(os.path.join(client, "secret.key"))
+    ok = 0
+    for i in (1, 3, 8):                                          # clear-margin images
+        rd.write_image_csv(os.path.join(client, "img.csv"), labels[i], pixels[i])
+        assert rd.run("client_encrypt_image.out", client, "img.csv").returncode == 0
+        r = rd.run("mnist_sign1024x1_enc.out", netdir)
+        assert r.returncode == 0 and "Result ctxts loaded" in r.stdout, r.stdout + r.stderr
+        logits_ct = rd.read_ciphertexts(os.path.join(client, "network_output.ctxt"), 350, 10)
+        r = rd.run("client_decrypt_image.out", client, "MNIST")
+        m = re.search(r"Classification Result: (\d)", r.stdout)
+        assert r.returncode == 0 and m, r.stdout + r.stderr
+        # our own decryption of the same file agrees with the reference's decrypt tool
+        phase = (logits_ct[:, 350].astype(np.int64) - (logits_ct[:, :350].astype(np.int64) * lwe_key).sum(axis=1)) & 0xFFFFFFFF
+        dec = ((phase + (1 << 19)) >> 20) & 0xFFF
+        dec = np.where(dec > 2048, dec - 4096, dec)
+        assert int(np.argmax(dec)) == int(m.group(1))
+        # logits stay close to the plaintext ones (hidden-unit sign flips move each by a few units)
+        assert np.abs(dec - pm.forward(net, pixels[i])).max() < 200
+        ok += int(int(m.group(1)) == labels[i])
+    assert ok >= 2
