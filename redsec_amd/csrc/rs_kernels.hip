@@ -14,6 +14,8 @@
 // other after the twiddle tables are staged, so the 2 waves per SIMD interleave freely.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "rs_kernels.h"
 #include "rs_ntt.h"
 
@@ -293,6 +295,119 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs 
 }
 
 // -------------------------------------------------------------------------------------------------
+// Cooperative blind rotation (latency form, B <= 2 x #CUs): G waves share ONE ciphertext.
+// Wave g transforms the digit polynomials [g R, (g+1) R) (R = 2l / G, so each wave stays within one
+// accumulator component) and accumulates its partial column sums; the partials meet in LDS, waves 0
+// and 1 sum one column each, run the inverse transform and update the shared accumulator. Two
+// workgroup barriers per CMUX step. A 196-neuron layer thus spreads over 196 CUs x 4 SIMDs
+// instead of one wave per CU (MNIST layer 0: 18.4 ms -> see profiles/).
+// -------------------------------------------------------------------------------------------------
+#if !defined(RS_STAMPS)
+template <class C, int G>
+__global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateArgs a) {
+  constexpr int KPL = 2 * C::L;
+  constexpr int R = KPL / G;
+  static_assert(KPL % G == 0 && G % 2 == 0, "waves must split the digit rows evenly within a component");
+  __shared__ double s_tw[kTwTotal];
+  __shared__ double s_buf[G][kBufDoubles];
+  __shared__ double s_part[G][2][kN];
+  __shared__ int32_t s_acc[2][kN];
+  stage_tables(s_tw, a.tw, 64 * G, kTwTotal);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const long ct = blockIdx.x;
+  const Field f = a.f;
+  double* buf = s_buf[wave];
+  const double* tw = s_tw;
+  const double* twi = s_tw + kN;
+  const int32_t* row0 = a.in0 + ct * a.W;
+  const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
+  const int n = a.n;
+  const int comp = wave / (G / 2);
+  const int row_begin = wave * R;
+  auto word = [&](int i) -> int32_t {
+    uint32_t v = (uint32_t)a.c0 * (uint32_t)row0[i];
+    if (row1) v += (uint32_t)a.c1 * (uint32_t)row1[i];
+    return (int32_t)v;
+  };
+  if (wave < 2) {
+    const int32_t barb = modswitch_2N((int32_t)((uint32_t)word(n) + (uint32_t)a.bconst));
+    const int rot = 2 * kN - barb;
+#pragma unroll
+    for (int r = 0; r < kRegs; ++r) {
+      const int j = lane + 64 * r;
+      s_acc[wave][j] = wave == 0 ? 0 : rotated_const(a.mu, j, rot);
+    }
+  }
+  __syncthreads();
+  constexpr uint32_t offset = gadget_offset<C>();
+  for (int i = 0; i < n; ++i) {
+    const int32_t bara = __builtin_amdgcn_readfirstlane(modswitch_2N(word(i)));
+    if (bara == 0) continue;   // uniform over the workgroup: every wave works on the same ciphertext
+    double s0[kRegs], s1[kRegs];
+#pragma unroll
+    for (int u = 0; u < kRegs; ++u) { s0[u] = 0.0; s1[u] = 0.0; }
+    const double* bk_i = a.bk_ntt + (size_t)i * KPL * 2 * kN;
+    int32_t d[kRegs];
+#pragma unroll
+    for (int r = 0; r < kRegs; ++r) d[r] = rotated_diff(s_acc[comp], lane + 64 * r, bara);
+#pragma unroll 1
+    for (int rr = 0; rr < R; ++rr) {
+      const int row = row_begin + rr;
+      const int q = row - comp * C::L;
+      const double2* bp0 = reinterpret_cast<const double2*>(bk_i + (size_t)(row * 2) * kN);
+      const double2* bp1 = bp0 + kN / 2;
+      double2 w0[8], w1[8];
+#pragma unroll
+      for (int v = 0; v < 8; ++v) { w0[v] = bp0[v * 64 + lane]; w1[v] = bp1[v * 64 + lane]; }
+      double x[kRegs];
+      ntt_forward_digits<C>(lane, x, d, q, offset, tw, buf, f);
+#pragma unroll
+      for (int v = 0; v < 8; ++v) {
+        s0[2 * v] += f_mulmod(x[2 * v], w0[v].x, f);
+        s0[2 * v + 1] += f_mulmod(x[2 * v + 1], w0[v].y, f);
+        s1[2 * v] += f_mulmod(x[2 * v], w1[v].x, f);
+        s1[2 * v + 1] += f_mulmod(x[2 * v + 1], w1[v].y, f);
+      }
+    }
+    // partial sums (<= R products each) reduced, then exchanged: position u*64 + lane is conflict-free
+#pragma unroll
+    for (int u = 0; u < kRegs; ++u) {
+      s_part[wave][0][u * 64 + lane] = f_reduce(s0[u], f);
+      s_part[wave][1][u * 64 + lane] = f_reduce(s1[u], f);
+    }
+    __syncthreads();   // partials visible; every wave has finished reading the accumulator
+    if (wave < 2) {
+      double x[kRegs];
+#pragma unroll
+      for (int u = 0; u < kRegs; ++u) {
+        double t = s_part[0][wave][u * 64 + lane];
+#pragma unroll
+        for (int g = 1; g < G; ++g) t += s_part[g][wave][u * 64 + lane];
+        x[u] = t;
+      }
+      ntt_inverse<C>(lane, x, twi, buf, f);
+#pragma unroll
+      for (int r = 0; r < kRegs; ++r) {
+        const int j = lane + 64 * r;
+        s_acc[wave][j] = (int32_t)((uint32_t)s_acc[wave][j] + (uint32_t)f_to_torus32(x[r]));
+      }
+    }
+    __syncthreads();   // accumulator updated
+  }
+  int32_t* out = a.u_out + ct * (kN + 1);
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < kRegs; ++r) {
+      const int j = lane + 64 * r;
+      out[j] = (j == 0) ? s_acc[0][0] : (int32_t)(0u - (uint32_t)s_acc[0][kN - j]);
+    }
+    if (lane == 0) out[kN] = s_acc[1][0];
+  }
+}
+#endif
+
+// -------------------------------------------------------------------------------------------------
 // Keyswitch: one workgroup per ciphertext, threads over output words. The KSK (83-104 MB) stays in
 // the Infinity Cache; rows are gathered by digit. u = u0 (+ u1) (+ bconst on the b word): the sum
 // form serves bootsMUX.
@@ -392,12 +507,17 @@ __global__ __launch_bounds__(KS_TILE_THREADS) void keyswitch_tiled_kernel(Keyswi
     }
   };
 
+  // blockIdx.z selects a slice of the N input coefficients (latency form for small batches: the
+  // slices add their partial sums into a zeroed output with integer atomics -- exact and
+  // order-independent mod 2^32); gridDim.z == 1 is the plain-store throughput form.
+  const int groups_per_split = (kN / KS_IG) / (int)gridDim.z;
+  const int g_begin = (int)blockIdx.z * groups_per_split, g_end = g_begin + groups_per_split;
   __syncthreads();
-  stage(0, 0);
+  stage(g_begin & 1, g_begin * KS_IG);
   __syncthreads();
-  for (int g = 0; g < kN / KS_IG; ++g) {
+  for (int g = g_begin; g < g_end; ++g) {
     const int buf = g & 1;
-    if (g + 1 < kN / KS_IG) stage(buf ^ 1, (g + 1) * KS_IG);
+    if (g + 1 < g_end) stage(buf ^ 1, (g + 1) * KS_IG);
     const int i0 = g * KS_IG;
     uint32_t ai[KS_IG];
 #pragma unroll
@@ -425,14 +545,25 @@ __global__ __launch_bounds__(KS_TILE_THREADS) void keyswitch_tiled_kernel(Keyswi
     __syncthreads();
   }
   if (!live) return;
-  uint32_t bw = (uint32_t)u0[kN];
-  if (u1) bw += (uint32_t)u1[kN];
-  bw += (uint32_t)a.bconst;
+  uint32_t bw = 0;
+  if (blockIdx.z == 0) {
+    bw = (uint32_t)u0[kN];
+    if (u1) bw += (uint32_t)u1[kN];
+    bw += (uint32_t)a.bconst;
+  }
   int32_t* out = a.out + ct * W + w0;
+  if (gridDim.z == 1) {
 #pragma unroll
-  for (int k = 0; k < KS_CH; ++k) {
-    const int w = w0 + k;
-    if (w < W) out[k] = (int32_t)((w == W - 1 ? bw : 0u) - acc[k]);
+    for (int k = 0; k < KS_CH; ++k) {
+      const int w = w0 + k;
+      if (w < W) out[k] = (int32_t)((w == W - 1 ? bw : 0u) - acc[k]);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < KS_CH; ++k) {
+      const int w = w0 + k;
+      if (w < W) atomicAdd(reinterpret_cast<unsigned int*>(out + k), (w == W - 1 ? bw : 0u) - acc[k]);
+    }
   }
 }
 
@@ -602,6 +733,20 @@ static hipError_t launch_br_cfg(const BlindRotateArgs& a, int wpb, long num_cus,
 
 hipError_t launch_blind_rotate(int cfg, const BlindRotateArgs& a, int wpb, int num_cus, hipStream_t st) {
   if (a.B <= 0) return hipSuccess;
+#if !defined(RS_STAMPS)
+  // latency form: several waves per ciphertext while the batch cannot fill the chip by itself
+  if (!getenv("RS_NO_COOP")) {
+    if (cfg == 1 && a.B <= num_cus) {
+      hipLaunchKernelGGL((blind_rotate_coop_kernel<CfgRedsecV2, 4>), dim3((unsigned)a.B), dim3(256), 0, st, a);
+      return hipGetLastError();
+    }
+    if (a.B <= 2L * num_cus) {
+      if (cfg == 0) hipLaunchKernelGGL((blind_rotate_coop_kernel<CfgDefault128, 2>), dim3((unsigned)a.B), dim3(128), 0, st, a);
+      else hipLaunchKernelGGL((blind_rotate_coop_kernel<CfgRedsecV2, 2>), dim3((unsigned)a.B), dim3(128), 0, st, a);
+      return hipGetLastError();
+    }
+  }
+#endif
   return cfg == 0 ? launch_br_cfg<CfgDefault128>(a, wpb, num_cus, st) : launch_br_cfg<CfgRedsecV2>(a, wpb, num_cus, st);
 }
 
@@ -618,7 +763,18 @@ hipError_t launch_bk_transform(int cfg, const int32_t* bk, double* bk_ntt, const
 
 hipError_t launch_keyswitch(const KeyswitchArgs& a, hipStream_t st) {
   if (a.B <= 0) return hipSuccess;
-  const dim3 grid((unsigned)((a.B + KS_TILE_THREADS - 1) / KS_TILE_THREADS), (unsigned)((a.W + KS_CH - 1) / KS_CH));
+  dim3 grid((unsigned)((a.B + KS_TILE_THREADS - 1) / KS_TILE_THREADS), (unsigned)((a.W + KS_CH - 1) / KS_CH), 1);
+  const bool tiled = (a.t == 8 && a.basebit == 2) || (a.t == 9 && a.basebit == 3);
+  if (tiled) {
+    // small batches: slice the input coefficients until ~1024 workgroups exist (latency form)
+    unsigned split = 1;
+    while (split < 64 && grid.x * grid.y * split < 1024) split *= 2;
+    if (split > 1) {
+      hipError_t e = hipMemsetAsync(a.out, 0, (size_t)a.B * a.W * sizeof(int32_t), st);
+      if (e != hipSuccess) return e;
+      grid.z = split;
+    }
+  }
   if (a.t == 8 && a.basebit == 2) {
     hipLaunchKernelGGL((keyswitch_tiled_kernel<8, 2, 4>), grid, dim3(KS_TILE_THREADS), 0, st, a);
   } else if (a.t == 9 && a.basebit == 3) {
