@@ -144,8 +144,16 @@ def main():
         per_boot = bk_bytes / R + 2 * be.W * 4 + (p.N + 1) * 4
         alg_bytes = per_boot * G
         achieved = alg_bytes / (last_br * 1e-3) / 1e9
+        # fabric-side traffic of the same launch from the committed rocprofv3 --pmc passes (cannot be
+        # collected from inside the process); only filled when it was measured for this workload
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
+            traffic = pmc.get("%s_%d" % (args.params, G), {}).get("traffic_bytes")
+        except Exception:
+            pass
         roofline = {"bound": "hbm", "kernel": "blind_rotate_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                     "kernel_ms": round(last_br, 3), "algorithmic_bytes_per_launch": int(alg_bytes),
                     "resident_ciphertexts_per_key_sweep": R}
         fwd_red, inv_red = (2, 3) if p.bk_l == 3 else (0, 1)
