@@ -30,15 +30,15 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_GOPS = 256 * 4 * 16 * 2.4   # CUs x SIMDs x fp64 lanes/clk x GHz = 39,322 G lane-ops/s
 
 
-def fp64_ops_per_bootstrap(n, l, fwd_red, inv_red):
-    """FP64 VALU lane-operations per bootstrap: per CMUX 2l forward and 2
-    inverse transforms of 5,120 butterflies x 8 ops, full reductions of 1,024 x 3 ops, the
-    pointwise stage 4l x 1,024 x 7 ops, digit conversion and output conversion."""
-    bfly = 5120 * 8
-    fwd = bfly + fwd_red * 1024 * 3 + 1024           # + int -> fp64 conversion
-    inv = bfly + (inv_red + 2) * 1024 * 3 + 1024     # + input/output reductions, + magic add
-    point = 4 * l * 1024 * 7
-    return n * (2 * l * fwd + 2 * inv + point)
+def fp64_ops_per_bootstrap(n, l, fwd_red, inv_red, fused_ops):
+    """FP64 VALU lane-operations per bootstrap. Per lane (16 coefficients)
+    and CMUX: 2l forward transforms = fused stages 0-1 (`fused_ops`) + 8 stages x 8 butterflies x 8 ops
+    + full reductions of 16 x 3 ops; pointwise 2 columns x 16 x 7 ops per row; one mid-reduction of
+    32 x 3; 2 inverse transforms = 80 butterflies x 8 + (inv_red + 2) reductions + 16 conversions."""
+    fwd = fused_ops + 8 * 8 * 8 + fwd_red * 48
+    inv = 80 * 8 + (inv_red + 2) * 48 + 16
+    per_lane = 2 * l * (fwd + 2 * 16 * 7) + 2 * inv + 96
+    return n * per_lane * 64
 
 
 def main():
@@ -156,12 +156,12 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                     "kernel_ms": round(last_br, 3), "algorithmic_bytes_per_launch": int(alg_bytes),
                     "resident_ciphertexts_per_key_sweep": R}
-        fwd_red, inv_red = (2, 3) if p.bk_l == 3 else (0, 1)
-        ops = fp64_ops_per_bootstrap(p.n, p.bk_l, fwd_red, inv_red) * G
+        fwd_red, inv_red, fused = (2, 3, 36) if p.bk_l == 3 else (0, 1, 48)
+        ops = fp64_ops_per_bootstrap(p.n, p.bk_l, fwd_red, inv_red, fused) * G
         valu = ops / (last_br * 1e-3) / 1e9
         roofline_valu = {"bound": "fp64-valu-issue", "achieved": round(valu, 1), "peak": round(FP64_VALU_PEAK_GOPS, 1),
                          "unit": "G fp64 lane-ops/s", "frac": round(valu / FP64_VALU_PEAK_GOPS, 4),
-                         "fp64_ops_per_bootstrap": fp64_ops_per_bootstrap(p.n, p.bk_l, fwd_red, inv_red)}
+                         "fp64_ops_per_bootstrap": fp64_ops_per_bootstrap(p.n, p.bk_l, fwd_red, inv_red, fused)}
 
         # ---- CPU baseline + parity on a bounded sample of the same workload ----
         cpu = None

@@ -99,7 +99,7 @@ REFNETS_DIR = os.path.join(ROOT, "build", "refnets")
 
 
 def build_reference_drivers(verbose=False):
-    """Compile the reference's OWN, UNMODIFIED sources -- nets/mnist/sign1024x{1,2,3}/{net,main}.cpp and
+    """Compile the reference's OWN, UNMODIFIED sources -- nets/mnist/sign1024x{1,2,3}/{net,main}.cpp, nets/cifar/binarynet{,_small}/{net,main}.cpp and
     client/{gen_secure_keyset,encrypt_image,decrypt_image}.cpp -- with -DENCRYPTED against the shim
     headers and link them to libredsec_layers.so. Only possible where /root/reference exists; the
     binaries land in build/refnets/ (git-ignored, shipped to the GPU box with the snapshot)."""
@@ -111,9 +111,10 @@ def build_reference_drivers(verbose=False):
     common = ["-O1", "-w", "-DENCRYPTED", "-fopenmp", "-I" + HOST, "-L" + HERE, "-lredsec_layers", "-lredsec_hip",
               "-Wl,-rpath," + HERE]
     built = []
-    for net in ("sign1024x1", "sign1024x2", "sign1024x3"):
-        d = os.path.join(REF, "nets", "mnist", net)
-        out = os.path.join(REFNETS_DIR, "mnist_%s_enc.out" % net)
+    for family, net in (("mnist", "sign1024x1"), ("mnist", "sign1024x2"), ("mnist", "sign1024x3"),
+                        ("cifar", "binarynet"), ("cifar", "binarynet_small")):
+        d = os.path.join(REF, "nets", family, net)
+        out = os.path.join(REFNETS_DIR, "%s_%s_enc.out" % (family, net))
         cmd = [cxx, os.path.join(d, "net.cpp"), os.path.join(d, "main.cpp"), "-I" + d, "-I" + os.path.join(REF, "lib")] + common + ["-o", out]
         if verbose:
             print(" ".join(cmd))

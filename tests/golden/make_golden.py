@@ -51,5 +51,31 @@ def main():
         print(net, "accuracy", acc, "image0", logits[0] if logits else progress[:3])
 
 
+def cifar():
+    """CIFAR nets: the reference's main.cpp runs NUM_SAMPLES = 1 image (main.cpp:25) and prints only
+    label/prediction, so the fixture holds that one prediction plus the first 20 rows of
+    nets/cifar/cifar_data.csv and the packed weights."""
+    rows = [l.strip() for l in open(os.path.join(REF, "nets/cifar/cifar_data.csv")) if l.strip()]
+    images = []
+    for line in rows[:20]:
+        vals = [int(v) for v in line.split(",") if v != ""]
+        images.append({"label": vals[0], "pixels": vals[1:3073]})
+    json.dump({"source": "first 20 rows of nets/cifar/cifar_data.csv (label, 3072 values, HWC order)",
+               "labels": [im["label"] for im in images], "pixels": [im["pixels"] for im in images]},
+              open(os.path.join(HERE, "cifar_images.json"), "w"), separators=(",", ":"))
+    for net in ("binarynet", "binarynet_small"):
+        exe = os.path.join(ROOT, "oracle/_ref/cifar_%s_ptxt.out" % net)
+        out = subprocess.run([exe], cwd=os.path.join(REF, "nets/cifar", net), capture_output=True, text=True, check=True).stdout
+        progress = [[int(g) for g in m.groups()] for m in
+                    re.finditer(r"correct:\s+(\d+)\s+image_i:\s+(\d+)\s+Label: (\d+)\s+Prediction: (\d+)", out)]
+        json.dump({"source": "reference plaintext flavour (make ptxt), nets/cifar/%s, NUM_SAMPLES=1" % net,
+                   "progress_correct_image_label_prediction": progress},
+                  open(os.path.join(HERE, "cifar_%s.json" % net), "w"), separators=(",", ":"))
+        shutil.copyfile(os.path.join(REF, "nets/cifar", net, "var_prep.dat"), os.path.join(HERE, "cifar_%s_var_prep.dat" % net))
+        print("cifar", net, progress)
+
+
 if __name__ == "__main__":
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    cifar()
     main()

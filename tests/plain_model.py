@@ -41,3 +41,61 @@ def forward(net, pixels, taps=None):
     sign, zero, bias = net.final
     w = np.where(zero == 1, 0, np.where(sign == 1, 1, -1)).astype(np.int64)
     return bits @ w + bias.astype(np.int64)
+
+
+# ---- CIFAR binarynet / binarynet_small (nets/cifar/*/net.cpp:96-209) ---------------------------------
+CIFAR_WIDTHS = {"binarynet": ([128, 128, 256, 256, 512, 512], [1024, 1024]),
+                "binarynet_small": ([64, 64, 128, 128, 256, 256], [512, 512])}
+
+
+def load_cifar_images():
+    d = json.load(open(os.path.join(GOLD, "cifar_images.json")))
+    return np.array(d["labels"]), np.array(d["pixels"], dtype=np.int64)
+
+
+class CifarNet:
+    """IntLayer(NO_CONV, SIGN) ; 6 x BinLayer(CONV 3x3 same, SIGN, max-pool after every second) ;
+    2 x BinLayer(FC, SIGN) ; BinLayer(FC_FINAL, NONE). Weight layouts as lib/BinFunc.cpp:388."""
+
+    def __init__(self, name):
+        from redsec_amd.nets import WeightReader
+        convs, fcs = CIFAR_WIDTHS[name]
+        r = WeightReader(open(os.path.join(GOLD, "cifar_%s_var_prep.dat" % name), "rb").read())
+        self.bias0 = r.ints(3)
+        self.convs = []
+        cin = 3
+        for cout in convs:
+            sign, zero = r.ternary(3 * 3 * cin * cout)
+            self.convs.append((sign.reshape(3, 3, cin, cout), zero.reshape(3, 3, cin, cout), r.ints(cout)))
+            cin = cout
+        k = 4 * 4 * cin
+        self.fcs = []
+        for m in fcs + [10]:
+            sign, zero = r.ternary(k * m)
+            self.fcs.append((sign.reshape(k, m), zero.reshape(k, m), r.ints(m)))
+            k = m
+        assert r.done()
+
+
+def cifar_forward(net, pixels, taps=None):
+    x = (2 * pixels - 255).reshape(32, 32, 3)
+    bits = np.where(x + net.bias0.astype(np.int64)[None, None, :] >= 0, 1, -1)
+    for li, (sign, zero, bias) in enumerate(net.convs):
+        H, W, C = bits.shape
+        w = np.where(zero == 1, 0, np.where(sign == 1, 1, -1)).astype(np.int64).reshape(9 * C, -1)
+        pad = np.zeros((H + 2, W + 2, C), np.int64)
+        pad[1:-1, 1:-1] = bits                                   # out-of-image taps contribute 0 (BinFunc.cpp:266-289)
+        cols = np.stack([pad[fh:fh + H, fw:fw + W] for fh in range(3) for fw in range(3)], axis=2).reshape(H * W, 9 * C)
+        pre = (cols @ w + bias.astype(np.int64)).reshape(H, W, -1)
+        bits = np.where(pre >= 0, 1, -1)
+        if taps is not None:
+            taps["pre%d" % (li + 1)] = pre
+        if li % 2 == 1:                                          # E_MAXPOOL 2x2 on layers 2, 4, 6
+            bits = bits.reshape(H // 2, 2, W // 2, 2, -1).max(axis=(1, 3))
+    v = bits.reshape(-1)
+    for i, (sign, zero, bias) in enumerate(net.fcs):
+        w = np.where(zero == 1, 0, np.where(sign == 1, 1, -1)).astype(np.int64)
+        pre = v @ w + bias.astype(np.int64)
+        if i == len(net.fcs) - 1:
+            return pre
+        v = np.where(pre >= 0, 1, -1)

@@ -40,3 +40,35 @@ def test_unmodified_sign1024x1_driver_end_to_end(tmp_path):
         assert np.abs(dec - pm.forward(net, pixels[i])).max() < 200
         ok += int(int(m.group(1)) == labels[i])
     assert ok >= 2
+
+
+def test_unmodified_cifar_binarynet_small_driver(tmp_path):
+    """BASELINE configs[3] shape through the C++ mirror: the reference's nets/cifar/binarynet_small
+    {net,main}.cpp, unmodified -- IntLayer(NO_CONV) + 6 ternary 3x3 convolutions with three 2x2
+    max-pools (OR chains) + 3 FC layers = 348,160 bootstraps -- on one clear-margin image."""
+    import shutil
+    if not os.path.exists(os.path.join(rd.REFNETS, "cifar_binarynet_small_enc.out")):
+        pytest.skip("build/refnets not shipped")
+    client = str(tmp_path / "client")
+    netdir = str(tmp_path / "nets" / "cifar" / "binarynet_small")
+    os.makedirs(client); os.makedirs(netdir)
+    shutil.copyfile(os.path.join(rd.GOLD, "cifar_binarynet_small_var_prep.dat"), os.path.join(netdir, "var_prep.dat"))
+    assert rd.run("client_gen_secure_keyset.out", client).returncode == 0
+    labels, pix = pm.load_cifar_images()
+    net = pm.CifarNet("binarynet_small")
+    i = 1
+    with open(os.path.join(client, "img.csv"), "w") as f:
+        f.write(",".join(str(int(v)) for v in [labels[i], 32, 32, 3] + list(pix[i])) + ",\n")
+    assert rd.run("client_encrypt_image.out", client, "img.csv").returncode == 0
+    r = rd.run("cifar_binarynet_small_enc.out", netdir)
+    assert r.returncode == 0 and "Result ctxts loaded" in r.stdout, r.stdout + r.stderr
+    r = rd.run("client_decrypt_image.out", client, "CIFAR-10")
+    m = re.search(r"Classification Result: (\d)", r.stdout)
+    plain = pm.cifar_forward(net, pix[i])
+    assert m and int(m.group(1)) == int(np.argmax(plain)) == labels[i]       # margin 342 vs 36 in plaintext
+    params, lwe_key = rd.read_secret_key(os.path.join(client, "secret.key"))
+    ct = rd.read_ciphertexts(os.path.join(client, "network_output.ctxt"), 350, 10)
+    phase = (ct[:, 350].astype(np.int64) - (ct[:, :350].astype(np.int64) * lwe_key).sum(axis=1)) & 0xFFFFFFFF
+    dec = ((phase + (1 << 19)) >> 20) & 0xFFF
+    dec = np.where(dec > 2048, dec - 4096, dec)
+    assert np.corrcoef(dec, plain)[0, 1] > 0.9

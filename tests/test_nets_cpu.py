@@ -43,3 +43,14 @@ def test_weight_file_layout_sign1024x1():
     net = pm.load_net("sign1024x1")
     assert net.fc[0][0].shape == (196, 1024) and net.final[0].shape == (1024, 10)
     assert set(np.unique(net.fc[0][1])) <= {0, 1}
+
+
+def test_cifar_checker_matches_reference_prediction():
+    """The CIFAR plaintext checker (conv / max-pool / FC index math) reproduces the prediction the
+    reference's own `make ptxt` build prints for its one sample (NUM_SAMPLES = 1, main.cpp:25)."""
+    labels, pix = pm.load_cifar_images()
+    gold = json.load(open(os.path.join(pm.GOLD, "cifar_binarynet_small.json")))
+    (_, image_i, label, pred), = gold["progress_correct_image_label_prediction"]
+    net = pm.CifarNet("binarynet_small")
+    assert labels[image_i] == label
+    assert int(np.argmax(pm.cifar_forward(net, pix[image_i]))) == pred
