@@ -215,7 +215,11 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs 
 #pragma unroll
       for (int r = 0; r < kRegs; ++r) d[r] = rotated_diff(accc, lane + 64 * r, bara);
       RS_STAMP(0);
+#if defined(RS_EXP_UNROLLQ)
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
       for (int q = 0; q < C::L; ++q) {
         const int row = comp * C::L + q;
         const double2* bp0 = reinterpret_cast<const double2*>(bk_i + (size_t)(row * 2) * kN);
