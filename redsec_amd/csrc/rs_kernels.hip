@@ -203,6 +203,9 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs 
   for (int i = 0; i < n; ++i) {
     const int32_t bara = __builtin_amdgcn_readfirstlane(modswitch_2N(word(i)));
     if (bara == 0) continue;  // tfhe_blindRotate_FFT skips the identity CMUX
+    if (WPB >= 8 && a.prio == 2) {   // experiment: alternate issue priority between the SIMD partners
+      if (((wave >> 2) ^ i) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    }
     double s0[kRegs], s1[kRegs];
 #pragma unroll
     for (int u = 0; u < kRegs; ++u) { s0[u] = 0.0; s1[u] = 0.0; }
@@ -222,6 +225,9 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs 
 #endif
       for (int q = 0; q < C::L; ++q) {
         const int row = comp * C::L + q;
+        if (WPB >= 8 && a.prio == 3) {   // experiment: alternate priority per digit row
+          if (((wave >> 2) ^ row) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
         const double2* bp0 = reinterpret_cast<const double2*>(bk_i + (size_t)(row * 2) * kN);
         const double2* bp1 = bp0 + kN / 2;
         double2 w0[8], w1[8];

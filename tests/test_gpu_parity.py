@@ -204,3 +204,30 @@ def test_linear_stage_matches_oracle(be_toy_redsec, toy_redsec):
     ref = (3 * x.astype(np.int64) - y.astype(np.int64))
     ref[:, -1] += 12345
     assert np.array_equal(got, (ref & 0xFFFFFFFF).astype(np.uint32).view(np.int32))
+
+
+def test_output_noise_matches_cggi_theory(be_full_default, full_default):
+    """KAT (4) of SURVEY.md section 8c: the noise of a bootstrapped gate is what the CGGI analysis
+    predicts -- blind-rotate term n (k+1) l N E[d^2] sigma_bk^2 + keyswitch term N t E[...] sigma_ks^2.
+    A wrong gadget, a dropped digit, a mis-scaled key row or a broken keyswitch all move this by far
+    more than the factor 2 allowed here."""
+    be = be_full_default
+    ks, _ = full_default
+    p = ks.p
+    B = 4096
+    ba, ca = _bits(ks, B, 31)
+    bb, cb = _bits(ks, B, 32)
+    out = be.gate("AND", _dev(ca), _dev(cb)).cpu().numpy()
+    ph = ks.phase(out).astype(np.float64) / 2.0**32
+    ideal = np.where((ba & bb) == 1, 0.125, -0.125)
+    err = ph - ideal
+    assert abs(err.mean()) < 5e-4
+    Bg = 1 << p.bk_Bgbit
+    var_br = p.n * 2 * p.bk_l * p.N * (Bg * Bg / 12.0) * p.bk_stdev ** 2          # digits ~ uniform in [-Bg/2, Bg/2)
+    var_br += p.n * (1 + p.N / 2.0) * (2.0 ** -(p.bk_l * p.bk_Bgbit + 1)) ** 2 / 3     # gadget rounding
+    base = 1 << p.ks_basebit
+    var_ks = p.N * p.ks_t * (1 - 1.0 / base) * p.lwe_stdev ** 2                       # rows actually subtracted
+    var_ks += p.N / 2.0 * (2.0 ** -(p.ks_t * p.ks_basebit + 1)) ** 2 / 3               # keyswitch rounding
+    theory = np.sqrt(var_br + var_ks)
+    measured = err.std()
+    assert 0.5 * theory < measured < 2.0 * theory, (measured, theory)
