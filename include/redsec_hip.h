@@ -80,6 +80,22 @@ int rs_destroy(rs_ctx* ctx);
  * Transforms bk to the transform domain on the device (the bkFFT analogue). */
 int rs_load_keys(rs_ctx* ctx, const int32_t* bk, const int32_t* ksk);
 
+/* Arithmetic of the external product (both are resident after rs_load_keys; switching is free):
+ *   RS_MODE_FFT        folded 512-point complex FP64 FFT -- the arithmetic class of TFHE's own
+ *                      tGswFFTExternMulToTLwe. The true product is an integer and the FFT error is two
+ *                      orders of magnitude below 1/2, so rounding returns exactly the integer result
+ *                      (= RS_MODE_EXACT_NTT = the CPU oracle, bit for bit) with overwhelming probability;
+ *                      rs_rounding_certificate() reports the largest distance to an integer ever rounded.
+ *   RS_MODE_EXACT_NTT  exact negacyclic NTT over a 51-bit prime carried in FP64: guaranteed exact, 2.3x
+ *                      the FP64 operations.
+ * Default RS_MODE_FFT (environment REDSEC_MODE=exact selects the NTT at context creation). */
+enum { RS_MODE_EXACT_NTT = 0, RS_MODE_FFT = 1 };
+int rs_set_mode(rs_ctx* ctx, int mode);
+int rs_get_mode(rs_ctx* ctx, int* mode);
+/* Largest |x - rint(x)| over every value the FFT path has rounded since the last reset (0 in NTT mode).
+ * Anything far below 0.5 certifies that no rounding can have picked a neighbouring integer. */
+int rs_rounding_certificate(rs_ctx* ctx, double* max_distance, int reset);
+
 /* Workspace is grown on demand; this pre-sizes it for batches of up to max_batch ciphertexts. */
 int rs_reserve(rs_ctx* ctx, size_t max_batch);
 

@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "rs_load_keys", "rs_reserve", "rs_bootstrap_dev", "rs_bootstrap", "rs_gate_dev", "rs_gate", "rs_mux_dev", "rs_mux",
     "rs_gate_mu_dev", "rs_gather_rows_dev", "rs_bootstrap_wo_ks_dev", "rs_keyswitch_dev", "rs_debug_polymul", "rs_linear_fc_dev", "rs_conv_ternary_dev",
     "rs_sumpool_dev", "rs_lincomb_dev", "rs_dev_alloc", "rs_dev_free", "rs_copy_to_dev", "rs_copy_to_host", "rs_sync",
-    "rs_set_timing", "rs_last_kernel_ms", "rs_info",
+    "rs_set_timing", "rs_last_kernel_ms", "rs_info", "rs_set_mode", "rs_get_mode", "rs_rounding_certificate",
 ]
 
 GATES = {"NAND": 0, "OR": 1, "AND": 2, "NOR": 3, "XOR": 4, "XNOR": 5, "ANDNY": 6, "ANDYN": 7, "ORNY": 8, "ORYN": 9}
@@ -94,6 +94,9 @@ def load_library(path=None):
     L.rs_set_timing.argtypes = [vp, C.c_int]
     L.rs_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.rs_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.rs_set_mode.argtypes = [vp, C.c_int]
+    L.rs_get_mode.argtypes = [vp, C.POINTER(C.c_int)]
+    L.rs_rounding_certificate.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
     if path is None:
         _lib = L
     return L
@@ -301,6 +304,21 @@ class Backend:
         out = np.empty_like(b)
         _check(self.L, self.L.rs_debug_polymul(self.h, out.ctypes.data_as(_i32p), pa, pb, a.size // self.p.N))
         return out
+
+    # ---- arithmetic mode ----
+    def set_mode(self, mode):
+        """'fft' (default) or 'exact' (guaranteed-exact NTT)."""
+        _check(self.L, self.L.rs_set_mode(self.h, {"exact": 0, "ntt": 0, "fft": 1}[mode]))
+
+    def mode(self):
+        m = C.c_int()
+        _check(self.L, self.L.rs_get_mode(self.h, C.byref(m)))
+        return "fft" if m.value == 1 else "exact"
+
+    def rounding_certificate(self, reset=True):
+        d = C.c_double()
+        _check(self.L, self.L.rs_rounding_certificate(self.h, C.byref(d), 1 if reset else 0))
+        return d.value
 
     # ---- timing / facts ----
     def set_timing(self, on=True):

@@ -45,8 +45,12 @@ struct rs_ctx {
   int device = 0;
   int cfg = 0;  // 0 default128-shaped gadget, 1 redsec_v2-shaped gadget
   rs::Tables tables;
-  double* d_tw = nullptr;
-  double* d_bk_ntt = nullptr;
+  int mode = 1;  // RS_MODE_FFT by default; RS_MODE_EXACT_NTT = 0
+  double* d_tw = nullptr;          // exact-NTT tables (kTwTotal doubles)
+  double* d_tw_fft = nullptr;      // FFT tables (kFftTwDoubles doubles)
+  double* d_bk_ntt = nullptr;      // key in the NTT domain
+  double* d_bk_fft = nullptr;      // key in the FFT domain
+  unsigned long long* d_dev_flag = nullptr;  // FFT rounding certificate (max distance to an integer)
   int32_t* d_ksk = nullptr;
   size_t bk_bytes = 0, ksk_bytes = 0;
   bool keys = false;
@@ -60,10 +64,6 @@ struct rs_ctx {
   bool timing = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool ev_valid = false;
-  int stagger = 0;  // tuning knobs (env RS_STAGGER / RS_PRIO), see blind_rotate_kernel
-  int prio = 0;
-  unsigned long long* dbg = nullptr;  // RS_STAMPS builds only
-  size_t dbg_B = 0;
 };
 
 namespace {
@@ -135,18 +135,12 @@ rs::BlindRotateArgs br_args(rs_ctx* c, const int32_t* in0, const int32_t* in1, i
                             size_t B, int32_t* u) {
   rs::BlindRotateArgs a;
   a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.bconst = bconst; a.mu = mu;
-  a.bk_ntt = c->d_bk_ntt; a.tw = c->d_tw; a.f = c->tables.f;
+  a.bk_x = c->mode == 1 ? c->d_bk_fft : c->d_bk_ntt;
+  a.tw = c->mode == 1 ? c->d_tw_fft : c->d_tw;
+  a.f = c->tables.f;
   a.n = c->p.n; a.W = c->p.n + 1; a.B = (long)B; a.u_out = u;
-  a.stagger = c->stagger; a.prio = c->prio;
   a.counter = c->d_counter;
-  a.debug = nullptr;
-#if defined(RS_STAMPS)
-  {  // diagnostic build: cycle stamps land in a buffer of their own, dumped by rs_destroy
-    static unsigned long long* dbg = nullptr; static size_t cap = 0;
-    if (B > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc(&dbg, B * 12 * sizeof(unsigned long long)); cap = B; }
-    a.debug = dbg; c->dbg = dbg; c->dbg_B = B;
-  }
-#endif
+  a.dev_flag = c->mode == 1 ? c->d_dev_flag : nullptr;
   return a;
 }
 
@@ -164,7 +158,7 @@ int run_bootstrap(rs_ctx* c, int32_t* out, const int32_t* in0, const int32_t* in
   if (rc) return rc;
   const int wpb = pick_wpb(c, B);
   if (c->timing) RS_HIP(hipEventRecord(c->ev[0], st));
-  RS_HIP(rs::launch_blind_rotate(c->cfg, br_args(c, in0, in1, c0, c1, bconst, mu, B, c->d_u0), wpb, c->num_cus, st));
+  RS_HIP(rs::launch_blind_rotate(c->cfg, c->mode, br_args(c, in0, in1, c0, c1, bconst, mu, B, c->d_u0), wpb, c->num_cus, st));
   if (c->timing) RS_HIP(hipEventRecord(c->ev[1], st));
   RS_HIP(rs::launch_keyswitch(ks_args(c, c->d_u0, nullptr, 0, B, out), st));
   if (c->timing) { RS_HIP(hipEventRecord(c->ev[2], st)); c->ev_valid = true; }
@@ -176,7 +170,7 @@ int run_bootstrap(rs_ctx* c, int32_t* out, const int32_t* in0, const int32_t* in
 extern "C" {
 
 const char* rs_last_error(void) { return g_err.c_str(); }
-const char* rs_version(void) { return "redsec_hip 0.1 (gfx950, fp64-ntt)"; }
+const char* rs_version(void) { return "redsec_hip 0.2 (gfx950; fp64 fft + exact fp64-carried ntt)"; }
 
 int rs_params_default128(rs_params* p) {
   if (!p) return fail(RS_ERR_INVALID, "null params");
@@ -222,16 +216,19 @@ int rs_create(rs_ctx** out, const rs_params* p, int device) {
       return fail(RS_ERR_NO_DEVICE, "device %d is %s; this library ships gfx950 code only", device, prop.gcnArchName);
     }
   }
+  const std::vector<double> fft_tw = rs::make_fft_tables();
   if (hipMalloc(&c->d_tw, sizeof(double) * rs::kTwTotal) != hipSuccess ||
-      hipMemcpy(c->d_tw, c->tables.tw.data(), sizeof(double) * rs::kTwTotal, hipMemcpyHostToDevice) != hipSuccess) {
+      hipMemcpy(c->d_tw, c->tables.tw.data(), sizeof(double) * rs::kTwTotal, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMalloc(&c->d_tw_fft, sizeof(double) * rs::kFftTwDoubles) != hipSuccess ||
+      hipMemcpy(c->d_tw_fft, fft_tw.data(), sizeof(double) * rs::kFftTwDoubles, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMalloc(&c->d_dev_flag, 64) != hipSuccess || hipMemset(c->d_dev_flag, 0, 64) != hipSuccess) {
     delete c;
     return fail(RS_ERR_HIP, "twiddle table upload failed");
   }
+  if (const char* m = getenv("REDSEC_MODE")) c->mode = (strcmp(m, "exact") == 0 || strcmp(m, "ntt") == 0) ? 0 : 1;
   for (auto& e : c->ev) (void)hipEventCreate(&e);
   if (hipMalloc(&c->d_counter, 256) != hipSuccess) { delete c; return fail(RS_ERR_HIP, "counter allocation failed"); }
   if (getenv("RS_NO_PERSIST")) { (void)hipFree(c->d_counter); c->d_counter = nullptr; }
-  if (const char* s = getenv("RS_STAGGER")) c->stagger = atoi(s);
-  if (const char* s = getenv("RS_PRIO")) c->prio = atoi(s);
   *out = c;
   return RS_OK;
 }
@@ -240,18 +237,8 @@ int rs_destroy(rs_ctx* c) {
   if (!c) return RS_OK;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-#if defined(RS_STAMPS)
-  if (c->dbg && c->dbg_B) {
-    std::vector<unsigned long long> h(c->dbg_B * 12);
-    (void)hipMemcpy(h.data(), c->dbg, h.size() * 8, hipMemcpyDeviceToHost);
-    double sum[12] = {0};
-    for (size_t b = 0; b < c->dbg_B; ++b) for (int k = 0; k < 12; ++k) sum[k] += (double)h[b * 12 + k];
-    fprintf(stderr, "RS_STAMPS mean cycles per wave per bootstrap:");
-    for (int k = 0; k < 12; ++k) fprintf(stderr, " [%d]=%.0f", k, sum[k] / c->dbg_B);
-    fprintf(stderr, "\n");
-  }
-#endif
-  (void)hipFree(c->d_tw); (void)hipFree(c->d_bk_ntt); (void)hipFree(c->d_ksk);
+  (void)hipFree(c->d_tw); (void)hipFree(c->d_tw_fft); (void)hipFree(c->d_bk_ntt); (void)hipFree(c->d_bk_fft); (void)hipFree(c->d_ksk);
+  (void)hipFree(c->d_dev_flag);
   (void)hipFree(c->d_u0); (void)hipFree(c->d_u1); (void)hipFree(c->d_counter);
   for (auto& p : c->d_io) (void)hipFree(p);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -268,13 +255,18 @@ int rs_load_keys(rs_ctx* c, const int32_t* bk, const int32_t* ksk) {
   const size_t bk_words = n_polys * rs::kN;
   const size_t ksk_words = (size_t)rs::kN * p.ks_t * ((size_t)1 << p.ks_basebit) * (size_t)(p.n + 1);
   if (c->d_bk_ntt) { (void)hipFree(c->d_bk_ntt); c->d_bk_ntt = nullptr; }
+  if (c->d_bk_fft) { (void)hipFree(c->d_bk_fft); c->d_bk_fft = nullptr; }
   if (c->d_ksk) { (void)hipFree(c->d_ksk); c->d_ksk = nullptr; }
   c->keys = false;
   int32_t* d_bk = nullptr;
   RS_HIP(hipMalloc(&d_bk, bk_words * sizeof(int32_t)));
   RS_HIP(hipMemcpy(d_bk, bk, bk_words * sizeof(int32_t), hipMemcpyHostToDevice));
+  // both transform domains are kept resident (62 + 62 MB default-128, 115 + 115 MB REDsec) so that the
+  // mode can be switched per call
   RS_HIP(hipMalloc(&c->d_bk_ntt, bk_words * sizeof(double)));
-  RS_HIP(rs::launch_bk_transform(c->cfg, d_bk, c->d_bk_ntt, c->d_tw, c->tables.f, c->tables.ninv, (long)n_polys, nullptr));
+  RS_HIP(hipMalloc(&c->d_bk_fft, bk_words * sizeof(double)));
+  RS_HIP(rs::launch_bk_transform(c->cfg, 0, d_bk, c->d_bk_ntt, c->d_tw, c->tables.f, c->tables.ninv, (long)n_polys, nullptr));
+  RS_HIP(rs::launch_bk_transform(c->cfg, 1, d_bk, c->d_bk_fft, c->d_tw_fft, c->tables.f, 0.0, (long)n_polys, nullptr));
   RS_HIP(hipDeviceSynchronize());
   RS_HIP(hipFree(d_bk));
   RS_HIP(hipMalloc(&c->d_ksk, ksk_words * sizeof(int32_t)));
@@ -340,8 +332,8 @@ int rs_mux_dev(rs_ctx* c, int32_t* out, const int32_t* a, const int32_t* b, cons
   const int32_t e8 = 1 << 29;
   if (c->timing) RS_HIP(hipEventRecord(c->ev[0], st));
   // u1 = woKS(AND(a,b)), u2 = woKS(ANDNY(a,c)); out = KS((0,1/8) + u1 + u2)
-  RS_HIP(rs::launch_blind_rotate(c->cfg, br_args(c, a, b, 1, 1, -e8, e8, B, c->d_u0), wpb, c->num_cus, st));
-  RS_HIP(rs::launch_blind_rotate(c->cfg, br_args(c, a, cc, -1, 1, -e8, e8, B, c->d_u1), wpb, c->num_cus, st));
+  RS_HIP(rs::launch_blind_rotate(c->cfg, c->mode, br_args(c, a, b, 1, 1, -e8, e8, B, c->d_u0), wpb, c->num_cus, st));
+  RS_HIP(rs::launch_blind_rotate(c->cfg, c->mode, br_args(c, a, cc, -1, 1, -e8, e8, B, c->d_u1), wpb, c->num_cus, st));
   if (c->timing) RS_HIP(hipEventRecord(c->ev[1], st));
   RS_HIP(rs::launch_keyswitch(ks_args(c, c->d_u0, c->d_u1, e8, B, out), st));
   if (c->timing) { RS_HIP(hipEventRecord(c->ev[2], st)); c->ev_valid = true; }
@@ -353,7 +345,7 @@ int rs_bootstrap_wo_ks_dev(rs_ctx* c, int32_t* u, const int32_t* in, int32_t mu,
   if (rc) return rc;
   if (B == 0) return RS_OK;
   if (!u || !in) return fail(RS_ERR_INVALID, "null ciphertext pointer");
-  RS_HIP(rs::launch_blind_rotate(c->cfg, br_args(c, in, nullptr, 1, 0, 0, mu, B, u), pick_wpb(c, B), c->num_cus, (hipStream_t)stream));
+  RS_HIP(rs::launch_blind_rotate(c->cfg, c->mode, br_args(c, in, nullptr, 1, 0, 0, mu, B, u), pick_wpb(c, B), c->num_cus, (hipStream_t)stream));
   return RS_OK;
 }
 
@@ -420,13 +412,41 @@ int rs_debug_polymul(rs_ctx* c, int32_t* out, const int32_t* a_small, const int3
   if (!out || !a_small || !b_torus) return fail(RS_ERR_INVALID, "null pointer");
   const size_t bytes = count * rs::kN * sizeof(int32_t);
   int32_t *da = nullptr, *db = nullptr, *dout = nullptr;
+  double* scratch = nullptr;
   RS_HIP(hipMalloc(&da, bytes)); RS_HIP(hipMalloc(&db, bytes)); RS_HIP(hipMalloc(&dout, bytes));
+  RS_HIP(hipMalloc(&scratch, count * rs::kN * sizeof(double)));
   RS_HIP(hipMemcpy(da, a_small, bytes, hipMemcpyHostToDevice));
   RS_HIP(hipMemcpy(db, b_torus, bytes, hipMemcpyHostToDevice));
-  RS_HIP(rs::launch_polymul(c->cfg, da, db, dout, c->d_tw, c->tables.f, c->tables.ninv, (long)count, nullptr));
+  RS_HIP(rs::launch_polymul(c->cfg, c->mode, da, db, dout, scratch, c->mode == 1 ? c->d_tw_fft : c->d_tw, c->tables.f, c->tables.ninv,
+                            (long)count, c->mode == 1 ? c->d_dev_flag : nullptr, nullptr));
   RS_HIP(hipDeviceSynchronize());
   RS_HIP(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
-  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout); (void)hipFree(scratch);
+  return RS_OK;
+}
+
+int rs_set_mode(rs_ctx* c, int mode) {
+  if (!c) return fail(RS_ERR_INVALID, "null context");
+  if (mode != RS_MODE_EXACT_NTT && mode != RS_MODE_FFT) return fail(RS_ERR_INVALID, "unknown mode %d", mode);
+  c->mode = mode;
+  return RS_OK;
+}
+
+int rs_get_mode(rs_ctx* c, int* mode) {
+  if (!c || !mode) return fail(RS_ERR_INVALID, "null argument");
+  *mode = c->mode;
+  return RS_OK;
+}
+
+int rs_rounding_certificate(rs_ctx* c, double* max_distance, int reset) {
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (!max_distance) return fail(RS_ERR_INVALID, "null pointer");
+  RS_HIP(hipDeviceSynchronize());
+  unsigned long long bits = 0;
+  RS_HIP(hipMemcpy(&bits, c->d_dev_flag, sizeof bits, hipMemcpyDeviceToHost));
+  memcpy(max_distance, &bits, sizeof bits);
+  if (reset) RS_HIP(hipMemset(c->d_dev_flag, 0, sizeof bits));
   return RS_OK;
 }
 

@@ -1,0 +1,537 @@
+// rs_bootstrap.hip -- the transform-based kernels of the gate bootstrap, written once over a
+// "transform policy":
+//   XfNtt<Cfg>  exact negacyclic NTT over a 51-bit prime carried in FP64 (rs_ntt.h)  -- guaranteed exact
+//   XfFft<Cfg>  folded 512-point complex FP64 FFT (rs_fft.h), TFHE's own arithmetic class -- 2.5x fewer
+//               FP64 ops; exact after rounding with overwhelming probability, with a run-time certificate
+//
+//   bk_transform_kernel       bootstrapping key -> transform domain (the bkFFT analogue; once per key)
+//   blind_rotate_kernel       gate pre-combination + modswitch + n CMUX steps + sample extract
+//                             (tfhe_bootstrap_woKS_FFT; REDsec: lib/BinOps_enc.cpp:185,191), throughput form
+//   blind_rotate_coop_kernel  the same with G waves per ciphertext (latency form for small batches)
+//   polymul_kernel            debug/parity tap through the same transform path
+//
+// One wavefront owns one ciphertext for the whole blind rotation: its TRLWE accumulator (2 x 1024
+// int32) lives in LDS, each of the (k+1) l digit polynomials is transformed in registers with two
+// LDS transposes, multiplied against the coalesced-streamed key row and accumulated in registers,
+// and two inverse transforms update the accumulator. Waves never synchronise with each other after
+// the twiddle tables are staged.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "rs_fft.h"
+#include "rs_kernels.h"
+#include "rs_ntt.h"
+
+namespace rs {
+
+// Same-wave LDS hand-off: DS operations of one wavefront execute in order, so only the compiler
+// needs to be told not to move LDS accesses across this point.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void stage_tables(double* s_tw, const double* tw_g, int nthreads, int count) {
+  for (int i = threadIdx.x; i < count; i += nthreads) s_tw[i] = tw_g[i];
+  __syncthreads();
+}
+
+// -------------------------------------------------------------------------------------------------
+// Transform policies
+// -------------------------------------------------------------------------------------------------
+template <class C>
+struct XfNtt {
+  using Cfg = C;
+  static constexpr int kTableDoubles = kTwTotal;
+  static constexpr bool kCertificate = false;
+
+  __device__ static __forceinline__ void fwd_digits(int lane, double (&x)[kRegs], const int32_t (&d)[kRegs], int q, uint32_t offset,
+                                                    const double* tw, double* buf, const Field& f) {
+    fwd_F1_digits<C>(lane, x, d, q, offset, tw, buf, f);
+    wave_lds_sync();
+    fwd_F2<C>(lane, x, tw, buf, f);
+    wave_lds_sync();
+    fwd_F3(lane, x, buf);
+    wave_lds_sync();
+    fwd_F4<C>(lane, x, tw, buf, f);
+    wave_lds_sync();
+  }
+  __device__ static __forceinline__ void fwd_generic(int lane, double (&x)[kRegs], const double* tw, double* buf, const Field& f) {
+    fwd_F1<C>(lane, x, tw, buf, f);
+    wave_lds_sync();
+    fwd_F2<C>(lane, x, tw, buf, f);
+    wave_lds_sync();
+    fwd_F3(lane, x, buf);
+    wave_lds_sync();
+    fwd_F4<C>(lane, x, tw, buf, f);
+    wave_lds_sync();
+  }
+  // key values: scaled by 1/N and fully reduced; stored as pairs (positions 16 lane + 2v, +1)
+  __device__ static __forceinline__ void key_store(double2* dst, int lane, const double (&x)[kRegs], double scale, const Field& f) {
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      const double a = f_reduce(f_mulmod(f_reduce(x[2 * v], f), scale, f), f);
+      const double b = f_reduce(f_mulmod(f_reduce(x[2 * v + 1], f), scale, f), f);
+      dst[v * 64 + lane] = make_double2(a, b);
+    }
+  }
+  __device__ static __forceinline__ void mac(double (&s0)[kRegs], double (&s1)[kRegs], const double (&x)[kRegs],
+                                             const double2 (&w0)[8], const double2 (&w1)[8], const Field& f) {
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      s0[2 * v] += f_mulmod(x[2 * v], w0[v].x, f);
+      s0[2 * v + 1] += f_mulmod(x[2 * v + 1], w0[v].y, f);
+      s1[2 * v] += f_mulmod(x[2 * v], w1[v].x, f);
+      s1[2 * v + 1] += f_mulmod(x[2 * v + 1], w1[v].y, f);
+    }
+  }
+  __device__ static __forceinline__ void mid(double (&s0)[kRegs], double (&s1)[kRegs], const Field& f) {
+    if (C::MID_REDUCE) {
+#pragma unroll
+      for (int u = 0; u < kRegs; ++u) { s0[u] = f_reduce(s0[u], f); s1[u] = f_reduce(s1[u], f); }
+    }
+  }
+  __device__ static __forceinline__ double partial(double v, const Field& f) { return f_reduce(v, f); }
+  __device__ static __forceinline__ void inverse(int lane, double (&x)[kRegs], const double* tw, double* buf, const Field& f) {
+    const double* twi = tw + kN;
+    inv_I1<C>(lane, x, twi, buf, f);
+    wave_lds_sync();
+    inv_I2<C>(lane, x, twi, buf, f);
+    wave_lds_sync();
+    inv_I3(lane, x, buf);
+    wave_lds_sync();
+    inv_I4<C>(lane, x, twi, buf, f);
+    wave_lds_sync();
+  }
+  __device__ static __forceinline__ int32_t to_torus(double v, double&) { return f_to_torus32(v); }
+};
+
+template <class C>
+struct XfFft {
+  using Cfg = C;
+  static constexpr int kTableDoubles = kFftTwDoubles;
+  static constexpr bool kCertificate = true;
+
+  __device__ static __forceinline__ void fwd_generic(int lane, double (&x)[kRegs], const double* tw, double* buf, const Field&) {
+    ffwd_F1(lane, x, tw, buf);
+    wave_lds_sync();
+    ffwd_F2(lane, x, tw, buf);
+    wave_lds_sync();
+    ffwd_F3(lane, x, buf);
+    wave_lds_sync();
+    ffwd_F4(lane, x, tw, buf);
+    wave_lds_sync();
+  }
+  __device__ static __forceinline__ void fwd_digits(int lane, double (&x)[kRegs], const int32_t (&d)[kRegs], int q, uint32_t offset,
+                                                    const double* tw, double* buf, const Field& f) {
+#pragma unroll
+    for (int r = 0; r < kRegs; ++r) x[r] = (double)gadget_digit<C>(d[r], q, offset);
+    fwd_generic(lane, x, tw, buf, f);
+  }
+  // key values scaled by 1/M (exact power of two); stored as (re, im) of position 8 lane + v
+  __device__ static __forceinline__ void key_store(double2* dst, int lane, const double (&x)[kRegs], double, const Field&) {
+#pragma unroll
+    for (int v = 0; v < 8; ++v) dst[v * 64 + lane] = make_double2(x[v] * (1.0 / kM), x[v + 8] * (1.0 / kM));
+  }
+  __device__ static __forceinline__ void mac(double (&s0)[kRegs], double (&s1)[kRegs], const double (&x)[kRegs],
+                                             const double2 (&w0)[8], const double2 (&w1)[8], const Field&) {
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      fft_cmac(s0[v], s0[v + 8], x[v], x[v + 8], w0[v].x, w0[v].y);
+      fft_cmac(s1[v], s1[v + 8], x[v], x[v + 8], w1[v].x, w1[v].y);
+    }
+  }
+  __device__ static __forceinline__ void mid(double (&)[kRegs], double (&)[kRegs], const Field&) {}
+  __device__ static __forceinline__ double partial(double v, const Field&) { return v; }
+  __device__ static __forceinline__ void inverse(int lane, double (&x)[kRegs], const double* tw, double* buf, const Field&) {
+    finv_I1(lane, x, tw, buf);
+    wave_lds_sync();
+    finv_I2(lane, x, tw, buf);
+    wave_lds_sync();
+    finv_I3(lane, x, buf);
+    wave_lds_sync();
+    finv_I4(lane, x, tw, buf);
+    wave_lds_sync();
+  }
+  __device__ static __forceinline__ int32_t to_torus(double v, double& dev) { return fft_round_torus32(v, dev); }
+};
+
+// largest rounding distance of the wave -> device flag (positive doubles order like their bit patterns)
+__device__ __forceinline__ void publish_certificate(double dev, unsigned long long* flag, int lane) {
+  if (!flag) return;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_xor(dev, off, 64);
+    dev = o > dev ? o : dev;
+  }
+  if (lane == 0) atomicMax(flag, (unsigned long long)__double_as_longlong(dev));
+}
+
+// -------------------------------------------------------------------------------------------------
+// Key transform: one wavefront per key polynomial. Output layout per polynomial: [v 0..7][lane][2]
+// doubles in the exact register order of the consuming wavefront, so the blind rotation reads each
+// row with eight perfectly coalesced 16-byte-per-lane loads.
+// -------------------------------------------------------------------------------------------------
+template <class Xf, int WPB>
+__global__ __launch_bounds__(64 * WPB) void bk_transform_kernel(const int32_t* __restrict__ bk, double* __restrict__ bk_x,
+                                                                 const double* __restrict__ tw_g, Field f, double scale, long n_polys) {
+  __shared__ double s_tw[Xf::kTableDoubles];
+  __shared__ double s_buf[WPB][kBufDoubles];
+  stage_tables(s_tw, tw_g, 64 * WPB, Xf::kTableDoubles);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const long poly = (long)blockIdx.x * WPB + wave;
+  if (poly >= n_polys) return;
+  double x[kRegs];
+  const int32_t* src = bk + poly * kN;
+#pragma unroll
+  for (int r = 0; r < kRegs; ++r) x[r] = (double)src[lane + 64 * r];
+  Xf::fwd_generic(lane, x, s_tw, s_buf[wave], f);
+  Xf::key_store(reinterpret_cast<double2*>(bk_x + poly * kN), lane, x, scale, f);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Blind rotation + sample extract, throughput form (persistent waves).
+// -------------------------------------------------------------------------------------------------
+template <class Xf, int WPB>
+__global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs a) {
+  using C = typename Xf::Cfg;
+  __shared__ double s_tw[Xf::kTableDoubles];
+  __shared__ double s_buf[WPB][kBufDoubles];
+  __shared__ int32_t s_acc[WPB][2][kN];
+  stage_tables(s_tw, a.tw, 64 * WPB, Xf::kTableDoubles);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  // Persistent waves: the first ciphertext is assigned statically, further ones are pulled from a
+  // device counter (zeroed by the launcher on the same stream). A 150 KB-LDS workgroup cannot be
+  // replaced until its LAST wave exits, and waves sharing a SIMD finish up to 20 % apart (issue
+  // arbitration favours the older wave), which left 18 % of the wave slots idle with one ciphertext
+  // per wave. Every wave leaves the loop as soon as the counter passes B, so the grid always drains.
+  long ct = (long)blockIdx.x * WPB + wave;
+  const long first_dynamic = (long)gridDim.x * WPB;
+  if (ct >= a.B) return;
+
+  const Field f = a.f;
+  double* buf = s_buf[wave];
+  int32_t* acc0 = s_acc[wave][0];
+  int32_t* acc1 = s_acc[wave][1];
+  const double* tw = s_tw;
+  const int n = a.n;
+  constexpr uint32_t offset = gadget_offset<C>();
+  constexpr int KPL = 2 * C::L;
+  double dev = 0.0;
+
+  for (;;) {
+    const int32_t* row0 = a.in0 + ct * a.W;
+    const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
+    // gate pre-combination (0, bconst) + c0*in0 + c1*in1, evaluated word by word as it is consumed
+    auto word = [&](int i) -> int32_t {
+      uint32_t v = (uint32_t)a.c0 * (uint32_t)row0[i];
+      if (row1) v += (uint32_t)a.c1 * (uint32_t)row1[i];
+      return (int32_t)v;
+    };
+    {
+      const int32_t barb = modswitch_2N((int32_t)((uint32_t)word(n) + (uint32_t)a.bconst));
+      const int rot = 2 * kN - barb;  // in (0, 2N]
+#pragma unroll
+      for (int r = 0; r < kRegs; ++r) {
+        const int j = lane + 64 * r;
+        acc0[j] = 0;
+        acc1[j] = rotated_const(a.mu, j, rot);
+      }
+    }
+    wave_lds_sync();
+
+    for (int i = 0; i < n; ++i) {
+      const int32_t bara = __builtin_amdgcn_readfirstlane(modswitch_2N(word(i)));
+      if (bara == 0) continue;  // tfhe_blindRotate_FFT skips the identity CMUX
+      double s0[kRegs], s1[kRegs];
+#pragma unroll
+      for (int u = 0; u < kRegs; ++u) { s0[u] = 0.0; s1[u] = 0.0; }
+      const double* bk_i = a.bk_x + (size_t)i * KPL * 2 * kN;
+
+#pragma unroll 1
+      for (int comp = 0; comp < 2; ++comp) {
+        const int32_t* accc = comp ? acc1 : acc0;
+        int32_t d[kRegs];
+#pragma unroll
+        for (int r = 0; r < kRegs; ++r) d[r] = rotated_diff(accc, lane + 64 * r, bara);
+#pragma unroll 1
+        for (int q = 0; q < C::L; ++q) {
+          const int row = comp * C::L + q;
+          const double2* bp0 = reinterpret_cast<const double2*>(bk_i + (size_t)(row * 2) * kN);
+          const double2* bp1 = bp0 + kN / 2;
+          double2 w0[8], w1[8];
+#pragma unroll
+          for (int v = 0; v < 8; ++v) { w0[v] = bp0[v * 64 + lane]; w1[v] = bp1[v * 64 + lane]; }
+          double x[kRegs];
+          Xf::fwd_digits(lane, x, d, q, offset, tw, buf, f);
+          Xf::mac(s0, s1, x, w0, w1, f);
+        }
+        if (comp == 0) Xf::mid(s0, s1, f);
+      }
+
+      Xf::inverse(lane, s0, tw, buf, f);
+#pragma unroll
+      for (int r = 0; r < kRegs; ++r) {
+        const int j = lane + 64 * r;
+        acc0[j] = (int32_t)((uint32_t)acc0[j] + (uint32_t)Xf::to_torus(s0[r], dev));
+      }
+      Xf::inverse(lane, s1, tw, buf, f);
+#pragma unroll
+      for (int r = 0; r < kRegs; ++r) {
+        const int j = lane + 64 * r;
+        acc1[j] = (int32_t)((uint32_t)acc1[j] + (uint32_t)Xf::to_torus(s1[r], dev));
+      }
+      wave_lds_sync();
+    }
+
+    // tLweExtractLweSampleIndex(index 0): a'[0] = acc_a[0], a'[j] = -acc_a[N-j], b' = acc_b[0]
+    int32_t* out = a.u_out + ct * (kN + 1);
+#pragma unroll
+    for (int r = 0; r < kRegs; ++r) {
+      const int j = lane + 64 * r;
+      out[j] = (j == 0) ? acc0[0] : (int32_t)(0u - (uint32_t)acc0[kN - j]);
+    }
+    if (lane == 0) out[kN] = acc1[0];
+
+    if (!a.counter) break;
+    unsigned int nxt = 0;
+    if (lane == 0) nxt = atomicAdd(a.counter, 1u);
+    nxt = (unsigned int)__builtin_amdgcn_readfirstlane((int)nxt);
+    ct = first_dynamic + (long)nxt;
+    if (ct >= a.B) break;
+    wave_lds_sync();
+  }
+  if (Xf::kCertificate) publish_certificate(dev, a.dev_flag, lane);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Cooperative blind rotation (latency form, B <= 2 x #CUs): G waves share ONE ciphertext.
+// Wave g transforms the digit polynomials [g R, (g+1) R) (R = 2l / G, so each wave stays within one
+// accumulator component) and accumulates its partial column sums; the partials meet in LDS, waves 0
+// and 1 sum one column each, run the inverse transform and update the shared accumulator. Two
+// workgroup barriers per CMUX step.
+// -------------------------------------------------------------------------------------------------
+template <class Xf, int G>
+__global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateArgs a) {
+  using C = typename Xf::Cfg;
+  constexpr int KPL = 2 * C::L;
+  constexpr int R = KPL / G;
+  static_assert(KPL % G == 0 && G % 2 == 0, "waves must split the digit rows evenly within a component");
+  __shared__ double s_tw[Xf::kTableDoubles];
+  __shared__ double s_buf[G][kBufDoubles];
+  __shared__ double s_part[G][2][kN];
+  __shared__ int32_t s_acc[2][kN];
+  stage_tables(s_tw, a.tw, 64 * G, Xf::kTableDoubles);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const long ct = blockIdx.x;
+  const Field f = a.f;
+  double* buf = s_buf[wave];
+  const double* tw = s_tw;
+  const int32_t* row0 = a.in0 + ct * a.W;
+  const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
+  const int n = a.n;
+  const int comp = wave / (G / 2);
+  const int row_begin = wave * R;
+  double dev = 0.0;
+  auto word = [&](int i) -> int32_t {
+    uint32_t v = (uint32_t)a.c0 * (uint32_t)row0[i];
+    if (row1) v += (uint32_t)a.c1 * (uint32_t)row1[i];
+    return (int32_t)v;
+  };
+  if (wave < 2) {
+    const int32_t barb = modswitch_2N((int32_t)((uint32_t)word(n) + (uint32_t)a.bconst));
+    const int rot = 2 * kN - barb;
+#pragma unroll
+    for (int r = 0; r < kRegs; ++r) {
+      const int j = lane + 64 * r;
+      s_acc[wave][j] = wave == 0 ? 0 : rotated_const(a.mu, j, rot);
+    }
+  }
+  __syncthreads();
+  constexpr uint32_t offset = gadget_offset<C>();
+  for (int i = 0; i < n; ++i) {
+    const int32_t bara = __builtin_amdgcn_readfirstlane(modswitch_2N(word(i)));
+    if (bara == 0) continue;   // uniform over the workgroup: every wave works on the same ciphertext
+    double s0[kRegs], s1[kRegs];
+#pragma unroll
+    for (int u = 0; u < kRegs; ++u) { s0[u] = 0.0; s1[u] = 0.0; }
+    const double* bk_i = a.bk_x + (size_t)i * KPL * 2 * kN;
+    int32_t d[kRegs];
+#pragma unroll
+    for (int r = 0; r < kRegs; ++r) d[r] = rotated_diff(s_acc[comp], lane + 64 * r, bara);
+#pragma unroll 1
+    for (int rr = 0; rr < R; ++rr) {
+      const int row = row_begin + rr;
+      const int q = row - comp * C::L;
+      const double2* bp0 = reinterpret_cast<const double2*>(bk_i + (size_t)(row * 2) * kN);
+      const double2* bp1 = bp0 + kN / 2;
+      double2 w0[8], w1[8];
+#pragma unroll
+      for (int v = 0; v < 8; ++v) { w0[v] = bp0[v * 64 + lane]; w1[v] = bp1[v * 64 + lane]; }
+      double x[kRegs];
+      Xf::fwd_digits(lane, x, d, q, offset, tw, buf, f);
+      Xf::mac(s0, s1, x, w0, w1, f);
+    }
+    // partial sums exchanged through LDS: position u*64 + lane is conflict-free
+#pragma unroll
+    for (int u = 0; u < kRegs; ++u) {
+      s_part[wave][0][u * 64 + lane] = Xf::partial(s0[u], f);
+      s_part[wave][1][u * 64 + lane] = Xf::partial(s1[u], f);
+    }
+    __syncthreads();   // partials visible; every wave has finished reading the accumulator
+    if (wave < 2) {
+      double x[kRegs];
+#pragma unroll
+      for (int u = 0; u < kRegs; ++u) {
+        double t = s_part[0][wave][u * 64 + lane];
+#pragma unroll
+        for (int g = 1; g < G; ++g) t += s_part[g][wave][u * 64 + lane];
+        x[u] = t;
+      }
+      Xf::inverse(lane, x, tw, buf, f);
+#pragma unroll
+      for (int r = 0; r < kRegs; ++r) {
+        const int j = lane + 64 * r;
+        s_acc[wave][j] = (int32_t)((uint32_t)s_acc[wave][j] + (uint32_t)Xf::to_torus(x[r], dev));
+      }
+    }
+    __syncthreads();   // accumulator updated
+  }
+  int32_t* out = a.u_out + ct * (kN + 1);
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < kRegs; ++r) {
+      const int j = lane + 64 * r;
+      out[j] = (j == 0) ? s_acc[0][0] : (int32_t)(0u - (uint32_t)s_acc[0][kN - j]);
+    }
+    if (lane == 0) out[kN] = s_acc[1][0];
+  }
+  if (Xf::kCertificate && wave < 2) publish_certificate(dev, a.dev_flag, lane);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Debug tap: out = a_small * b_torus (negacyclic, mod 2^32) through forward/pointwise/inverse.
+// -------------------------------------------------------------------------------------------------
+template <class Xf, int WPB>
+__global__ __launch_bounds__(64 * WPB) void polymul_kernel(const int32_t* __restrict__ a_small, const int32_t* __restrict__ b_torus,
+                                                            int32_t* __restrict__ out, double* __restrict__ scratch,
+                                                            const double* __restrict__ tw_g, Field f, double scale, long count,
+                                                            unsigned long long* dev_flag) {
+  __shared__ double s_tw[Xf::kTableDoubles];
+  __shared__ double s_buf[WPB][kBufDoubles];
+  stage_tables(s_tw, tw_g, 64 * WPB, Xf::kTableDoubles);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const long idx = (long)blockIdx.x * WPB + wave;
+  if (idx >= count) return;
+  double* buf = s_buf[wave];
+  double xa[kRegs], xb[kRegs];
+#pragma unroll
+  for (int r = 0; r < kRegs; ++r) {
+    xa[r] = (double)a_small[idx * kN + lane + 64 * r];
+    xb[r] = (double)b_torus[idx * kN + lane + 64 * r];
+  }
+  // key side exactly as bk_transform_kernel: through global memory in the key layout
+  Xf::fwd_generic(lane, xb, s_tw, buf, f);
+  double2* key = reinterpret_cast<double2*>(scratch + idx * kN);
+  Xf::key_store(key, lane, xb, scale, f);
+  double2 w0[8], w1[8];
+#pragma unroll
+  for (int v = 0; v < 8; ++v) { w0[v] = key[v * 64 + lane]; w1[v] = w0[v]; }
+  Xf::fwd_generic(lane, xa, s_tw, buf, f);
+  double s0[kRegs], s1[kRegs];
+#pragma unroll
+  for (int u = 0; u < kRegs; ++u) { s0[u] = 0.0; s1[u] = 0.0; }
+  Xf::mac(s0, s1, xa, w0, w1, f);
+  Xf::inverse(lane, s0, s_tw, buf, f);
+  double dev = 0.0;
+#pragma unroll
+  for (int r = 0; r < kRegs; ++r) out[idx * kN + lane + 64 * r] = Xf::to_torus(s0[r], dev);
+  if (Xf::kCertificate) publish_certificate(dev, dev_flag, lane);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Launchers. cfg: 0 = default-128-shaped gadget, 1 = REDsec-shaped; mode: 0 = exact NTT, 1 = FFT.
+// -------------------------------------------------------------------------------------------------
+template <class Xf, int WPB>
+static hipError_t launch_br(const BlindRotateArgs& a, long max_blocks, hipStream_t st) {
+  long blocks = (a.B + WPB - 1) / WPB;
+  BlindRotateArgs args = a;
+  if (a.counter && blocks > max_blocks) {
+    blocks = max_blocks;                       // persistent: one workgroup per CU, waves pull work
+    hipError_t e = hipMemsetAsync(a.counter, 0, sizeof(unsigned int), st);
+    if (e != hipSuccess) return e;
+  } else {
+    args.counter = nullptr;                    // every wave has exactly one ciphertext
+  }
+  hipLaunchKernelGGL((blind_rotate_kernel<Xf, WPB>), dim3((unsigned)blocks), dim3(64 * WPB), 0, st, args);
+  return hipGetLastError();
+}
+
+template <class Xf>
+static hipError_t launch_br_xf(const BlindRotateArgs& a, int wpb, long num_cus, bool coop4, hipStream_t st) {
+  // latency form: several waves per ciphertext while the batch cannot fill the chip by itself
+  if (!getenv("RS_NO_COOP")) {
+    if (coop4 && a.B <= num_cus) {
+      if constexpr ((2 * Xf::Cfg::L) % 4 == 0) {
+        hipLaunchKernelGGL((blind_rotate_coop_kernel<Xf, 4>), dim3((unsigned)a.B), dim3(256), 0, st, a);
+        return hipGetLastError();
+      }
+    }
+    if (a.B <= 2L * num_cus) {
+      hipLaunchKernelGGL((blind_rotate_coop_kernel<Xf, 2>), dim3((unsigned)a.B), dim3(128), 0, st, a);
+      return hipGetLastError();
+    }
+  }
+  switch (wpb) {
+    case 1: return launch_br<Xf, 1>(a, 1L << 40, st);
+    case 2: return launch_br<Xf, 2>(a, 1L << 40, st);
+    case 4: return launch_br<Xf, 4>(a, 1L << 40, st);
+    default: return launch_br<Xf, 8>(a, num_cus, st);   // ~150 KB LDS: exactly one workgroup per CU
+  }
+}
+
+hipError_t launch_blind_rotate(int cfg, int mode, const BlindRotateArgs& a, int wpb, int num_cus, hipStream_t st) {
+  if (a.B <= 0) return hipSuccess;
+  if (mode == 0) {
+    return cfg == 0 ? launch_br_xf<XfNtt<CfgDefault128>>(a, wpb, num_cus, false, st)
+                    : launch_br_xf<XfNtt<CfgRedsecV2>>(a, wpb, num_cus, true, st);
+  }
+  return cfg == 0 ? launch_br_xf<XfFft<CfgDefault128>>(a, wpb, num_cus, false, st)
+                  : launch_br_xf<XfFft<CfgRedsecV2>>(a, wpb, num_cus, true, st);
+}
+
+hipError_t launch_bk_transform(int cfg, int mode, const int32_t* bk, double* bk_x, const double* tw, Field f, double scale,
+                               long n_polys, hipStream_t st) {
+  constexpr int WPB = 4;
+  const dim3 grid((unsigned)((n_polys + WPB - 1) / WPB)), block(64 * WPB);
+  if (mode == 1) {
+    hipLaunchKernelGGL((bk_transform_kernel<XfFft<CfgDefault128>, WPB>), grid, block, 0, st, bk, bk_x, tw, f, scale, n_polys);
+  } else if (cfg == 0) {
+    hipLaunchKernelGGL((bk_transform_kernel<XfNtt<CfgDefault128>, WPB>), grid, block, 0, st, bk, bk_x, tw, f, scale, n_polys);
+  } else {
+    hipLaunchKernelGGL((bk_transform_kernel<XfNtt<CfgRedsecV2>, WPB>), grid, block, 0, st, bk, bk_x, tw, f, scale, n_polys);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_polymul(int cfg, int mode, const int32_t* a_small, const int32_t* b_torus, int32_t* out, double* scratch,
+                          const double* tw, Field f, double scale, long count, unsigned long long* dev_flag, hipStream_t st) {
+  constexpr int WPB = 4;
+  const dim3 grid((unsigned)((count + WPB - 1) / WPB)), block(64 * WPB);
+  if (mode == 1) {
+    hipLaunchKernelGGL((polymul_kernel<XfFft<CfgDefault128>, WPB>), grid, block, 0, st, a_small, b_torus, out, scratch, tw, f, scale, count, dev_flag);
+  } else if (cfg == 0) {
+    hipLaunchKernelGGL((polymul_kernel<XfNtt<CfgDefault128>, WPB>), grid, block, 0, st, a_small, b_torus, out, scratch, tw, f, scale, count, dev_flag);
+  } else {
+    hipLaunchKernelGGL((polymul_kernel<XfNtt<CfgRedsecV2>, WPB>), grid, block, 0, st, a_small, b_torus, out, scratch, tw, f, scale, count, dev_flag);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace rs

@@ -158,9 +158,134 @@ int emu_blind_rotate(int n, const int32_t* in0, const int32_t* in1, int32_t c0, 
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// FFT mode (rs_fft.h)
+// ---------------------------------------------------------------------------------------------
+void emu_fft_forward(Wave& w, const double* tw, double* buf) {
+  for (int l = 0; l < kLanes; ++l) rs::ffwd_F1(l, w.x[l], tw, buf);
+  for (int l = 0; l < kLanes; ++l) rs::ffwd_F2(l, w.x[l], tw, buf);
+  for (int l = 0; l < kLanes; ++l) rs::ffwd_F3(l, w.x[l], buf);
+  for (int l = 0; l < kLanes; ++l) rs::ffwd_F4(l, w.x[l], tw, buf);
+}
+void emu_fft_inverse(Wave& w, const double* tw, double* buf) {
+  for (int l = 0; l < kLanes; ++l) rs::finv_I1(l, w.x[l], tw, buf);
+  for (int l = 0; l < kLanes; ++l) rs::finv_I2(l, w.x[l], tw, buf);
+  for (int l = 0; l < kLanes; ++l) rs::finv_I3(l, w.x[l], buf);
+  for (int l = 0; l < kLanes; ++l) rs::finv_I4(l, w.x[l], tw, buf);
+}
+// key polynomial -> [v][lane][2] = (re, im) of transform position 8*lane + v, scaled by 1/M
+void emu_fft_key_transform(const int32_t* poly, double* dst, const double* tw, double* buf) {
+  Wave w;
+  for (int l = 0; l < kLanes; ++l)
+    for (int r = 0; r < kRegs; ++r) w.x[l][r] = (double)poly[l + 64 * r];
+  emu_fft_forward(w, tw, buf);
+  for (int l = 0; l < kLanes; ++l)
+    for (int v = 0; v < 8; ++v) {
+      dst[(v * 64 + l) * 2] = w.x[l][v] * (1.0 / rs::kM);
+      dst[(v * 64 + l) * 2 + 1] = w.x[l][v + 8] * (1.0 / rs::kM);
+    }
+}
+
+template <class C>
+int emu_blind_rotate_fft(int n, const int32_t* in0, const int32_t* in1, int32_t c0, int32_t c1, int32_t bconst, int32_t mu,
+                         const int32_t* bk, int32_t* u_out, int32_t* acc_out, int steps, double* max_dev_out) {
+  std::vector<double> tw = rs::make_fft_tables();
+  std::vector<double> buf(rs::kBufDoubles);
+  constexpr int KPL = 2 * C::L;
+  std::vector<double> bk_fft((size_t)n * KPL * 2 * kN);
+  for (size_t poly = 0; poly < (size_t)n * KPL * 2; ++poly)
+    emu_fft_key_transform(bk + poly * kN, bk_fft.data() + poly * kN, tw.data(), buf.data());
+  auto word = [&](int i) -> int32_t {
+    uint32_t v = (uint32_t)c0 * (uint32_t)in0[i];
+    if (in1) v += (uint32_t)c1 * (uint32_t)in1[i];
+    return (int32_t)v;
+  };
+  std::vector<int32_t> acc0(kN), acc1(kN);
+  const int32_t barb = rs::modswitch_2N((int32_t)((uint32_t)word(n) + (uint32_t)bconst));
+  const int rot = 2 * kN - barb;
+  for (int j = 0; j < kN; ++j) { acc0[j] = 0; acc1[j] = rs::rotated_const(mu, j, rot); }
+  constexpr uint32_t offset = rs::gadget_offset<C>();
+  if (steps < 0 || steps > n) steps = n;
+  Wave s0, s1, x;
+  double max_dev = 0.0;
+  for (int i = 0; i < steps; ++i) {
+    const int32_t bara = rs::modswitch_2N(word(i));
+    if (bara == 0) continue;
+    std::memset(&s0, 0, sizeof s0);
+    std::memset(&s1, 0, sizeof s1);
+    const double* bk_i = bk_fft.data() + (size_t)i * KPL * 2 * kN;
+    for (int comp = 0; comp < 2; ++comp) {
+      const int32_t* accc = comp ? acc1.data() : acc0.data();
+      for (int q = 0; q < C::L; ++q) {
+        const int row = comp * C::L + q;
+        const double* bp0 = bk_i + (size_t)(row * 2) * kN;
+        const double* bp1 = bp0 + kN;
+        for (int l = 0; l < kLanes; ++l)
+          for (int r = 0; r < kRegs; ++r) x.x[l][r] = (double)rs::gadget_digit<C>(rs::rotated_diff(accc, l + 64 * r, bara), q, offset);
+        emu_fft_forward(x, tw.data(), buf.data());
+        for (int l = 0; l < kLanes; ++l)
+          for (int v = 0; v < 8; ++v) {
+            const size_t k = ((size_t)v * 64 + l) * 2;
+            rs::fft_cmac(s0.x[l][v], s0.x[l][v + 8], x.x[l][v], x.x[l][v + 8], bp0[k], bp0[k + 1]);
+            rs::fft_cmac(s1.x[l][v], s1.x[l][v + 8], x.x[l][v], x.x[l][v + 8], bp1[k], bp1[k + 1]);
+          }
+      }
+    }
+    emu_fft_inverse(s0, tw.data(), buf.data());
+    emu_fft_inverse(s1, tw.data(), buf.data());
+    for (int l = 0; l < kLanes; ++l)
+      for (int r = 0; r < kRegs; ++r) {
+        const int j = l + 64 * r;
+        acc0[j] = (int32_t)((uint32_t)acc0[j] + (uint32_t)rs::fft_round_torus32(s0.x[l][r], max_dev));
+        acc1[j] = (int32_t)((uint32_t)acc1[j] + (uint32_t)rs::fft_round_torus32(s1.x[l][r], max_dev));
+      }
+  }
+  if (max_dev_out) *max_dev_out = max_dev;
+  if (acc_out) {
+    std::memcpy(acc_out, acc0.data(), sizeof(int32_t) * kN);
+    std::memcpy(acc_out + kN, acc1.data(), sizeof(int32_t) * kN);
+  }
+  if (u_out) {
+    for (int j = 0; j < kN; ++j) u_out[j] = (j == 0) ? acc0[0] : (int32_t)(0u - (uint32_t)acc0[kN - j]);
+    u_out[kN] = acc1[0];
+  }
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+// FFT-mode product of a small polynomial with a torus polynomial; returns the largest distance to
+// the nearest integer seen before rounding in *max_dev.
+int rs_emu_polymul_fft(const int32_t* a_small, const int32_t* b_torus, int32_t* out, double* max_dev) {
+  std::vector<double> tw = rs::make_fft_tables();
+  std::vector<double> buf(rs::kBufDoubles), bkd(kN);
+  emu_fft_key_transform(b_torus, bkd.data(), tw.data(), buf.data());
+  Wave w, s;
+  std::memset(&s, 0, sizeof s);
+  for (int l = 0; l < kLanes; ++l)
+    for (int r = 0; r < kRegs; ++r) w.x[l][r] = (double)a_small[l + 64 * r];
+  emu_fft_forward(w, tw.data(), buf.data());
+  for (int l = 0; l < kLanes; ++l)
+    for (int v = 0; v < 8; ++v) {
+      const size_t k = ((size_t)v * 64 + l) * 2;
+      rs::fft_cmac(s.x[l][v], s.x[l][v + 8], w.x[l][v], w.x[l][v + 8], bkd[k], bkd[k + 1]);
+    }
+  emu_fft_inverse(s, tw.data(), buf.data());
+  double dev = 0.0;
+  for (int l = 0; l < kLanes; ++l)
+    for (int r = 0; r < kRegs; ++r) out[l + 64 * r] = rs::fft_round_torus32(s.x[l][r], dev);
+  if (max_dev) *max_dev = dev;
+  return 0;
+}
+
+int rs_emu_blind_rotate_fft(int cfg, int n, const int32_t* in0, const int32_t* in1, int32_t c0, int32_t c1, int32_t bconst, int32_t mu,
+                            const int32_t* bk, int32_t* u_out, int32_t* acc_out, int steps, double* max_dev) {
+  return cfg == 0 ? emu_blind_rotate_fft<rs::CfgDefault128>(n, in0, in1, c0, c1, bconst, mu, bk, u_out, acc_out, steps, max_dev)
+                  : emu_blind_rotate_fft<rs::CfgRedsecV2>(n, in0, in1, c0, c1, bconst, mu, bk, u_out, acc_out, steps, max_dev);
+}
+
 
 // cfg: 0 = l=3/Bgbit=7, 1 = l=10/Bgbit=3
 int rs_emu_polymul(int cfg, const int32_t* a_small, const int32_t* b_torus, int32_t* out) {

@@ -1,0 +1,164 @@
+// rs_fft.h -- negacyclic N=1024 product via a folded 512-point complex FP64 FFT, one wavefront per
+// polynomial. This is the arithmetic CLASS TFHE itself uses (tGswFFTExternMulToTLwe: Lagrange
+// half-complex FFT in double precision), restated with this backend's own butterfly order.
+//
+// Folding: for real a(X) of degree < N let z_j = a_j + i a_{j+N/2} (j < M = N/2) and zeta = exp(i pi / N).
+// Then a(zeta^(4k+1)) = sum_j z_j zeta^j omega^(jk), omega = zeta^4 = exp(2 pi i / M): an M-point DFT of
+// the twisted sequence; the other N/2 evaluation points are complex conjugates, so M complex values
+// represent the polynomial and products are pointwise. With registers x[r] = coefficient L + 64 r
+// (r < 16) the complex value j = L + 64 r (r < 8) is (x[r], x[r+8]): the folding costs nothing.
+//
+// The twist is merged into the twiddles (evaluation-tree form): block i of stage s (m = 2^s blocks)
+// handles the roots of X^(M/m) = c_{m,i}, c_{1,0} = zeta^M = i; its twiddle is sqrt(c) =
+// exp(i theta_{m,i} / 2) with theta_{1,0} = pi/2, theta_{2m,2i} = theta_{m,i}/2,
+// theta_{2m,2i+1} = theta_{m,i}/2 + pi. Forward: Cooley-Tukey butterflies (x + w y, x - w y), natural ->
+// bit-reversed; inverse: Gentleman-Sande with conj(w). 1/M is folded into the key (a power of two).
+//
+// Exactness: the true product coefficients are integers below 2^50; the FP64 FFT returns them with an
+// error of standard deviation ~0.02 (default-128) or less, so rounding to the nearest integer
+// reproduces the exact product (and hence the exact-NTT path and the CPU oracle) bit for bit with
+// overwhelming probability. It is not a worst-case guarantee: the kernels track the largest distance
+// to the nearest integer they ever round (the "certificate": values << 0.5 mean errors of +-1 are
+// many tens of sigma away) and the exact NTT path remains available (RS_MODE_EXACT_NTT).
+//
+// Layouts (8 complex per lane): A' j = L + 64 r; B' j = 64 (L>>3) + 8 s + (L&7); C' j = 8 L + u.
+// Stages 0-2 in A', LDS transpose, 3-5 in B', LDS transpose, 6-8 in C' (inverse mirrored).
+#pragma once
+
+#include <cstdint>
+
+#include "rs_ntt.h"
+
+namespace rs {
+
+constexpr int kM = kN / 2;           // complex points
+constexpr int kCRegs = 8;            // complex values per lane
+constexpr int kFftTwDoubles = 2 * kM;  // complex twiddle table (interleaved re, im), stage-transposed
+
+struct Cplx { double re, im; };
+
+// Position (in complex units) of table entry m + i in the stage-transposed table (cf. tw_pos).
+RS_HD int ftw_pos(int idx) {
+  int s = 0;
+  while ((2 << s) <= idx) ++s;
+  const int m = 1 << s, off = idx - m;
+  if (s <= 2) return idx;
+  if (s <= 5) { const int E = m >> 3; return m + (off % E) * 8 + off / E; }     // stages 3-5: b = lane>>3 in [0,8)
+  const int E = m >> 6;
+  return m + (off % E) * 64 + off / E;                                            // stages 6-8: lane in [0,64)
+}
+
+// exchange-buffer positions (complex units); paddings give conflict-free 16-byte accesses
+RS_HD int fpos_t1(int j) { return j + 8 * (j >> 7); }
+RS_HD int fpos_t2(int j) { return j + (j >> 3); }
+
+RS_HD void fft_bfly_fwd(double& xr, double& xi, double& yr, double& yi, double wr, double wi) {
+  const double tr = __builtin_fma(-wi, yi, wr * yr);
+  const double ti = __builtin_fma(wr, yi, wi * yr);
+  const double ar = xr, ai = xi;
+  xr = ar + tr; xi = ai + ti;
+  yr = ar - tr; yi = ai - ti;
+}
+RS_HD void fft_bfly_inv(double& xr, double& xi, double& yr, double& yi, double wr, double wi) {
+  const double dr = xr - yr, di = xi - yi;
+  xr = xr + yr; xi = xi + yi;
+  yr = __builtin_fma(wi, di, wr * dr);      // conj(w) * d
+  yi = __builtin_fma(-wi, dr, wr * di);
+}
+
+// x[e] = re, x[e+8] = im of the lane's e-th complex value. tw: interleaved complex table.
+RS_HD void fft_stage_fwd(double (&x)[kRegs], int half, const double* tw, int tw_base, int shift, int stride) {
+#pragma unroll
+  for (int e = 0; e < kCRegs; ++e) {
+    if (e & half) continue;
+    const int t = tw_base + (e >> shift) * stride;
+    fft_bfly_fwd(x[e], x[e + 8], x[e + half], x[e + half + 8], tw[2 * t], tw[2 * t + 1]);
+  }
+}
+RS_HD void fft_stage_inv(double (&x)[kRegs], int half, const double* tw, int tw_base, int shift, int stride) {
+#pragma unroll
+  for (int e = 0; e < kCRegs; ++e) {
+    if (e & half) continue;
+    const int t = tw_base + (e >> shift) * stride;
+    fft_bfly_inv(x[e], x[e + 8], x[e + half], x[e + half + 8], tw[2 * t], tw[2 * t + 1]);
+  }
+}
+
+RS_HD void fbuf_store(double* buf, int pos, double re, double im) { buf[2 * pos] = re; buf[2 * pos + 1] = im; }
+RS_HD void fbuf_load(const double* buf, int pos, double& re, double& im) { re = buf[2 * pos]; im = buf[2 * pos + 1]; }
+
+// ---- forward: input x[r] = real coefficient L + 64 r (r < 16), i.e. already folded ----
+RS_HD void ffwd_F1(int lane, double (&x)[kRegs], const double* tw, double* buf) {
+#pragma unroll
+  for (int s = 0; s < 3; ++s) fft_stage_fwd(x, 4 >> s, tw, 1 << s, 3 - s, 1);
+#pragma unroll
+  for (int r = 0; r < kCRegs; ++r) fbuf_store(buf, fpos_t1(lane + 64 * r), x[r], x[r + 8]);
+}
+RS_HD void ffwd_F2(int lane, double (&x)[kRegs], const double* tw, const double* buf) {
+  const int b = lane >> 3, q = lane & 7;
+#pragma unroll
+  for (int s = 0; s < kCRegs; ++s) fbuf_load(buf, fpos_t1(64 * b + 8 * s + q), x[s], x[s + 8]);
+#pragma unroll
+  for (int s = 3; s < 6; ++s) fft_stage_fwd(x, 4 >> (s - 3), tw, (1 << s) + b, 6 - s, 8);
+}
+RS_HD void ffwd_F3(int lane, const double (&x)[kRegs], double* buf) {
+  const int b = lane >> 3, q = lane & 7;
+#pragma unroll
+  for (int s = 0; s < kCRegs; ++s) fbuf_store(buf, fpos_t2(64 * b + 8 * s + q), x[s], x[s + 8]);
+}
+// output: x[u] + i x[u+8] = transform value at position 8*lane + u
+RS_HD void ffwd_F4(int lane, double (&x)[kRegs], const double* tw, const double* buf) {
+#pragma unroll
+  for (int u = 0; u < kCRegs; ++u) fbuf_load(buf, fpos_t2(8 * lane + u), x[u], x[u + 8]);
+#pragma unroll
+  for (int s = 6; s < 9; ++s) fft_stage_fwd(x, 4 >> (s - 6), tw, (1 << s) + lane, 9 - s, 64);
+}
+
+// ---- inverse (mirror) ----
+RS_HD void finv_I1(int lane, double (&x)[kRegs], const double* tw, double* buf) {
+#pragma unroll
+  for (int s = 8; s >= 6; --s) fft_stage_inv(x, 4 >> (s - 6), tw, (1 << s) + lane, 9 - s, 64);
+#pragma unroll
+  for (int u = 0; u < kCRegs; ++u) fbuf_store(buf, fpos_t2(8 * lane + u), x[u], x[u + 8]);
+}
+RS_HD void finv_I2(int lane, double (&x)[kRegs], const double* tw, const double* buf) {
+  const int b = lane >> 3, q = lane & 7;
+#pragma unroll
+  for (int s = 0; s < kCRegs; ++s) fbuf_load(buf, fpos_t2(64 * b + 8 * s + q), x[s], x[s + 8]);
+#pragma unroll
+  for (int s = 5; s >= 3; --s) fft_stage_inv(x, 4 >> (s - 3), tw, (1 << s) + b, 6 - s, 8);
+}
+RS_HD void finv_I3(int lane, const double (&x)[kRegs], double* buf) {
+  const int b = lane >> 3, q = lane & 7;
+#pragma unroll
+  for (int s = 0; s < kCRegs; ++s) fbuf_store(buf, fpos_t1(64 * b + 8 * s + q), x[s], x[s + 8]);
+}
+// output: x[r] = real coefficient L + 64 r of the product (r < 16), before rounding
+RS_HD void finv_I4(int lane, double (&x)[kRegs], const double* tw, const double* buf) {
+#pragma unroll
+  for (int r = 0; r < kCRegs; ++r) fbuf_load(buf, fpos_t1(lane + 64 * r), x[r], x[r + 8]);
+#pragma unroll
+  for (int s = 2; s >= 0; --s) fft_stage_inv(x, 4 >> s, tw, 1 << s, 3 - s, 1);
+}
+
+// pointwise complex multiply-accumulate: (sr, si) += (xr, xi) * (wr, wi)
+RS_HD void fft_cmac(double& sr, double& si, double xr, double xi, double wr, double wi) {
+  sr = __builtin_fma(xr, wr, sr);
+  sr = __builtin_fma(-xi, wi, sr);
+  si = __builtin_fma(xr, wi, si);
+  si = __builtin_fma(xi, wr, si);
+}
+
+// round an almost-integer double (|v| < 2^51) to torus32 and report its distance to that integer
+RS_HD int32_t fft_round_torus32(double v, double& max_dev) {
+  const double t = v + 6755399441055744.0;       // 1.5 * 2^52: t's low mantissa bits = rint(v)
+  const double r = t - 6755399441055744.0;
+  double dev = v - r;
+  dev = dev < 0 ? -dev : dev;
+  max_dev = dev > max_dev ? dev : max_dev;
+  long long bits;
+  __builtin_memcpy(&bits, &t, sizeof(bits));
+  return (int32_t)(uint32_t)(unsigned long long)bits;
+}
+
+}  // namespace rs

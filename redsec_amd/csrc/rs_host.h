@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 
+#include "rs_fft.h"
 #include "rs_ntt.h"
 
 namespace rs {
@@ -75,6 +76,26 @@ inline Tables make_tables(const PrimeSpec& ps, int fuse) {
         const uint64_t du = dgt >= 0 ? (uint64_t)dgt : ps.p - (uint64_t)(-dgt);
         sm[k * 128 + tt] = centered(mulmod_u64(c[k], du, ps.p), ps.p);
       }
+  }
+  return t;
+}
+
+// Complex twiddles of the folded FFT (rs_fft.h): w_{m,i} = exp(2 pi i (1 + 4 bitrev_s(i)) / 2^(s+3)),
+// m = 2^s, stored interleaved (re, im) at the stage-transposed position ftw_pos(m + i).
+inline std::vector<double> make_fft_tables() {
+  std::vector<double> t(kFftTwDoubles, 0.0);
+  const long double two_pi = 6.283185307179586476925286766559005768L;
+  for (int s = 0; s < 9; ++s) {
+    const int m = 1 << s;
+    for (int i = 0; i < m; ++i) {
+      int br = 0;
+      for (int b = 0; b < s; ++b) br |= ((i >> b) & 1) << (s - 1 - b);
+      const long a = (long)(1 + 4 * br) << (9 - s);            // angle in units of 2 pi / 4096
+      const long double ang = two_pi * (long double)a / 4096.0L;
+      const int pos = ftw_pos(m + i);
+      t[2 * pos] = (double)cosl(ang);
+      t[2 * pos + 1] = (double)sinl(ang);
+    }
   }
   return t;
 }

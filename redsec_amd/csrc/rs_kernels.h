@@ -16,17 +16,15 @@ struct BlindRotateArgs {
   int32_t c0, c1;       // x = c0*in0 + c1*in1 (word-wise, wrapping)
   int32_t bconst;       // added to the b word
   int32_t mu;           // test-vector value
-  const double* bk_ntt; // [n][2l][2][8][64][2]
-  const double* tw;     // [2048]
+  const double* bk_x;   // transform-domain key of the active mode: [n][2l][2][8][64][2]
+  const double* tw;     // twiddle tables of the active mode
   Field f;
   int32_t n;
   int32_t W;            // n + 1
   long B;
   int32_t* u_out;       // [B][N+1] extracted samples
-  int32_t stagger;      // start delay of waves 4-7, units of s_sleep(8) = 512 cycles
-  int32_t prio;         // 1: waves 4-7 run at s_setprio 1
   unsigned int* counter;  // persistent-wave work counter (device), or nullptr
-  unsigned long long* debug;  // diagnostic builds only (RS_STAMPS): [B][12] cycle sums, else unused
+  unsigned long long* dev_flag;  // FFT mode: running max of the rounding distance (double bits), or nullptr
 };
 
 struct KeyswitchArgs {
@@ -42,13 +40,13 @@ struct KeyswitchArgs {
 struct ConvShape { int32_t H, Wd, Cin, Cout, fh, fw, stride_h, stride_w, off_h, off_w, Ho, Wo; };
 struct PoolShape { int32_t H, Wd, C, win_h, win_w, stride_h, stride_w, off_h, off_w, Ho, Wo; };
 
-// cfg: 0 = CfgDefault128 (l=3, Bgbit=7), 1 = CfgRedsecV2 (l=10, Bgbit=3)
-hipError_t launch_blind_rotate(int cfg, const BlindRotateArgs& a, int waves_per_block, int num_cus, hipStream_t st);
-hipError_t launch_bk_transform(int cfg, const int32_t* bk, double* bk_ntt, const double* tw, Field f, double ninv, long n_polys,
-                               hipStream_t st);
+// cfg: 0 = CfgDefault128 (l=3, Bgbit=7), 1 = CfgRedsecV2 (l=10, Bgbit=3); mode: 0 = exact NTT, 1 = FFT
+hipError_t launch_blind_rotate(int cfg, int mode, const BlindRotateArgs& a, int waves_per_block, int num_cus, hipStream_t st);
+hipError_t launch_bk_transform(int cfg, int mode, const int32_t* bk, double* bk_x, const double* tw, Field f, double scale,
+                               long n_polys, hipStream_t st);
 hipError_t launch_keyswitch(const KeyswitchArgs& a, hipStream_t st);
-hipError_t launch_polymul(int cfg, const int32_t* a_small, const int32_t* b_torus, int32_t* out, const double* tw, Field f,
-                          double ninv, long count, hipStream_t st);
+hipError_t launch_polymul(int cfg, int mode, const int32_t* a_small, const int32_t* b_torus, int32_t* out, double* scratch,
+                          const double* tw, Field f, double scale, long count, unsigned long long* dev_flag, hipStream_t st);
 hipError_t launch_lincomb(int32_t* out, const int32_t* x, int32_t cx, const int32_t* y, int32_t cy, int32_t bconst, int W, long B,
                           hipStream_t st);
 hipError_t launch_gather_rows(int32_t* out, const int32_t* in, const int32_t* idx, int W, long B, hipStream_t st);

@@ -1,17 +1,8 @@
-// rs_kernels.hip -- gfx950 kernels of the gate-bootstrapping hot path.
-//
-//   bk_transform_kernel    bootstrapping key -> transform domain (the bkFFT analogue; once per key)
-//   blind_rotate_kernel    gate pre-combination + modswitch + n CMUX steps + sample extract
-//                          (tfhe_bootstrap_woKS_FFT; REDsec: lib/BinOps_enc.cpp:185,191)
-//   keyswitch_kernel       lweKeySwitch (N -> n)
-//   polymul_kernel         debug/parity tap through the same transform path
-//   lincomb / linear_fc / conv_ternary / sumpool   LWE word arithmetic of the layer linear stage
-//
-// One wavefront owns one ciphertext for the whole blind rotation: its TRLWE accumulator (2 x 1024
-// int32) lives in LDS, each of the (k+1) l digit polynomials is transformed in registers with two
-// LDS transposes (rs_ntt.h), multiplied against the coalesced-streamed key row and accumulated in
-// registers, and two inverse transforms update the accumulator. Waves never synchronise with each
-// other after the twiddle tables are staged, so the 2 waves per SIMD interleave freely.
+// rs_kernels.hip -- integer kernels of the gate-bootstrapping hot path (the transform-based ones
+// live in rs_bootstrap.hip):
+//   keyswitch_tiled_kernel / keyswitch_kernel   lweKeySwitch (N -> n)
+//   lincomb / gather_rows / linear_fc / conv_ternary / sumpool   LWE word arithmetic of the layer
+//                                                                linear stage and the max-pool gather
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -20,402 +11,6 @@
 #include "rs_ntt.h"
 
 namespace rs {
-
-// Same-wave LDS hand-off: DS operations of one wavefront execute in order, so only the compiler
-// needs to be told not to move LDS accesses across this point.
-__device__ __forceinline__ void wave_lds_sync() {
-#if defined(RS_EXP_NOSYNC)  // timing experiment: let the compiler reorder/merge across LDS hand-offs
-  return;
-#endif
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// Diagnostic build only (-DRS_STAMPS): per-phase cycle stamps, accumulated per wave and written to
-// a debug buffer nothing else reads. Never enabled in the product build.
-#if defined(RS_STAMPS)
-#define RS_NSTAMP 12
-struct Stamps { unsigned long long t, acc[RS_NSTAMP]; };
-__device__ __forceinline__ void stamp_start(Stamps& s) {
-  __builtin_amdgcn_sched_barrier(0);
-  s.t = __builtin_amdgcn_s_memtime();
-  __builtin_amdgcn_sched_barrier(0);
-}
-__device__ __forceinline__ void stamp(Stamps& s, int k) {
-  __builtin_amdgcn_sched_barrier(0);
-  const unsigned long long now = __builtin_amdgcn_s_memtime();
-  s.acc[k] += now - s.t;
-  s.t = now;
-  __builtin_amdgcn_sched_barrier(0);
-}
-#define RS_STAMP(k) stamp(st, k)
-#else
-#define RS_STAMP(k)
-#endif
-
-template <class C>
-__device__ __forceinline__ void ntt_forward(int lane, double (&x)[kRegs], const double* tw, double* buf, const Field& f) {
-  fwd_F1<C>(lane, x, tw, buf, f);
-  wave_lds_sync();
-  fwd_F2<C>(lane, x, tw, buf, f);
-  wave_lds_sync();
-  fwd_F3(lane, x, buf);
-  wave_lds_sync();
-  fwd_F4<C>(lane, x, tw, buf, f);
-  wave_lds_sync();
-}
-
-// forward transform of gadget digit q of the coefficients d (fused stages 0-1, rs_ntt.h)
-template <class C>
-__device__ __forceinline__ void ntt_forward_digits(int lane, double (&x)[kRegs], const int32_t (&d)[kRegs], int q, uint32_t offset,
-                                                   const double* tw, double* buf, const Field& f
-#if defined(RS_STAMPS)
-                                                   , Stamps& st
-#endif
-) {
-  fwd_F1_digits<C>(lane, x, d, q, offset, tw, buf, f);
-  wave_lds_sync();
-  RS_STAMP(1);
-  fwd_F2<C>(lane, x, tw, buf, f);
-  wave_lds_sync();
-  RS_STAMP(2);
-  fwd_F3(lane, x, buf);
-  wave_lds_sync();
-  RS_STAMP(3);
-  fwd_F4<C>(lane, x, tw, buf, f);
-  wave_lds_sync();
-  RS_STAMP(4);
-}
-
-template <class C>
-__device__ __forceinline__ void ntt_inverse(int lane, double (&x)[kRegs], const double* twi, double* buf, const Field& f) {
-  inv_I1<C>(lane, x, twi, buf, f);
-  wave_lds_sync();
-  inv_I2<C>(lane, x, twi, buf, f);
-  wave_lds_sync();
-  inv_I3(lane, x, buf);
-  wave_lds_sync();
-  inv_I4<C>(lane, x, twi, buf, f);
-  wave_lds_sync();
-}
-
-__device__ __forceinline__ void stage_tables(double* s_tw, const double* tw_g, int nthreads, int count = 2 * kN) {
-  for (int i = threadIdx.x; i < count; i += nthreads) s_tw[i] = tw_g[i];
-  __syncthreads();
-}
-
-// -------------------------------------------------------------------------------------------------
-// Key transform: one wavefront per key polynomial. Output layout per polynomial: [v 0..7][lane][2]
-// doubles = transform positions 16*lane + 2v, +1, so that the blind rotation reads each row with
-// eight perfectly coalesced 16-byte-per-lane loads. Values are scaled by 1/N and fully reduced.
-// -------------------------------------------------------------------------------------------------
-template <class C, int WPB>
-__global__ __launch_bounds__(64 * WPB) void bk_transform_kernel(const int32_t* __restrict__ bk, double* __restrict__ bk_ntt,
-                                                                 const double* __restrict__ tw_g, Field f, double ninv,
-                                                                 long n_polys) {
-  __shared__ double s_tw[2 * kN];
-  __shared__ double s_buf[WPB][kBufDoubles];
-  stage_tables(s_tw, tw_g, 64 * WPB);
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = threadIdx.x & 63;
-  const long poly = (long)blockIdx.x * WPB + wave;
-  if (poly >= n_polys) return;
-  double x[kRegs];
-  const int32_t* src = bk + poly * kN;
-#pragma unroll
-  for (int r = 0; r < kRegs; ++r) x[r] = (double)src[lane + 64 * r];
-  ntt_forward<C>(lane, x, s_tw, s_buf[wave], f);
-  double2* dst = reinterpret_cast<double2*>(bk_ntt + poly * kN);
-#pragma unroll
-  for (int v = 0; v < 8; ++v) {
-    double a = f_reduce(f_mulmod(f_reduce(x[2 * v], f), ninv, f), f);
-    double b = f_reduce(f_mulmod(f_reduce(x[2 * v + 1], f), ninv, f), f);
-    dst[v * 64 + lane] = make_double2(a, b);
-  }
-}
-
-// -------------------------------------------------------------------------------------------------
-// Blind rotation + sample extract.
-// -------------------------------------------------------------------------------------------------
-template <class C, int WPB>
-__global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs a) {
-  __shared__ double s_tw[kTwTotal];
-  __shared__ double s_buf[WPB][kBufDoubles];
-  __shared__ int32_t s_acc[WPB][2][kN];
-  stage_tables(s_tw, a.tw, 64 * WPB, kTwTotal);
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = threadIdx.x & 63;
-  // De-phase knobs (measured: no effect, kept for experiments): waves 4-7 start late / higher prio.
-  if (WPB >= 8 && wave >= 4) {
-    for (int k = 0; k < a.stagger; ++k) __builtin_amdgcn_s_sleep(8);
-    if (a.prio) __builtin_amdgcn_s_setprio(1);
-  }
-  // Persistent waves: the first ciphertext is assigned statically, further ones are pulled from a
-  // device counter (zeroed by the launcher on the same stream). A 152 KB-LDS workgroup cannot be
-  // replaced until its LAST wave exits, and waves sharing a SIMD finish up to 20 % apart (issue
-  // arbitration favours the older wave), which left 18 % of the wave slots idle with one
-  // ciphertext per wave (profiles/r01: stamps build). Every wave leaves the loop as soon as the
-  // counter passes B, so the grid always drains.
-  long ct = (long)blockIdx.x * WPB + wave;
-  const long first_dynamic = (long)gridDim.x * WPB;
-  if (ct >= a.B) return;
-
-  const Field f = a.f;
-  double* buf = s_buf[wave];
-  int32_t* acc0 = s_acc[wave][0];
-  int32_t* acc1 = s_acc[wave][1];
-  const double* tw = s_tw;
-  const double* twi = s_tw + kN;
- for (;;) {
-  const int32_t* row0 = a.in0 + ct * a.W;
-  const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
-  const int n = a.n;
-
-  // gate pre-combination (0, bconst) + c0*in0 + c1*in1, evaluated word by word as it is consumed
-  auto word = [&](int i) -> int32_t {
-    uint32_t v = (uint32_t)a.c0 * (uint32_t)row0[i];
-    if (row1) v += (uint32_t)a.c1 * (uint32_t)row1[i];
-    return (int32_t)v;
-  };
-
-  {
-    const int32_t barb = modswitch_2N((int32_t)((uint32_t)word(n) + (uint32_t)a.bconst));
-    const int rot = 2 * kN - barb;  // in (0, 2N]
-#pragma unroll
-    for (int r = 0; r < kRegs; ++r) {
-      const int j = lane + 64 * r;
-      acc0[j] = 0;
-      acc1[j] = rotated_const(a.mu, j, rot);
-    }
-  }
-  wave_lds_sync();
-
-  constexpr uint32_t offset = gadget_offset<C>();
-  constexpr int KPL = 2 * C::L;
-#if defined(RS_STAMPS)
-  Stamps st;
-  for (int k = 0; k < RS_NSTAMP; ++k) st.acc[k] = 0;
-  const unsigned long long real0 = __builtin_amdgcn_s_memrealtime();
-  stamp_start(st);
-#endif
-
-  for (int i = 0; i < n; ++i) {
-    const int32_t bara = __builtin_amdgcn_readfirstlane(modswitch_2N(word(i)));
-    if (bara == 0) continue;  // tfhe_blindRotate_FFT skips the identity CMUX
-    if (WPB >= 8 && a.prio == 2) {   // experiment: alternate issue priority between the SIMD partners
-      if (((wave >> 2) ^ i) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-    }
-    double s0[kRegs], s1[kRegs];
-#pragma unroll
-    for (int u = 0; u < kRegs; ++u) { s0[u] = 0.0; s1[u] = 0.0; }
-    const double* bk_i = a.bk_ntt + (size_t)i * KPL * 2 * kN;
-
-#pragma unroll 1
-    for (int comp = 0; comp < 2; ++comp) {
-      const int32_t* accc = comp ? acc1 : acc0;
-      int32_t d[kRegs];
-#pragma unroll
-      for (int r = 0; r < kRegs; ++r) d[r] = rotated_diff(accc, lane + 64 * r, bara);
-      RS_STAMP(0);
-#if defined(RS_EXP_UNROLLQ)
-#pragma unroll
-#else
-#pragma unroll 1
-#endif
-      for (int q = 0; q < C::L; ++q) {
-        const int row = comp * C::L + q;
-        if (WPB >= 8 && a.prio == 3) {   // experiment: alternate priority per digit row
-          if (((wave >> 2) ^ row) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-        }
-        const double2* bp0 = reinterpret_cast<const double2*>(bk_i + (size_t)(row * 2) * kN);
-        const double2* bp1 = bp0 + kN / 2;
-        double2 w0[8], w1[8];
-#if defined(RS_EXP_NOBK)   // timing experiment: no key-row loads
-#pragma unroll
-        for (int v = 0; v < 8; ++v) { w0[v] = make_double2(1.0 + lane + q, 2.0 + v); w1[v] = make_double2(3.0 + v, 5.0 + lane); }
-#else
-#pragma unroll
-        for (int v = 0; v < 8; ++v) { w0[v] = bp0[v * 64 + lane]; w1[v] = bp1[v * 64 + lane]; }
-#endif
-        double x[kRegs];
-#if defined(RS_STAMPS)
-        RS_STAMP(5);
-        ntt_forward_digits<C>(lane, x, d, q, offset, tw, buf, f, st);
-#else
-        ntt_forward_digits<C>(lane, x, d, q, offset, tw, buf, f);
-#endif
-#pragma unroll
-        for (int v = 0; v < 8; ++v) {
-          s0[2 * v] += f_mulmod(x[2 * v], w0[v].x, f);
-          s0[2 * v + 1] += f_mulmod(x[2 * v + 1], w0[v].y, f);
-          s1[2 * v] += f_mulmod(x[2 * v], w1[v].x, f);
-          s1[2 * v + 1] += f_mulmod(x[2 * v + 1], w1[v].y, f);
-        }
-        RS_STAMP(6);
-      }
-      if (C::MID_REDUCE && comp == 0) {
-#pragma unroll
-        for (int u = 0; u < kRegs; ++u) { s0[u] = f_reduce(s0[u], f); s1[u] = f_reduce(s1[u], f); }
-      }
-    }
-
-    RS_STAMP(7);
-    ntt_inverse<C>(lane, s0, twi, buf, f);
-    RS_STAMP(8);
-#pragma unroll
-    for (int r = 0; r < kRegs; ++r) {
-      const int j = lane + 64 * r;
-      acc0[j] = (int32_t)((uint32_t)acc0[j] + (uint32_t)f_to_torus32(s0[r]));
-    }
-    RS_STAMP(9);
-    ntt_inverse<C>(lane, s1, twi, buf, f);
-    RS_STAMP(10);
-#pragma unroll
-    for (int r = 0; r < kRegs; ++r) {
-      const int j = lane + 64 * r;
-      acc1[j] = (int32_t)((uint32_t)acc1[j] + (uint32_t)f_to_torus32(s1[r]));
-    }
-    wave_lds_sync();
-  }
-
-#if defined(RS_STAMPS)
-  RS_STAMP(11);
-  st.acc[11] = __builtin_amdgcn_s_memrealtime() - real0;   // 100 MHz ticks for the whole rotation
-  if (lane == 0 && a.debug)
-    for (int k = 0; k < RS_NSTAMP; ++k) a.debug[ct * RS_NSTAMP + k] = st.acc[k];
-#endif
-  // tLweExtractLweSampleIndex(index 0): a'[0] = acc_a[0], a'[j] = -acc_a[N-j], b' = acc_b[0]
-  int32_t* out = a.u_out + ct * (kN + 1);
-#pragma unroll
-  for (int r = 0; r < kRegs; ++r) {
-    const int j = lane + 64 * r;
-    out[j] = (j == 0) ? acc0[0] : (int32_t)(0u - (uint32_t)acc0[kN - j]);
-  }
-  if (lane == 0) out[kN] = acc1[0];
-
-  if (!a.counter) break;
-  unsigned int nxt = 0;
-  if (lane == 0) nxt = atomicAdd(a.counter, 1u);
-  nxt = (unsigned int)__builtin_amdgcn_readfirstlane((int)nxt);
-  ct = first_dynamic + (long)nxt;
-  if (ct >= a.B) break;
-  wave_lds_sync();
- }
-}
-
-// -------------------------------------------------------------------------------------------------
-// Cooperative blind rotation (latency form, B <= 2 x #CUs): G waves share ONE ciphertext.
-// Wave g transforms the digit polynomials [g R, (g+1) R) (R = 2l / G, so each wave stays within one
-// accumulator component) and accumulates its partial column sums; the partials meet in LDS, waves 0
-// and 1 sum one column each, run the inverse transform and update the shared accumulator. Two
-// workgroup barriers per CMUX step. A 196-neuron layer thus spreads over 196 CUs x 4 SIMDs
-// instead of one wave per CU (MNIST layer 0: 18.4 ms -> see profiles/).
-// -------------------------------------------------------------------------------------------------
-#if !defined(RS_STAMPS)
-template <class C, int G>
-__global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateArgs a) {
-  constexpr int KPL = 2 * C::L;
-  constexpr int R = KPL / G;
-  static_assert(KPL % G == 0 && G % 2 == 0, "waves must split the digit rows evenly within a component");
-  __shared__ double s_tw[kTwTotal];
-  __shared__ double s_buf[G][kBufDoubles];
-  __shared__ double s_part[G][2][kN];
-  __shared__ int32_t s_acc[2][kN];
-  stage_tables(s_tw, a.tw, 64 * G, kTwTotal);
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = threadIdx.x & 63;
-  const long ct = blockIdx.x;
-  const Field f = a.f;
-  double* buf = s_buf[wave];
-  const double* tw = s_tw;
-  const double* twi = s_tw + kN;
-  const int32_t* row0 = a.in0 + ct * a.W;
-  const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
-  const int n = a.n;
-  const int comp = wave / (G / 2);
-  const int row_begin = wave * R;
-  auto word = [&](int i) -> int32_t {
-    uint32_t v = (uint32_t)a.c0 * (uint32_t)row0[i];
-    if (row1) v += (uint32_t)a.c1 * (uint32_t)row1[i];
-    return (int32_t)v;
-  };
-  if (wave < 2) {
-    const int32_t barb = modswitch_2N((int32_t)((uint32_t)word(n) + (uint32_t)a.bconst));
-    const int rot = 2 * kN - barb;
-#pragma unroll
-    for (int r = 0; r < kRegs; ++r) {
-      const int j = lane + 64 * r;
-      s_acc[wave][j] = wave == 0 ? 0 : rotated_const(a.mu, j, rot);
-    }
-  }
-  __syncthreads();
-  constexpr uint32_t offset = gadget_offset<C>();
-  for (int i = 0; i < n; ++i) {
-    const int32_t bara = __builtin_amdgcn_readfirstlane(modswitch_2N(word(i)));
-    if (bara == 0) continue;   // uniform over the workgroup: every wave works on the same ciphertext
-    double s0[kRegs], s1[kRegs];
-#pragma unroll
-    for (int u = 0; u < kRegs; ++u) { s0[u] = 0.0; s1[u] = 0.0; }
-    const double* bk_i = a.bk_ntt + (size_t)i * KPL * 2 * kN;
-    int32_t d[kRegs];
-#pragma unroll
-    for (int r = 0; r < kRegs; ++r) d[r] = rotated_diff(s_acc[comp], lane + 64 * r, bara);
-#pragma unroll 1
-    for (int rr = 0; rr < R; ++rr) {
-      const int row = row_begin + rr;
-      const int q = row - comp * C::L;
-      const double2* bp0 = reinterpret_cast<const double2*>(bk_i + (size_t)(row * 2) * kN);
-      const double2* bp1 = bp0 + kN / 2;
-      double2 w0[8], w1[8];
-#pragma unroll
-      for (int v = 0; v < 8; ++v) { w0[v] = bp0[v * 64 + lane]; w1[v] = bp1[v * 64 + lane]; }
-      double x[kRegs];
-      ntt_forward_digits<C>(lane, x, d, q, offset, tw, buf, f);
-#pragma unroll
-      for (int v = 0; v < 8; ++v) {
-        s0[2 * v] += f_mulmod(x[2 * v], w0[v].x, f);
-        s0[2 * v + 1] += f_mulmod(x[2 * v + 1], w0[v].y, f);
-        s1[2 * v] += f_mulmod(x[2 * v], w1[v].x, f);
-        s1[2 * v + 1] += f_mulmod(x[2 * v + 1], w1[v].y, f);
-      }
-    }
-    // partial sums (<= R products each) reduced, then exchanged: position u*64 + lane is conflict-free
-#pragma unroll
-    for (int u = 0; u < kRegs; ++u) {
-      s_part[wave][0][u * 64 + lane] = f_reduce(s0[u], f);
-      s_part[wave][1][u * 64 + lane] = f_reduce(s1[u], f);
-    }
-    __syncthreads();   // partials visible; every wave has finished reading the accumulator
-    if (wave < 2) {
-      double x[kRegs];
-#pragma unroll
-      for (int u = 0; u < kRegs; ++u) {
-        double t = s_part[0][wave][u * 64 + lane];
-#pragma unroll
-        for (int g = 1; g < G; ++g) t += s_part[g][wave][u * 64 + lane];
-        x[u] = t;
-      }
-      ntt_inverse<C>(lane, x, twi, buf, f);
-#pragma unroll
-      for (int r = 0; r < kRegs; ++r) {
-        const int j = lane + 64 * r;
-        s_acc[wave][j] = (int32_t)((uint32_t)s_acc[wave][j] + (uint32_t)f_to_torus32(x[r]));
-      }
-    }
-    __syncthreads();   // accumulator updated
-  }
-  int32_t* out = a.u_out + ct * (kN + 1);
-  if (wave == 0) {
-#pragma unroll
-    for (int r = 0; r < kRegs; ++r) {
-      const int j = lane + 64 * r;
-      out[j] = (j == 0) ? s_acc[0][0] : (int32_t)(0u - (uint32_t)s_acc[0][kN - j]);
-    }
-    if (lane == 0) out[kN] = s_acc[1][0];
-  }
-}
-#endif
 
 // -------------------------------------------------------------------------------------------------
 // Keyswitch: one workgroup per ciphertext, threads over output words. The KSK (83-104 MB) stays in
@@ -578,38 +173,6 @@ __global__ __launch_bounds__(KS_TILE_THREADS) void keyswitch_tiled_kernel(Keyswi
 }
 
 // -------------------------------------------------------------------------------------------------
-// Debug tap: out = a_small * b_torus (negacyclic, mod 2^32) through forward/pointwise/inverse.
-// -------------------------------------------------------------------------------------------------
-template <class C, int WPB>
-__global__ __launch_bounds__(64 * WPB) void polymul_kernel(const int32_t* __restrict__ a_small, const int32_t* __restrict__ b_torus,
-                                                            int32_t* __restrict__ out, const double* __restrict__ tw_g, Field f,
-                                                            double ninv, long count) {
-  __shared__ double s_tw[2 * kN];
-  __shared__ double s_buf[WPB][kBufDoubles];
-  stage_tables(s_tw, tw_g, 64 * WPB);
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = threadIdx.x & 63;
-  const long idx = (long)blockIdx.x * WPB + wave;
-  if (idx >= count) return;
-  double* buf = s_buf[wave];
-  double xa[kRegs], xb[kRegs];
-#pragma unroll
-  for (int r = 0; r < kRegs; ++r) {
-    xa[r] = (double)a_small[idx * kN + lane + 64 * r];
-    xb[r] = (double)b_torus[idx * kN + lane + 64 * r];
-  }
-  ntt_forward<C>(lane, xb, s_tw, buf, f);
-#pragma unroll
-  for (int u = 0; u < kRegs; ++u) xb[u] = f_reduce(f_mulmod(f_reduce(xb[u], f), ninv, f), f);
-  ntt_forward<C>(lane, xa, s_tw, buf, f);
-#pragma unroll
-  for (int u = 0; u < kRegs; ++u) xa[u] = f_mulmod(xa[u], xb[u], f);
-  ntt_inverse<C>(lane, xa, s_tw + kN, buf, f);
-#pragma unroll
-  for (int r = 0; r < kRegs; ++r) out[idx * kN + lane + 64 * r] = f_to_torus32(xa[r]);
-}
-
-// -------------------------------------------------------------------------------------------------
 // LWE word arithmetic
 // -------------------------------------------------------------------------------------------------
 __global__ void lincomb_kernel(int32_t* __restrict__ out, const int32_t* __restrict__ x, int32_t cx, const int32_t* __restrict__ y,
@@ -716,61 +279,6 @@ __global__ __launch_bounds__(256) void sumpool_kernel(int32_t* __restrict__ out,
 // -------------------------------------------------------------------------------------------------
 // Launchers
 // -------------------------------------------------------------------------------------------------
-template <class C, int WPB>
-static hipError_t launch_br(const BlindRotateArgs& a, long max_blocks, hipStream_t st) {
-  long blocks = (a.B + WPB - 1) / WPB;
-  BlindRotateArgs args = a;
-  if (a.counter && blocks > max_blocks) {
-    blocks = max_blocks;                       // persistent: one workgroup per CU, waves pull work
-    hipError_t e = hipMemsetAsync(a.counter, 0, sizeof(unsigned int), st);
-    if (e != hipSuccess) return e;
-  } else {
-    args.counter = nullptr;                    // every wave has exactly one ciphertext
-  }
-  hipLaunchKernelGGL((blind_rotate_kernel<C, WPB>), dim3((unsigned)blocks), dim3(64 * WPB), 0, st, args);
-  return hipGetLastError();
-}
-
-template <class C>
-static hipError_t launch_br_cfg(const BlindRotateArgs& a, int wpb, long num_cus, hipStream_t st) {
-  switch (wpb) {
-    case 1: return launch_br<C, 1>(a, 1L << 40, st);
-    case 2: return launch_br<C, 2>(a, 1L << 40, st);
-    case 4: return launch_br<C, 4>(a, 1L << 40, st);
-    default: return launch_br<C, 8>(a, num_cus, st);   // 152 KB LDS: exactly one workgroup per CU
-  }
-}
-
-hipError_t launch_blind_rotate(int cfg, const BlindRotateArgs& a, int wpb, int num_cus, hipStream_t st) {
-  if (a.B <= 0) return hipSuccess;
-#if !defined(RS_STAMPS)
-  // latency form: several waves per ciphertext while the batch cannot fill the chip by itself
-  if (!getenv("RS_NO_COOP")) {
-    if (cfg == 1 && a.B <= num_cus) {
-      hipLaunchKernelGGL((blind_rotate_coop_kernel<CfgRedsecV2, 4>), dim3((unsigned)a.B), dim3(256), 0, st, a);
-      return hipGetLastError();
-    }
-    if (a.B <= 2L * num_cus) {
-      if (cfg == 0) hipLaunchKernelGGL((blind_rotate_coop_kernel<CfgDefault128, 2>), dim3((unsigned)a.B), dim3(128), 0, st, a);
-      else hipLaunchKernelGGL((blind_rotate_coop_kernel<CfgRedsecV2, 2>), dim3((unsigned)a.B), dim3(128), 0, st, a);
-      return hipGetLastError();
-    }
-  }
-#endif
-  return cfg == 0 ? launch_br_cfg<CfgDefault128>(a, wpb, num_cus, st) : launch_br_cfg<CfgRedsecV2>(a, wpb, num_cus, st);
-}
-
-hipError_t launch_bk_transform(int cfg, const int32_t* bk, double* bk_ntt, const double* tw, Field f, double ninv, long n_polys,
-                               hipStream_t st) {
-  constexpr int WPB = 4;
-  const long blocks = (n_polys + WPB - 1) / WPB;
-  if (cfg == 0)
-    hipLaunchKernelGGL((bk_transform_kernel<CfgDefault128, WPB>), dim3((unsigned)blocks), dim3(64 * WPB), 0, st, bk, bk_ntt, tw, f, ninv, n_polys);
-  else
-    hipLaunchKernelGGL((bk_transform_kernel<CfgRedsecV2, WPB>), dim3((unsigned)blocks), dim3(64 * WPB), 0, st, bk, bk_ntt, tw, f, ninv, n_polys);
-  return hipGetLastError();
-}
-
 hipError_t launch_keyswitch(const KeyswitchArgs& a, hipStream_t st) {
   if (a.B <= 0) return hipSuccess;
   dim3 grid((unsigned)((a.B + KS_TILE_THREADS - 1) / KS_TILE_THREADS), (unsigned)((a.W + KS_CH - 1) / KS_CH), 1);
@@ -792,17 +300,6 @@ hipError_t launch_keyswitch(const KeyswitchArgs& a, hipStream_t st) {
   } else {
     hipLaunchKernelGGL(keyswitch_kernel, dim3((unsigned)a.B), dim3(KS_THREADS), 0, st, a);  // generic gather form
   }
-  return hipGetLastError();
-}
-
-hipError_t launch_polymul(int cfg, const int32_t* a_small, const int32_t* b_torus, int32_t* out, const double* tw, Field f,
-                          double ninv, long count, hipStream_t st) {
-  constexpr int WPB = 4;
-  const long blocks = (count + WPB - 1) / WPB;
-  if (cfg == 0)
-    hipLaunchKernelGGL((polymul_kernel<CfgDefault128, WPB>), dim3((unsigned)blocks), dim3(64 * WPB), 0, st, a_small, b_torus, out, tw, f, ninv, count);
-  else
-    hipLaunchKernelGGL((polymul_kernel<CfgRedsecV2, WPB>), dim3((unsigned)blocks), dim3(64 * WPB), 0, st, a_small, b_torus, out, tw, f, ninv, count);
   return hipGetLastError();
 }
 

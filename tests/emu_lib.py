@@ -46,6 +46,25 @@ def forward(cfg, poly):
     return out
 
 
+def polymul_fft(a, b):
+    a = np.ascontiguousarray(a, np.int32); b = np.ascontiguousarray(b, np.int32)
+    out = np.zeros(1024, np.int32)
+    dev = C.c_double(0)
+    assert lib().rs_emu_polymul_fft(_p(a), _p(b), _p(out), C.byref(dev)) == 0
+    return out, dev.value
+
+
+def blind_rotate_fft(cfg, n, in0, in1, c0, c1, bconst, mu, bk, steps=-1):
+    in0 = np.ascontiguousarray(in0, np.int32)
+    in1 = None if in1 is None else np.ascontiguousarray(in1, np.int32)
+    u = np.zeros(1025, np.int32); acc = np.zeros(2048, np.int32)
+    dev = C.c_double(0)
+    rc = lib().rs_emu_blind_rotate_fft(cfg, n, _p(in0), _p(in1), int(c0), int(c1), int(bconst), int(mu), _p(bk), _p(u), _p(acc), steps,
+                                       C.byref(dev))
+    assert rc == 0
+    return u, acc, dev.value
+
+
 def forward_digits(cfg, coef, q):
     coef = np.ascontiguousarray(coef, np.int32)
     out = np.zeros(1024, np.float64)

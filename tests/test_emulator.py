@@ -104,3 +104,31 @@ def test_blind_rotate_sign_mu_4096(toy_redsec):
     for i in range(3):
         u, _ = emu_lib.blind_rotate(1, ks.p.n, ct[i], None, 1, 0, 0, mu, ks.bk)
         assert np.array_equal(u, ref[i])
+
+
+@pytest.mark.parametrize("half", [64, 4])
+def test_fft_mode_polymul_is_exact_after_rounding(half):
+    """rs_fft.h: the folded complex FFT, rounded, equals the exact negacyclic product; the distance
+    to the nearest integer before rounding stays orders of magnitude below 1/2 -- also for inputs of
+    the largest possible magnitude."""
+    rng = np.random.default_rng(half)
+    cases = [(rng.integers(-half, half, 1024), rng.integers(-2**31, 2**31, 1024)) for _ in range(8)]
+    cases.append((np.full(1024, -half), np.full(1024, -2**31)))
+    cases.append((np.where(np.arange(1024) % 2 == 0, -half, half - 1), np.where(np.arange(1024) % 3 == 0, -2**31, 2**31 - 1)))
+    for a, b in cases:
+        a = a.astype(np.int32); b = b.astype(np.int32)
+        out, dev = emu_lib.polymul_fft(a, b)
+        assert np.array_equal(out, ol.negacyclic_mul(a, b, "schoolbook"))
+        assert dev < 0.1
+
+
+@pytest.mark.parametrize("cfg,fixture", [(0, "toy_default"), (1, "toy_redsec")])
+def test_fft_mode_blind_rotate_matches_exact_oracle(cfg, fixture, request):
+    ks, ctx = request.getfixturevalue(fixture)
+    mu = ol.to_torus(1, 8)
+    ct = ks.encrypt([mu, -mu, mu, -mu], ALPHA, 21)
+    ref = ctx.bootstrap_wo_ks(ct, mu)
+    for i in range(4):
+        u, _, dev = emu_lib.blind_rotate_fft(cfg, ks.p.n, ct[i], None, 1, 0, 0, mu, ks.bk)
+        assert np.array_equal(u, ref[i])
+        assert dev < 0.05

@@ -11,6 +11,9 @@ ALPHA = 2.0 ** -15
 ALL_GATES = ["NAND", "OR", "AND", "NOR", "XOR", "XNOR", "ANDNY", "ANDYN", "ORNY", "ORYN"]
 
 
+_BACKENDS = []
+
+
 def _backend(ks, name):
     import torch
     import redsec_amd
@@ -18,7 +21,22 @@ def _backend(ks, name):
     p = redsec_amd.params(name, n=ks.p.n)
     be = redsec_amd.Backend(p, device=0)
     be.load_keys(ks.bk, ks.ksk)
+    _BACKENDS.append(be)
     return be
+
+
+@pytest.fixture(autouse=True, params=["fft", "exact"])
+def arith_mode(request):
+    """Every parity test runs twice: in the FFT mode (default; exact after rounding, checked against the
+    SAME exact oracle) and in the guaranteed-exact NTT mode. After an FFT-mode test the rounding
+    certificate must be far below 1/2."""
+    for be in _BACKENDS:
+        be.set_mode(request.param)
+        be.rounding_certificate(reset=True)
+    yield request.param
+    if request.param == "fft":
+        for be in _BACKENDS:
+            assert be.rounding_certificate(reset=True) < 0.2
 
 
 @pytest.fixture(scope="module")
@@ -107,7 +125,7 @@ def test_keyswitch_tile_boundaries(which, fix, request):
         assert np.array_equal(be.keyswitch(_dev(u)).cpu().numpy(), ctx.keyswitch(u)), B
 
 
-def test_generic_keyswitch_shape():
+def test_generic_keyswitch_shape(arith_mode):
     """ks_t = 6 is not one of the tiled instantiations: the generic gather kernel must agree too."""
     import redsec_amd
     p = ol.params("toy_ks6")
@@ -117,6 +135,7 @@ def test_generic_keyswitch_shape():
     rp.ks_t = 6
     be = redsec_amd.Backend(rp, device=0)
     be.load_keys(ks.bk, ks.ksk)
+    be.set_mode(arith_mode)
     _, ca = _bits(ks, 19, 1)
     _, cb = _bits(ks, 19, 2)
     assert np.array_equal(be.gate("XNOR", _dev(ca), _dev(cb)).cpu().numpy(), ctx.gate_batch("XNOR", ca, cb))
@@ -221,7 +240,6 @@ def test_output_noise_matches_cggi_theory(be_full_default, full_default):
     ph = ks.phase(out).astype(np.float64) / 2.0**32
     ideal = np.where((ba & bb) == 1, 0.125, -0.125)
     err = ph - ideal
-    assert abs(err.mean()) < 5e-4
     Bg = 1 << p.bk_Bgbit
     var_br = p.n * 2 * p.bk_l * p.N * (Bg * Bg / 12.0) * p.bk_stdev ** 2          # digits ~ uniform in [-Bg/2, Bg/2)
     var_br += p.n * (1 + p.N / 2.0) * (2.0 ** -(p.bk_l * p.bk_Bgbit + 1)) ** 2 / 3     # gadget rounding
@@ -229,5 +247,8 @@ def test_output_noise_matches_cggi_theory(be_full_default, full_default):
     var_ks = p.N * p.ks_t * (1 - 1.0 / base) * p.lwe_stdev ** 2                       # rows actually subtracted
     var_ks += p.N / 2.0 * (2.0 ** -(p.ks_t * p.ks_basebit + 1)) ** 2 / 3               # keyswitch rounding
     theory = np.sqrt(var_br + var_ks)
-    measured = err.std()
+    # RMS, not std: with ONE key the keyswitch rows' noises are fixed numbers, so part of the predicted
+    # variance shows up as a key-dependent offset common to all ciphertexts
+    measured = np.sqrt(np.mean(err ** 2))
     assert 0.5 * theory < measured < 2.0 * theory, (measured, theory)
+    assert abs(err.mean()) < 2.0 * theory
