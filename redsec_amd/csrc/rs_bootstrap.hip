@@ -44,11 +44,15 @@ __device__ __forceinline__ void stage_tables(double* s_tw, const double* tw_g, i
 template <class C>
 struct XfNtt {
   using Cfg = C;
-  static constexpr int kTableDoubles = kTwTotal;
+  static constexpr int kTableDoubles = kTwTotal;   // staged in LDS
   static constexpr bool kCertificate = false;
+  static constexpr bool kSplitKeyLoads = false;   // whole key row prefetched across the transform
+  struct State { const double* tw; };
+  __device__ static __forceinline__ void init(State& st, int, const double* tw_lds, const double*) { st.tw = tw_lds; }
 
   __device__ static __forceinline__ void fwd_digits(int lane, double (&x)[kRegs], const int32_t (&d)[kRegs], int q, uint32_t offset,
-                                                    const double* tw, double* buf, const Field& f) {
+                                                    const State& st, double* buf, const Field& f) {
+    const double* tw = st.tw;
     fwd_F1_digits<C>(lane, x, d, q, offset, tw, buf, f);
     wave_lds_sync();
     fwd_F2<C>(lane, x, tw, buf, f);
@@ -58,7 +62,8 @@ struct XfNtt {
     fwd_F4<C>(lane, x, tw, buf, f);
     wave_lds_sync();
   }
-  __device__ static __forceinline__ void fwd_generic(int lane, double (&x)[kRegs], const double* tw, double* buf, const Field& f) {
+  __device__ static __forceinline__ void fwd_generic(int lane, double (&x)[kRegs], const State& st, double* buf, const Field& f) {
+    const double* tw = st.tw;
     fwd_F1<C>(lane, x, tw, buf, f);
     wave_lds_sync();
     fwd_F2<C>(lane, x, tw, buf, f);
@@ -77,8 +82,20 @@ struct XfNtt {
       dst[v * 64 + lane] = make_double2(a, b);
     }
   }
+  // multiply-accumulate against key entries v0 .. v0+3 of both columns
   __device__ static __forceinline__ void mac(double (&s0)[kRegs], double (&s1)[kRegs], const double (&x)[kRegs],
-                                             const double2 (&w0)[8], const double2 (&w1)[8], const Field& f) {
+                                             const double2 (&w0)[4], const double2 (&w1)[4], int v0, const Field& f) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int v = v0 + k;
+      s0[2 * v] += f_mulmod(x[2 * v], w0[k].x, f);
+      s0[2 * v + 1] += f_mulmod(x[2 * v + 1], w0[k].y, f);
+      s1[2 * v] += f_mulmod(x[2 * v], w1[k].x, f);
+      s1[2 * v + 1] += f_mulmod(x[2 * v + 1], w1[k].y, f);
+    }
+  }
+  __device__ static __forceinline__ void mac8(double (&s0)[kRegs], double (&s1)[kRegs], const double (&x)[kRegs],
+                                              const double2 (&w0)[8], const double2 (&w1)[8], const Field& f) {
 #pragma unroll
     for (int v = 0; v < 8; ++v) {
       s0[2 * v] += f_mulmod(x[2 * v], w0[v].x, f);
@@ -94,8 +111,8 @@ struct XfNtt {
     }
   }
   __device__ static __forceinline__ double partial(double v, const Field& f) { return f_reduce(v, f); }
-  __device__ static __forceinline__ void inverse(int lane, double (&x)[kRegs], const double* tw, double* buf, const Field& f) {
-    const double* twi = tw + kN;
+  __device__ static __forceinline__ void inverse(int lane, double (&x)[kRegs], const State& st, double* buf, const Field& f) {
+    const double* twi = st.tw + kN;
     inv_I1<C>(lane, x, twi, buf, f);
     wave_lds_sync();
     inv_I2<C>(lane, x, twi, buf, f);
@@ -111,24 +128,30 @@ struct XfNtt {
 template <class C>
 struct XfFft {
   using Cfg = C;
-  static constexpr int kTableDoubles = kFftTwDoubles;
+  static constexpr int kTableDoubles = kFftTwDoubles;   // stage-transposed complex table staged in LDS (8 KB)
   static constexpr bool kCertificate = true;
+  static constexpr bool kSplitKeyLoads = true;    // second half of the key row fetched after the transform
+  // Twiddles are read from the LDS table at every use: keeping the 21 complex values of a lane in
+  // registers (FftTw) spilled 250 B/lane to scratch at the 256-VGPR budget and cost 40 % (scratch
+  // reloads share vmcnt with the in-flight key-row loads).
+  using State = FftTwTable;
+  __device__ static __forceinline__ void init(State& st, int lane, const double* tw_lds, const double*) { st.tw = tw_lds; st.lane = lane; }
 
-  __device__ static __forceinline__ void fwd_generic(int lane, double (&x)[kRegs], const double* tw, double* buf, const Field&) {
-    ffwd_F1(lane, x, tw, buf);
+  __device__ static __forceinline__ void fwd_generic(int lane, double (&x)[kRegs], const State& st, double* buf, const Field&) {
+    ffwd_F1(lane, x, st, buf);
     wave_lds_sync();
-    ffwd_F2(lane, x, tw, buf);
+    ffwd_F2(lane, x, st, buf);
     wave_lds_sync();
     ffwd_F3(lane, x, buf);
     wave_lds_sync();
-    ffwd_F4(lane, x, tw, buf);
+    ffwd_F4(lane, x, st, buf);
     wave_lds_sync();
   }
   __device__ static __forceinline__ void fwd_digits(int lane, double (&x)[kRegs], const int32_t (&d)[kRegs], int q, uint32_t offset,
-                                                    const double* tw, double* buf, const Field& f) {
+                                                    const State& st, double* buf, const Field& f) {
 #pragma unroll
     for (int r = 0; r < kRegs; ++r) x[r] = (double)gadget_digit<C>(d[r], q, offset);
-    fwd_generic(lane, x, tw, buf, f);
+    fwd_generic(lane, x, st, buf, f);
   }
   // key values scaled by 1/M (exact power of two); stored as (re, im) of position 8 lane + v
   __device__ static __forceinline__ void key_store(double2* dst, int lane, const double (&x)[kRegs], double, const Field&) {
@@ -136,7 +159,16 @@ struct XfFft {
     for (int v = 0; v < 8; ++v) dst[v * 64 + lane] = make_double2(x[v] * (1.0 / kM), x[v + 8] * (1.0 / kM));
   }
   __device__ static __forceinline__ void mac(double (&s0)[kRegs], double (&s1)[kRegs], const double (&x)[kRegs],
-                                             const double2 (&w0)[8], const double2 (&w1)[8], const Field&) {
+                                             const double2 (&w0)[4], const double2 (&w1)[4], int v0, const Field&) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int v = v0 + k;
+      fft_cmac(s0[v], s0[v + 8], x[v], x[v + 8], w0[k].x, w0[k].y);
+      fft_cmac(s1[v], s1[v + 8], x[v], x[v + 8], w1[k].x, w1[k].y);
+    }
+  }
+  __device__ static __forceinline__ void mac8(double (&s0)[kRegs], double (&s1)[kRegs], const double (&x)[kRegs],
+                                              const double2 (&w0)[8], const double2 (&w1)[8], const Field&) {
 #pragma unroll
     for (int v = 0; v < 8; ++v) {
       fft_cmac(s0[v], s0[v + 8], x[v], x[v + 8], w0[v].x, w0[v].y);
@@ -145,14 +177,14 @@ struct XfFft {
   }
   __device__ static __forceinline__ void mid(double (&)[kRegs], double (&)[kRegs], const Field&) {}
   __device__ static __forceinline__ double partial(double v, const Field&) { return v; }
-  __device__ static __forceinline__ void inverse(int lane, double (&x)[kRegs], const double* tw, double* buf, const Field&) {
-    finv_I1(lane, x, tw, buf);
+  __device__ static __forceinline__ void inverse(int lane, double (&x)[kRegs], const State& st, double* buf, const Field&) {
+    finv_I1(lane, x, st, buf);
     wave_lds_sync();
-    finv_I2(lane, x, tw, buf);
+    finv_I2(lane, x, st, buf);
     wave_lds_sync();
     finv_I3(lane, x, buf);
     wave_lds_sync();
-    finv_I4(lane, x, tw, buf);
+    finv_I4(lane, x, st, buf);
     wave_lds_sync();
   }
   __device__ static __forceinline__ int32_t to_torus(double v, double& dev) { return fft_round_torus32(v, dev); }
@@ -177,18 +209,20 @@ __device__ __forceinline__ void publish_certificate(double dev, unsigned long lo
 template <class Xf, int WPB>
 __global__ __launch_bounds__(64 * WPB) void bk_transform_kernel(const int32_t* __restrict__ bk, double* __restrict__ bk_x,
                                                                  const double* __restrict__ tw_g, Field f, double scale, long n_polys) {
-  __shared__ double s_tw[Xf::kTableDoubles];
+  __shared__ double s_tw[Xf::kTableDoubles + 1];
   __shared__ double s_buf[WPB][kBufDoubles];
   stage_tables(s_tw, tw_g, 64 * WPB, Xf::kTableDoubles);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const long poly = (long)blockIdx.x * WPB + wave;
   if (poly >= n_polys) return;
+  typename Xf::State st;
+  Xf::init(st, lane, s_tw, tw_g);
   double x[kRegs];
   const int32_t* src = bk + poly * kN;
 #pragma unroll
   for (int r = 0; r < kRegs; ++r) x[r] = (double)src[lane + 64 * r];
-  Xf::fwd_generic(lane, x, s_tw, s_buf[wave], f);
+  Xf::fwd_generic(lane, x, st, s_buf[wave], f);
   Xf::key_store(reinterpret_cast<double2*>(bk_x + poly * kN), lane, x, scale, f);
 }
 
@@ -198,7 +232,7 @@ __global__ __launch_bounds__(64 * WPB) void bk_transform_kernel(const int32_t* _
 template <class Xf, int WPB>
 __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs a) {
   using C = typename Xf::Cfg;
-  __shared__ double s_tw[Xf::kTableDoubles];
+  __shared__ double s_tw[Xf::kTableDoubles + 1];
   __shared__ double s_buf[WPB][kBufDoubles];
   __shared__ int32_t s_acc[WPB][2][kN];
   stage_tables(s_tw, a.tw, 64 * WPB, Xf::kTableDoubles);
@@ -217,7 +251,8 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs 
   double* buf = s_buf[wave];
   int32_t* acc0 = s_acc[wave][0];
   int32_t* acc1 = s_acc[wave][1];
-  const double* tw = s_tw;
+  typename Xf::State tw;
+  Xf::init(tw, lane, s_tw, a.tw);
   const int n = a.n;
   constexpr uint32_t offset = gadget_offset<C>();
   constexpr int KPL = 2 * C::L;
@@ -263,12 +298,25 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs 
           const int row = comp * C::L + q;
           const double2* bp0 = reinterpret_cast<const double2*>(bk_i + (size_t)(row * 2) * kN);
           const double2* bp1 = bp0 + kN / 2;
-          double2 w0[8], w1[8];
-#pragma unroll
-          for (int v = 0; v < 8; ++v) { w0[v] = bp0[v * 64 + lane]; w1[v] = bp1[v * 64 + lane]; }
           double x[kRegs];
-          Xf::fwd_digits(lane, x, d, q, offset, tw, buf, f);
-          Xf::mac(s0, s1, x, w0, w1, f);
+          if constexpr (Xf::kSplitKeyLoads) {
+            // first half of the key row prefetched across the transform, second half fetched after it
+            double2 wa0[4], wa1[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { wa0[v] = bp0[v * 64 + lane]; wa1[v] = bp1[v * 64 + lane]; }
+            Xf::fwd_digits(lane, x, d, q, offset, tw, buf, f);
+            double2 wb0[4], wb1[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { wb0[v] = bp0[(v + 4) * 64 + lane]; wb1[v] = bp1[(v + 4) * 64 + lane]; }
+            Xf::mac(s0, s1, x, wa0, wa1, 0, f);
+            Xf::mac(s0, s1, x, wb0, wb1, 4, f);
+          } else {
+            double2 w0[8], w1[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) { w0[v] = bp0[v * 64 + lane]; w1[v] = bp1[v * 64 + lane]; }
+            Xf::fwd_digits(lane, x, d, q, offset, tw, buf, f);
+            Xf::mac8(s0, s1, x, w0, w1, f);
+          }
         }
         if (comp == 0) Xf::mid(s0, s1, f);
       }
@@ -321,7 +369,7 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateAr
   constexpr int KPL = 2 * C::L;
   constexpr int R = KPL / G;
   static_assert(KPL % G == 0 && G % 2 == 0, "waves must split the digit rows evenly within a component");
-  __shared__ double s_tw[Xf::kTableDoubles];
+  __shared__ double s_tw[Xf::kTableDoubles + 1];
   __shared__ double s_buf[G][kBufDoubles];
   __shared__ double s_part[G][2][kN];
   __shared__ int32_t s_acc[2][kN];
@@ -331,7 +379,8 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateAr
   const long ct = blockIdx.x;
   const Field f = a.f;
   double* buf = s_buf[wave];
-  const double* tw = s_tw;
+  typename Xf::State tw;
+  Xf::init(tw, lane, s_tw, a.tw);
   const int32_t* row0 = a.in0 + ct * a.W;
   const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
   const int n = a.n;
@@ -370,12 +419,25 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateAr
       const int q = row - comp * C::L;
       const double2* bp0 = reinterpret_cast<const double2*>(bk_i + (size_t)(row * 2) * kN);
       const double2* bp1 = bp0 + kN / 2;
-      double2 w0[8], w1[8];
-#pragma unroll
-      for (int v = 0; v < 8; ++v) { w0[v] = bp0[v * 64 + lane]; w1[v] = bp1[v * 64 + lane]; }
       double x[kRegs];
-      Xf::fwd_digits(lane, x, d, q, offset, tw, buf, f);
-      Xf::mac(s0, s1, x, w0, w1, f);
+      if constexpr (Xf::kSplitKeyLoads) {
+        // first half of the key row prefetched across the transform, second half fetched after it
+        double2 wa0[4], wa1[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { wa0[v] = bp0[v * 64 + lane]; wa1[v] = bp1[v * 64 + lane]; }
+        Xf::fwd_digits(lane, x, d, q, offset, tw, buf, f);
+        double2 wb0[4], wb1[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { wb0[v] = bp0[(v + 4) * 64 + lane]; wb1[v] = bp1[(v + 4) * 64 + lane]; }
+        Xf::mac(s0, s1, x, wa0, wa1, 0, f);
+        Xf::mac(s0, s1, x, wb0, wb1, 4, f);
+      } else {
+        double2 w0[8], w1[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) { w0[v] = bp0[v * 64 + lane]; w1[v] = bp1[v * 64 + lane]; }
+        Xf::fwd_digits(lane, x, d, q, offset, tw, buf, f);
+        Xf::mac8(s0, s1, x, w0, w1, f);
+      }
     }
     // partial sums exchanged through LDS: position u*64 + lane is conflict-free
 #pragma unroll
@@ -422,7 +484,7 @@ __global__ __launch_bounds__(64 * WPB) void polymul_kernel(const int32_t* __rest
                                                             int32_t* __restrict__ out, double* __restrict__ scratch,
                                                             const double* __restrict__ tw_g, Field f, double scale, long count,
                                                             unsigned long long* dev_flag) {
-  __shared__ double s_tw[Xf::kTableDoubles];
+  __shared__ double s_tw[Xf::kTableDoubles + 1];
   __shared__ double s_buf[WPB][kBufDoubles];
   stage_tables(s_tw, tw_g, 64 * WPB, Xf::kTableDoubles);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -430,6 +492,8 @@ __global__ __launch_bounds__(64 * WPB) void polymul_kernel(const int32_t* __rest
   const long idx = (long)blockIdx.x * WPB + wave;
   if (idx >= count) return;
   double* buf = s_buf[wave];
+  typename Xf::State st;
+  Xf::init(st, lane, s_tw, tw_g);
   double xa[kRegs], xb[kRegs];
 #pragma unroll
   for (int r = 0; r < kRegs; ++r) {
@@ -437,18 +501,19 @@ __global__ __launch_bounds__(64 * WPB) void polymul_kernel(const int32_t* __rest
     xb[r] = (double)b_torus[idx * kN + lane + 64 * r];
   }
   // key side exactly as bk_transform_kernel: through global memory in the key layout
-  Xf::fwd_generic(lane, xb, s_tw, buf, f);
+  Xf::fwd_generic(lane, xb, st, buf, f);
   double2* key = reinterpret_cast<double2*>(scratch + idx * kN);
   Xf::key_store(key, lane, xb, scale, f);
-  double2 w0[8], w1[8];
+  double2 wa[4], wb[4];
 #pragma unroll
-  for (int v = 0; v < 8; ++v) { w0[v] = key[v * 64 + lane]; w1[v] = w0[v]; }
-  Xf::fwd_generic(lane, xa, s_tw, buf, f);
+  for (int v = 0; v < 4; ++v) { wa[v] = key[v * 64 + lane]; wb[v] = key[(v + 4) * 64 + lane]; }
+  Xf::fwd_generic(lane, xa, st, buf, f);
   double s0[kRegs], s1[kRegs];
 #pragma unroll
   for (int u = 0; u < kRegs; ++u) { s0[u] = 0.0; s1[u] = 0.0; }
-  Xf::mac(s0, s1, xa, w0, w1, f);
-  Xf::inverse(lane, s0, s_tw, buf, f);
+  Xf::mac(s0, s1, xa, wa, wa, 0, f);
+  Xf::mac(s0, s1, xa, wb, wb, 4, f);
+  Xf::inverse(lane, s0, st, buf, f);
   double dev = 0.0;
 #pragma unroll
   for (int r = 0; r < kRegs; ++r) out[idx * kN + lane + 64 * r] = Xf::to_torus(s0[r], dev);

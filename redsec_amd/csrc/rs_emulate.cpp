@@ -162,16 +162,20 @@ int emu_blind_rotate(int n, const int32_t* in0, const int32_t* in1, int32_t c0, 
 // FFT mode (rs_fft.h)
 // ---------------------------------------------------------------------------------------------
 void emu_fft_forward(Wave& w, const double* tw, double* buf) {
-  for (int l = 0; l < kLanes; ++l) rs::ffwd_F1(l, w.x[l], tw, buf);
-  for (int l = 0; l < kLanes; ++l) rs::ffwd_F2(l, w.x[l], tw, buf);
+  static rs::FftTw t[kLanes];
+  for (int l = 0; l < kLanes; ++l) rs::fft_tw_load(t[l], l, tw);
+  for (int l = 0; l < kLanes; ++l) rs::ffwd_F1(l, w.x[l], t[l], buf);
+  for (int l = 0; l < kLanes; ++l) rs::ffwd_F2(l, w.x[l], t[l], buf);
   for (int l = 0; l < kLanes; ++l) rs::ffwd_F3(l, w.x[l], buf);
-  for (int l = 0; l < kLanes; ++l) rs::ffwd_F4(l, w.x[l], tw, buf);
+  for (int l = 0; l < kLanes; ++l) rs::ffwd_F4(l, w.x[l], t[l], buf);
 }
 void emu_fft_inverse(Wave& w, const double* tw, double* buf) {
-  for (int l = 0; l < kLanes; ++l) rs::finv_I1(l, w.x[l], tw, buf);
-  for (int l = 0; l < kLanes; ++l) rs::finv_I2(l, w.x[l], tw, buf);
+  static rs::FftTw t[kLanes];
+  for (int l = 0; l < kLanes; ++l) rs::fft_tw_load(t[l], l, tw);
+  for (int l = 0; l < kLanes; ++l) rs::finv_I1(l, w.x[l], t[l], buf);
+  for (int l = 0; l < kLanes; ++l) rs::finv_I2(l, w.x[l], t[l], buf);
   for (int l = 0; l < kLanes; ++l) rs::finv_I3(l, w.x[l], buf);
-  for (int l = 0; l < kLanes; ++l) rs::finv_I4(l, w.x[l], tw, buf);
+  for (int l = 0; l < kLanes; ++l) rs::finv_I4(l, w.x[l], t[l], buf);
 }
 // key polynomial -> [v][lane][2] = (re, im) of transform position 8*lane + v, scaled by 1/M
 void emu_fft_key_transform(const int32_t* poly, double* dst, const double* tw, double* buf) {

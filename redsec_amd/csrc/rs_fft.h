@@ -66,21 +66,75 @@ RS_HD void fft_bfly_inv(double& xr, double& xi, double& yr, double& yi, double w
   yi = __builtin_fma(-wi, dr, wr * di);
 }
 
-// x[e] = re, x[e+8] = im of the lane's e-th complex value. tw: interleaved complex table.
-RS_HD void fft_stage_fwd(double (&x)[kRegs], int half, const double* tw, int tw_base, int shift, int stride) {
+// The twiddles depend only on (stage, lane, register index), never on the polynomial, so a wavefront
+// loads them ONCE: 7 wave-uniform ones for stages 0-2 and 14 per-lane ones for stages 3-8
+// (index of entry (stage, e'): 3 -> 0 ; 4 -> 1 + e' ; 5 -> 3 + e' ; 6 -> 7 ; 7 -> 8 + e' ; 8 -> 10 + e').
+// The inverse transform uses the conjugates of the same values.
+struct FftTw {
+  double ur[7], ui[7];     // table entries 1..7 (stages 0, 1, 2)
+  double lr[14], li[14];   // per-lane entries of stages 3..8
+};
+
+RS_HD void fft_tw_load(FftTw& t, int lane, const double* tw) {
 #pragma unroll
-  for (int e = 0; e < kCRegs; ++e) {
-    if (e & half) continue;
-    const int t = tw_base + (e >> shift) * stride;
-    fft_bfly_fwd(x[e], x[e + 8], x[e + half], x[e + half + 8], tw[2 * t], tw[2 * t + 1]);
+  for (int k = 0; k < 7; ++k) { t.ur[k] = tw[2 * (k + 1)]; t.ui[k] = tw[2 * (k + 1) + 1]; }
+  const int b = lane >> 3;
+  int k = 0;
+#pragma unroll
+  for (int s = 3; s < 9; ++s) {
+    const int per = 1 << ((s - 3) % 3);           // 1, 2, 4 entries per lane
+#pragma unroll
+    for (int e = 0; e < per; ++e) {
+      const int pos = (s < 6) ? (1 << s) + e * 8 + b : (1 << s) + e * 64 + lane;   // stage-transposed table (ftw_pos)
+      t.lr[k] = tw[2 * pos];
+      t.li[k] = tw[2 * pos + 1];
+      ++k;
+    }
   }
 }
-RS_HD void fft_stage_inv(double (&x)[kRegs], int half, const double* tw, int tw_base, int shift, int stride) {
+
+template <int S>
+RS_HD void fft_tw_get(const FftTw& t, int k, double& wr, double& wi) {
+  constexpr int lbase = (S < 3) ? 0 : (S - 3 < 3 ? (S == 3 ? 0 : (S == 4 ? 1 : 3)) : (S == 6 ? 7 : (S == 7 ? 8 : 10)));
+  wr = (S < 3) ? t.ur[(1 << S) - 1 + k] : t.lr[lbase + k];
+  wi = (S < 3) ? t.ui[(1 << S) - 1 + k] : t.li[lbase + k];
+}
+
+// Twiddle source reading the stage-transposed table (in LDS on the device) at every use: costs 21
+// 16-byte LDS reads per transform but no registers. Same values, hence bit-identical results.
+struct FftTwTable {
+  const double* tw;
+  int lane;
+};
+template <int S>
+RS_HD void fft_tw_get(const FftTwTable& t, int k, double& wr, double& wi) {
+  const int pos = (S < 3) ? (1 << S) + k : (S < 6 ? (1 << S) + k * 8 + (t.lane >> 3) : (1 << S) + k * 64 + t.lane);
+  wr = t.tw[2 * pos];
+  wi = t.tw[2 * pos + 1];
+}
+
+// x[e] = re, x[e+8] = im of the lane's e-th complex value. Stage s in [0,9): pairs (e, e+half),
+// half = 4 >> (s % 3); twiddle index within the stage = e >> (3 - s % 3).
+template <int S, class TW>
+RS_HD void fft_stage_fwd(double (&x)[kRegs], const TW& t) {
+  constexpr int g = S % 3, half = 4 >> g, shift = 3 - g;
 #pragma unroll
   for (int e = 0; e < kCRegs; ++e) {
     if (e & half) continue;
-    const int t = tw_base + (e >> shift) * stride;
-    fft_bfly_inv(x[e], x[e + 8], x[e + half], x[e + half + 8], tw[2 * t], tw[2 * t + 1]);
+    double wr, wi;
+    fft_tw_get<S>(t, e >> shift, wr, wi);
+    fft_bfly_fwd(x[e], x[e + 8], x[e + half], x[e + half + 8], wr, wi);
+  }
+}
+template <int S, class TW>
+RS_HD void fft_stage_inv(double (&x)[kRegs], const TW& t) {
+  constexpr int g = S % 3, half = 4 >> g, shift = 3 - g;
+#pragma unroll
+  for (int e = 0; e < kCRegs; ++e) {
+    if (e & half) continue;
+    double wr, wi;
+    fft_tw_get<S>(t, e >> shift, wr, wi);
+    fft_bfly_inv(x[e], x[e + 8], x[e + half], x[e + half + 8], wr, wi);
   }
 }
 
@@ -88,18 +142,18 @@ RS_HD void fbuf_store(double* buf, int pos, double re, double im) { buf[2 * pos]
 RS_HD void fbuf_load(const double* buf, int pos, double& re, double& im) { re = buf[2 * pos]; im = buf[2 * pos + 1]; }
 
 // ---- forward: input x[r] = real coefficient L + 64 r (r < 16), i.e. already folded ----
-RS_HD void ffwd_F1(int lane, double (&x)[kRegs], const double* tw, double* buf) {
-#pragma unroll
-  for (int s = 0; s < 3; ++s) fft_stage_fwd(x, 4 >> s, tw, 1 << s, 3 - s, 1);
+template <class TW>
+RS_HD void ffwd_F1(int lane, double (&x)[kRegs], const TW& t, double* buf) {
+  fft_stage_fwd<0>(x, t); fft_stage_fwd<1>(x, t); fft_stage_fwd<2>(x, t);
 #pragma unroll
   for (int r = 0; r < kCRegs; ++r) fbuf_store(buf, fpos_t1(lane + 64 * r), x[r], x[r + 8]);
 }
-RS_HD void ffwd_F2(int lane, double (&x)[kRegs], const double* tw, const double* buf) {
+template <class TW>
+RS_HD void ffwd_F2(int lane, double (&x)[kRegs], const TW& t, const double* buf) {
   const int b = lane >> 3, q = lane & 7;
 #pragma unroll
   for (int s = 0; s < kCRegs; ++s) fbuf_load(buf, fpos_t1(64 * b + 8 * s + q), x[s], x[s + 8]);
-#pragma unroll
-  for (int s = 3; s < 6; ++s) fft_stage_fwd(x, 4 >> (s - 3), tw, (1 << s) + b, 6 - s, 8);
+  fft_stage_fwd<3>(x, t); fft_stage_fwd<4>(x, t); fft_stage_fwd<5>(x, t);
 }
 RS_HD void ffwd_F3(int lane, const double (&x)[kRegs], double* buf) {
   const int b = lane >> 3, q = lane & 7;
@@ -107,26 +161,26 @@ RS_HD void ffwd_F3(int lane, const double (&x)[kRegs], double* buf) {
   for (int s = 0; s < kCRegs; ++s) fbuf_store(buf, fpos_t2(64 * b + 8 * s + q), x[s], x[s + 8]);
 }
 // output: x[u] + i x[u+8] = transform value at position 8*lane + u
-RS_HD void ffwd_F4(int lane, double (&x)[kRegs], const double* tw, const double* buf) {
+template <class TW>
+RS_HD void ffwd_F4(int lane, double (&x)[kRegs], const TW& t, const double* buf) {
 #pragma unroll
   for (int u = 0; u < kCRegs; ++u) fbuf_load(buf, fpos_t2(8 * lane + u), x[u], x[u + 8]);
-#pragma unroll
-  for (int s = 6; s < 9; ++s) fft_stage_fwd(x, 4 >> (s - 6), tw, (1 << s) + lane, 9 - s, 64);
+  fft_stage_fwd<6>(x, t); fft_stage_fwd<7>(x, t); fft_stage_fwd<8>(x, t);
 }
 
 // ---- inverse (mirror) ----
-RS_HD void finv_I1(int lane, double (&x)[kRegs], const double* tw, double* buf) {
-#pragma unroll
-  for (int s = 8; s >= 6; --s) fft_stage_inv(x, 4 >> (s - 6), tw, (1 << s) + lane, 9 - s, 64);
+template <class TW>
+RS_HD void finv_I1(int lane, double (&x)[kRegs], const TW& t, double* buf) {
+  fft_stage_inv<8>(x, t); fft_stage_inv<7>(x, t); fft_stage_inv<6>(x, t);
 #pragma unroll
   for (int u = 0; u < kCRegs; ++u) fbuf_store(buf, fpos_t2(8 * lane + u), x[u], x[u + 8]);
 }
-RS_HD void finv_I2(int lane, double (&x)[kRegs], const double* tw, const double* buf) {
+template <class TW>
+RS_HD void finv_I2(int lane, double (&x)[kRegs], const TW& t, const double* buf) {
   const int b = lane >> 3, q = lane & 7;
 #pragma unroll
   for (int s = 0; s < kCRegs; ++s) fbuf_load(buf, fpos_t2(64 * b + 8 * s + q), x[s], x[s + 8]);
-#pragma unroll
-  for (int s = 5; s >= 3; --s) fft_stage_inv(x, 4 >> (s - 3), tw, (1 << s) + b, 6 - s, 8);
+  fft_stage_inv<5>(x, t); fft_stage_inv<4>(x, t); fft_stage_inv<3>(x, t);
 }
 RS_HD void finv_I3(int lane, const double (&x)[kRegs], double* buf) {
   const int b = lane >> 3, q = lane & 7;
@@ -134,11 +188,11 @@ RS_HD void finv_I3(int lane, const double (&x)[kRegs], double* buf) {
   for (int s = 0; s < kCRegs; ++s) fbuf_store(buf, fpos_t1(64 * b + 8 * s + q), x[s], x[s + 8]);
 }
 // output: x[r] = real coefficient L + 64 r of the product (r < 16), before rounding
-RS_HD void finv_I4(int lane, double (&x)[kRegs], const double* tw, const double* buf) {
+template <class TW>
+RS_HD void finv_I4(int lane, double (&x)[kRegs], const TW& t, const double* buf) {
 #pragma unroll
   for (int r = 0; r < kCRegs; ++r) fbuf_load(buf, fpos_t1(lane + 64 * r), x[r], x[r + 8]);
-#pragma unroll
-  for (int s = 2; s >= 0; --s) fft_stage_inv(x, 4 >> s, tw, 1 << s, 3 - s, 1);
+  fft_stage_inv<2>(x, t); fft_stage_inv<1>(x, t); fft_stage_inv<0>(x, t);
 }
 
 // pointwise complex multiply-accumulate: (sr, si) += (xr, xi) * (wr, wi)
