@@ -41,6 +41,17 @@ def fp64_ops_per_bootstrap(n, l, fwd_red, inv_red, fused_ops):
     return n * per_lane * 64
 
 
+def fp64_ops_per_bootstrap_fft(n, l):
+    """Same count for the FFT mode (folded 512-point complex FFT, 8 complex points per lane, 9 stages
+    of 4 butterflies): forward = 36 butterflies x 6 FMAs + 16 int->f64 conversions; pointwise = 2 columns
+    x 8 points x 4 FMAs per row; inverse = 36 butterflies x 8 ops + 16 x 4 for rounding to the torus and
+    the rounding certificate."""
+    fwd = 36 * 6 + 16
+    inv = 36 * 8 + 16 * 4
+    per_lane = 2 * l * (fwd + 2 * 8 * 4) + 2 * inv
+    return n * per_lane * 64
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -48,6 +59,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gates", type=int, default=65536, help="gates per rank per step")
     ap.add_argument("--params", default="default128", choices=["default128", "redsec_small_v2"])
+    ap.add_argument("--mode", default="fft", choices=["fft", "exact"],
+                    help="ring arithmetic of the blind rotation: fft = FP64 complex FFT (library default, exact after "
+                         "rounding, run-time certificate); exact = NTT over a 51-bit prime (exact by construction)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="gates timed on the CPU oracle (0 = skip)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xC0FFEE)
     args = ap.parse_args()
@@ -78,6 +92,7 @@ def main():
     sk = client.SecretKeySet(args.params, seed=args.seed)
     be = redsec_amd.Backend(redsec_amd.params(args.params), device=local_rank)
     be.load_keys(sk.bk, sk.ksk)
+    be.set_mode(args.mode)
     G = args.gates
     rng = np.random.default_rng(args.seed + 17 * rank)
     bits_a = rng.integers(0, 2, G)
@@ -129,6 +144,10 @@ def main():
     got = out.cpu().numpy()
     decrypt_ok = bool(np.array_equal(sk.decrypt_bits(got), 1 - (bits_a & bits_b)))
 
+    # FFT mode: largest distance of any inverse-transform output from an integer over the whole run
+    # (exactness needs < 0.5). None in the exact mode.
+    certificate = round(be.rounding_certificate(), 6) if args.mode == "fft" else None
+
     total_gates = G * world
     value = total_gates * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
@@ -149,7 +168,7 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
-            traffic = pmc.get("%s_%d" % (args.params, G), {}).get("traffic_bytes")
+            traffic = pmc.get("%s_%d_%s" % (args.params, G, args.mode), {}).get("traffic_bytes")
         except Exception:
             pass
         roofline = {"bound": "hbm", "kernel": "blind_rotate_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
@@ -157,11 +176,13 @@ def main():
                     "kernel_ms": round(last_br, 3), "algorithmic_bytes_per_launch": int(alg_bytes),
                     "resident_ciphertexts_per_key_sweep": R}
         fwd_red, inv_red, fused = (2, 3, 36) if p.bk_l == 3 else (0, 1, 48)
-        ops = fp64_ops_per_bootstrap(p.n, p.bk_l, fwd_red, inv_red, fused) * G
+        ops_per = fp64_ops_per_bootstrap_fft(p.n, p.bk_l) if args.mode == "fft" else \
+            fp64_ops_per_bootstrap(p.n, p.bk_l, fwd_red, inv_red, fused)
+        ops = ops_per * G
         valu = ops / (last_br * 1e-3) / 1e9
         roofline_valu = {"bound": "fp64-valu-issue", "achieved": round(valu, 1), "peak": round(FP64_VALU_PEAK_GOPS, 1),
                          "unit": "G fp64 lane-ops/s", "frac": round(valu / FP64_VALU_PEAK_GOPS, 4),
-                         "fp64_ops_per_bootstrap": fp64_ops_per_bootstrap(p.n, p.bk_l, fwd_red, inv_red, fused)}
+                         "fp64_ops_per_bootstrap": ops_per}
 
         # ---- CPU baseline + parity on a bounded sample of the same workload ----
         cpu = None
@@ -190,14 +211,15 @@ def main():
         line = {
             "metric": "gate bootstraps/sec (N=1024)", "value": round(value, 1), "unit": "bootstraps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 torus (fp64-carried exact NTT)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 torus; ring products in f64 (%s)" % ("complex FFT, exact after rounding" if args.mode == "fft" else "exact NTT mod a 51-bit prime"),
             "data": "synthetic",
             "config": {"workload": "%d independent bootstrapped NAND gates per GPU, %s (n=%d N=%d l=%d Bgbit=%d t=%d basebit=%d)"
                                    % (G, args.params, p.n, p.N, p.bk_l, p.bk_Bgbit, p.ks_t, p.ks_basebit),
-                       "gates_per_gpu": G, "params": args.params, "parallelism": "gate-sharded x%d, no data-path collective" % world},
+                       "gates_per_gpu": G, "params": args.params, "mode": args.mode, "parallelism": "gate-sharded x%d, no data-path collective" % world},
             "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu,
             "kernels_ms": {"blind_rotate": round(last_br, 3), "keyswitch": round(last_ks, 3)},
-            "checks": {"all_outputs_decrypt_to_nand": decrypt_ok, "bit_exact_vs_oracle_on_sample": parity},
+            "checks": {"all_outputs_decrypt_to_nand": decrypt_ok, "bit_exact_vs_oracle_on_sample": parity,
+                       "fft_rounding_certificate": certificate},
             "setup_s": round(setup_s, 1),
         }
         print(json.dumps(line), flush=True)

@@ -47,6 +47,7 @@ struct XfNtt {
   static constexpr int kTableDoubles = kTwTotal;   // staged in LDS
   static constexpr bool kCertificate = false;
   static constexpr bool kSplitKeyLoads = false;   // whole key row prefetched across the transform
+  static constexpr bool kWorkgroupForm = false;
   struct State { const double* tw; };
   __device__ static __forceinline__ void init(State& st, int, const double* tw_lds, const double*) { st.tw = tw_lds; }
 
@@ -122,6 +123,10 @@ struct XfNtt {
     inv_I4<C>(lane, x, twi, buf, f);
     wave_lds_sync();
   }
+  __device__ static __forceinline__ void inverse2(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const State& st, double* buf, const Field& f) {
+    inverse(lane, xa, st, buf, f);
+    inverse(lane, xb, st, buf, f);
+  }
   __device__ static __forceinline__ int32_t to_torus(double v, double&) { return f_to_torus32(v); }
 };
 
@@ -131,6 +136,7 @@ struct XfFft {
   static constexpr int kTableDoubles = kFftTwDoubles;   // stage-transposed complex table staged in LDS (8 KB)
   static constexpr bool kCertificate = true;
   static constexpr bool kSplitKeyLoads = true;    // second half of the key row fetched after the transform
+  static constexpr bool kWorkgroupForm = true;    // blind_rotate_wg_kernel available
   // Twiddles are read from the LDS table at every use: keeping the 21 complex values of a lane in
   // registers (FftTw) spilled 250 B/lane to scratch at the 256-VGPR budget and cost 40 % (scratch
   // reloads share vmcnt with the in-flight key-row loads).
@@ -187,7 +193,33 @@ struct XfFft {
     finv_I4(lane, x, st, buf);
     wave_lds_sync();
   }
+  // both accumulator columns at once: the two inverse transforms interleaved phase by phase
+  __device__ static __forceinline__ void inverse2(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const State& st, double* buf, const Field&) {
+    finv_pair<false>(lane, xa, xb, st, buf, [] { wave_lds_sync(); });
+  }
   __device__ static __forceinline__ int32_t to_torus(double v, double& dev) { return fft_round_torus32(v, dev); }
+
+  // workgroup kernel: planar exchanges through a half-size per-wave buffer
+  static constexpr int kWgBufDoubles = kPlaneDoubles;
+  __device__ static __forceinline__ void fwd_digits_wg(int lane, double (&x)[kRegs], const int32_t (&d)[kRegs], int q, uint32_t offset,
+                                                       const State& st, double* buf, const Field&) {
+#pragma unroll
+    for (int r = 0; r < kRegs; ++r) x[r] = (double)gadget_digit<C>(d[r], q, offset);
+    ffwd_planar(lane, x, st, buf, [] { wave_lds_sync(); });
+  }
+  __device__ static __forceinline__ void inverse_wg(int lane, double (&x)[kRegs], const State& st, double* buf, const Field&) {
+    finv_planar(lane, x, st, buf, [] { wave_lds_sync(); });
+  }
+  __device__ static __forceinline__ void digits(double (&x)[kRegs], const int32_t (&d)[kRegs], int q, uint32_t offset) {
+#pragma unroll
+    for (int r = 0; r < kRegs; ++r) x[r] = (double)gadget_digit<C>(d[r], q, offset);
+  }
+  __device__ static __forceinline__ void fwd_pair_wg(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const State& st, double* buf) {
+    ffwd_pair<true>(lane, xa, xb, st, buf, [] { wave_lds_sync(); });
+  }
+  __device__ static __forceinline__ void inverse_pair_wg(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const State& st, double* buf) {
+    finv_pair<true>(lane, xa, xb, st, buf, [] { wave_lds_sync(); });
+  }
 };
 
 // largest rounding distance of the wave -> device flag (positive doubles order like their bit patterns)
@@ -321,16 +353,11 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs 
         if (comp == 0) Xf::mid(s0, s1, f);
       }
 
-      Xf::inverse(lane, s0, tw, buf, f);
+      Xf::inverse2(lane, s0, s1, tw, buf, f);
 #pragma unroll
       for (int r = 0; r < kRegs; ++r) {
         const int j = lane + 64 * r;
         acc0[j] = (int32_t)((uint32_t)acc0[j] + (uint32_t)Xf::to_torus(s0[r], dev));
-      }
-      Xf::inverse(lane, s1, tw, buf, f);
-#pragma unroll
-      for (int r = 0; r < kRegs; ++r) {
-        const int j = lane + 64 * r;
         acc1[j] = (int32_t)((uint32_t)acc1[j] + (uint32_t)Xf::to_torus(s1[r], dev));
       }
       wave_lds_sync();
@@ -352,6 +379,186 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs 
     ct = first_dynamic + (long)nxt;
     if (ct >= a.B) break;
     wave_lds_sync();
+  }
+  if (Xf::kCertificate) publish_certificate(dev, a.dev_flag, lane);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Blind rotation, workgroup lock-step form (large batches). The per-wave kernel above makes EVERY
+// wavefront stream the whole transformed key by itself: at 150k bootstraps/s that is ~9.6 TB/s of
+// L2 -> CU reads with a 64 % L2 miss rate (waves drift apart, so a key row is rarely still in L2 for
+// the next wave), and both parameter sets stall at that same byte rate. Here the WPB waves of a
+// workgroup walk the CMUX chain of WPB different ciphertexts in lock step and share each key row
+// through LDS: every wave fetches 1/WPB of the row with direct global->LDS loads (no VGPRs), one
+// workgroup barrier per row publishes it, and the multiply-accumulate reads it with 16-byte LDS
+// reads. Rows go in pairs through a two-slot ring (see the loop) -- two barriers per pair.
+// Every wave executes every barrier: inactive waves (ragged last group) and identity CMUX steps
+// (bara == 0) only skip the arithmetic. Groups are assigned round-robin: all groups take the same
+// number of steps, so there is nothing to balance dynamically.
+// -------------------------------------------------------------------------------------------------
+// Direct global -> LDS load of 16 bytes per lane (1 KB per wavefront): the LDS destination is the
+// wave-uniform byte address in M0 plus lane * 16. Written as asm because hipcc puts a vmcnt(0) in front
+// of the next LDS read whenever it knows of a pending LDS-DMA, which would serialise the prefetch;
+// the kernel's own `s_waitcnt vmcnt(0)` + barrier orders the data instead.
+__device__ __forceinline__ void glds16(const double* gsrc_lane, const double* lds_wave_base) {
+  const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane(
+      (int)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_dst) : "memory");
+}
+
+template <class Xf, int WPB>
+__global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateArgs a) {
+  using C = typename Xf::Cfg;
+  constexpr int KPL = 2 * C::L;
+  constexpr int kRowDoubles = 2 * kN;             // one key row: 2 columns x N doubles = 16 KB
+  constexpr int kChunks = kRowDoubles / 128;      // 1 KB pieces = one wave-wide 16-byte load each
+  constexpr int kChunksPerWave = kChunks / WPB;
+  static_assert(kChunks % WPB == 0, "waves must split a key row evenly");
+  __shared__ double s_tw[Xf::kTableDoubles + 1];
+  __shared__ double s_buf[WPB][Xf::kWgBufDoubles];
+  __shared__ int32_t s_acc[WPB][2][kN];
+  __shared__ __attribute__((aligned(16))) double s_key[2][kRowDoubles];
+  __shared__ uint16_t s_bara[WPB][kSmall];
+  stage_tables(s_tw, a.tw, 64 * WPB, Xf::kTableDoubles);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const Field f = a.f;
+  double* buf = s_buf[wave];
+  int32_t* acc0 = s_acc[wave][0];
+  int32_t* acc1 = s_acc[wave][1];
+  typename Xf::State tw;
+  Xf::init(tw, lane, s_tw, a.tw);
+  const int n = a.n;
+  constexpr uint32_t offset = gadget_offset<C>();
+  double dev = 0.0;
+  const long n_groups = (a.B + WPB - 1) / WPB;
+  const long total_rows = (long)n * KPL;
+
+  // my 1/WPB share of key row R -> ring slot R & 1
+  auto issue_row = [&](long R) {
+    const double* src = a.bk_x + (size_t)R * kRowDoubles + (size_t)(wave * kChunksPerWave) * 128 + 2 * lane;
+    double* dst = s_key[R & 1] + (wave * kChunksPerWave) * 128;
+#pragma unroll
+    for (int c = 0; c < kChunksPerWave; ++c) glds16(src + c * 128, dst + c * 128);
+  };
+  auto mac_row = [&](double (&s0)[kRegs], double (&s1)[kRegs], const double (&x)[kRegs], int slot) {
+    const double2* k0 = reinterpret_cast<const double2*>(s_key[slot]);
+    const double2* k1 = k0 + kN / 2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      double2 w0[4], w1[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) { w0[v] = k0[(4 * h + v) * 64 + lane]; w1[v] = k1[(4 * h + v) * 64 + lane]; }
+      Xf::mac(s0, s1, x, w0, w1, 4 * h, f);
+    }
+  };
+
+  for (long group = blockIdx.x; group < n_groups; group += gridDim.x) {
+    const long ct = group * WPB + wave;
+    const bool active = ct < a.B;
+    if (active) {
+      const int32_t* row0 = a.in0 + ct * a.W;
+      const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
+      auto word = [&](int i) -> int32_t {
+        uint32_t v = (uint32_t)a.c0 * (uint32_t)row0[i];
+        if (row1) v += (uint32_t)a.c1 * (uint32_t)row1[i];
+        return (int32_t)v;
+      };
+      for (int i = lane; i < n; i += 64) s_bara[wave][i] = (uint16_t)modswitch_2N(word(i));
+      const int32_t barb = modswitch_2N((int32_t)((uint32_t)word(n) + (uint32_t)a.bconst));
+      const int rot = 2 * kN - barb;  // in (0, 2N]
+#pragma unroll
+      for (int r = 0; r < kRegs; ++r) {
+        const int j = lane + 64 * r;
+        acc0[j] = 0;
+        acc1[j] = rotated_const(a.mu, j, rot);
+      }
+    }
+    // all global reads of this prologue are complete and every wave has left the previous group's
+    // last multiply-accumulate before the ring is refilled
+    __syncthreads();
+    issue_row(0);
+    issue_row(1);
+
+    // Rows are processed in PAIRS (R, R+1), the two digit transforms interleaved phase by phase.
+    // Barrier 1 of a pair publishes both rows (each wave first waits for its own shares); barrier 2
+    // says every wave has finished reading them, after which the next pair's loads are issued and
+    // have the whole next transform pair to land.
+    long R = 0;
+    for (int i = 0; i < n; ++i) {
+      const int32_t bara = active ? __builtin_amdgcn_readfirstlane((int)s_bara[wave][i]) : 0;
+      const bool work = bara != 0;   // tfhe_blindRotate_FFT skips the identity CMUX
+      double s0[kRegs], s1[kRegs];
+#pragma unroll
+      for (int u = 0; u < kRegs; ++u) { s0[u] = 0.0; s1[u] = 0.0; }
+      int32_t d[kRegs];
+
+      auto pair = [&](int compA, int qA, int compB, int qB) {
+        double xa[kRegs], xb[kRegs];
+        if (work) {
+          if (qA == 0) {
+#pragma unroll
+            for (int r = 0; r < kRegs; ++r) d[r] = rotated_diff(compA ? acc1 : acc0, lane + 64 * r, bara);
+          }
+          Xf::digits(xa, d, qA, offset);
+          if (qB == 0) {
+#pragma unroll
+            for (int r = 0; r < kRegs; ++r) d[r] = rotated_diff(compB ? acc1 : acc0, lane + 64 * r, bara);
+          }
+          Xf::digits(xb, d, qB, offset);
+          Xf::fwd_pair_wg(lane, xa, xb, tw, buf);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (work) {
+          mac_row(s0, s1, xa, 0);
+          mac_row(s0, s1, xb, 1);
+        }
+        __syncthreads();
+        R += 2;
+        if (R < total_rows) { issue_row(R); issue_row(R + 1); }
+      };
+      if constexpr (C::L % 2 == 0) {
+#pragma unroll 1
+        for (int comp = 0; comp < 2; ++comp) {
+#pragma unroll 1
+          for (int q = 0; q < C::L; q += 2) pair(comp, q, comp, q + 1);
+          if (comp == 0 && work) Xf::mid(s0, s1, f);
+        }
+      } else {
+        // odd l: the middle pair straddles the two accumulator components (no place for Xf::mid:
+        // the workgroup form is only instantiated for policies whose mid() is empty)
+#pragma unroll
+        for (int p = 0; p < C::L; ++p) {
+          const int rA = 2 * p, rB = 2 * p + 1;
+          pair(rA / C::L, rA % C::L, rB / C::L, rB % C::L);
+        }
+      }
+
+      if (work) {
+        Xf::inverse_pair_wg(lane, s0, s1, tw, buf);
+#pragma unroll
+        for (int r = 0; r < kRegs; ++r) {
+          const int j = lane + 64 * r;
+          acc0[j] = (int32_t)((uint32_t)acc0[j] + (uint32_t)Xf::to_torus(s0[r], dev));
+          acc1[j] = (int32_t)((uint32_t)acc1[j] + (uint32_t)Xf::to_torus(s1[r], dev));
+        }
+        wave_lds_sync();
+      }
+    }
+
+    if (active) {
+      // tLweExtractLweSampleIndex(index 0): a'[0] = acc_a[0], a'[j] = -acc_a[N-j], b' = acc_b[0]
+      int32_t* out = a.u_out + ct * (kN + 1);
+#pragma unroll
+      for (int r = 0; r < kRegs; ++r) {
+        const int j = lane + 64 * r;
+        out[j] = (j == 0) ? acc0[0] : (int32_t)(0u - (uint32_t)acc0[kN - j]);
+      }
+      if (lane == 0) out[kN] = acc1[0];
+    }
   }
   if (Xf::kCertificate) publish_certificate(dev, a.dev_flag, lane);
 }
@@ -550,6 +757,14 @@ static hipError_t launch_br_xf(const BlindRotateArgs& a, int wpb, long num_cus, 
     }
     if (a.B <= 2L * num_cus) {
       hipLaunchKernelGGL((blind_rotate_coop_kernel<Xf, 2>), dim3((unsigned)a.B), dim3(128), 0, st, a);
+      return hipGetLastError();
+    }
+  }
+  if constexpr (Xf::kWorkgroupForm) {
+    // throughput form for batches that fill the chip twice over: lock-step workgroups, key rows shared in LDS
+    if (!getenv("RS_NO_WG") && a.B >= 8L * num_cus) {
+      const long groups = (a.B + 7) / 8;
+      hipLaunchKernelGGL((blind_rotate_wg_kernel<Xf, 8>), dim3((unsigned)(groups < num_cus ? groups : num_cus)), dim3(512), 0, st, a);
       return hipGetLastError();
     }
   }

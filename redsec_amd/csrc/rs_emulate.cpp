@@ -161,9 +161,27 @@ int emu_blind_rotate(int n, const int32_t* in0, const int32_t* in1, int32_t c0, 
 // ---------------------------------------------------------------------------------------------
 // FFT mode (rs_fft.h)
 // ---------------------------------------------------------------------------------------------
+static int g_planar = 0;   // 1: exercise the planar (one plane at a time) exchange of the workgroup kernel
+
+template <int L0, int L1, int T>
+void emu_exchange(Wave& w, double* buf) {
+  for (int l = 0; l < kLanes; ++l) rs::fpl_store<L0, T, 0>(l, w.x[l], buf);
+  for (int l = 0; l < kLanes; ++l) rs::fpl_load<L1, T, 0>(l, w.x[l], buf);
+  for (int l = 0; l < kLanes; ++l) rs::fpl_store<L0, T, 1>(l, w.x[l], buf);
+  for (int l = 0; l < kLanes; ++l) rs::fpl_load<L1, T, 1>(l, w.x[l], buf);
+}
+
 void emu_fft_forward(Wave& w, const double* tw, double* buf) {
   static rs::FftTw t[kLanes];
   for (int l = 0; l < kLanes; ++l) rs::fft_tw_load(t[l], l, tw);
+  if (g_planar) {
+    for (int l = 0; l < kLanes; ++l) { rs::fft_stage_fwd<0>(w.x[l], t[l]); rs::fft_stage_fwd<1>(w.x[l], t[l]); rs::fft_stage_fwd<2>(w.x[l], t[l]); }
+    emu_exchange<rs::kLayA, rs::kLayB, 1>(w, buf);
+    for (int l = 0; l < kLanes; ++l) { rs::fft_stage_fwd<3>(w.x[l], t[l]); rs::fft_stage_fwd<4>(w.x[l], t[l]); rs::fft_stage_fwd<5>(w.x[l], t[l]); }
+    emu_exchange<rs::kLayB, rs::kLayC, 2>(w, buf);
+    for (int l = 0; l < kLanes; ++l) { rs::fft_stage_fwd<6>(w.x[l], t[l]); rs::fft_stage_fwd<7>(w.x[l], t[l]); rs::fft_stage_fwd<8>(w.x[l], t[l]); }
+    return;
+  }
   for (int l = 0; l < kLanes; ++l) rs::ffwd_F1(l, w.x[l], t[l], buf);
   for (int l = 0; l < kLanes; ++l) rs::ffwd_F2(l, w.x[l], t[l], buf);
   for (int l = 0; l < kLanes; ++l) rs::ffwd_F3(l, w.x[l], buf);
@@ -172,6 +190,14 @@ void emu_fft_forward(Wave& w, const double* tw, double* buf) {
 void emu_fft_inverse(Wave& w, const double* tw, double* buf) {
   static rs::FftTw t[kLanes];
   for (int l = 0; l < kLanes; ++l) rs::fft_tw_load(t[l], l, tw);
+  if (g_planar) {
+    for (int l = 0; l < kLanes; ++l) { rs::fft_stage_inv<8>(w.x[l], t[l]); rs::fft_stage_inv<7>(w.x[l], t[l]); rs::fft_stage_inv<6>(w.x[l], t[l]); }
+    emu_exchange<rs::kLayC, rs::kLayB, 2>(w, buf);
+    for (int l = 0; l < kLanes; ++l) { rs::fft_stage_inv<5>(w.x[l], t[l]); rs::fft_stage_inv<4>(w.x[l], t[l]); rs::fft_stage_inv<3>(w.x[l], t[l]); }
+    emu_exchange<rs::kLayB, rs::kLayA, 1>(w, buf);
+    for (int l = 0; l < kLanes; ++l) { rs::fft_stage_inv<2>(w.x[l], t[l]); rs::fft_stage_inv<1>(w.x[l], t[l]); rs::fft_stage_inv<0>(w.x[l], t[l]); }
+    return;
+  }
   for (int l = 0; l < kLanes; ++l) rs::finv_I1(l, w.x[l], t[l], buf);
   for (int l = 0; l < kLanes; ++l) rs::finv_I2(l, w.x[l], t[l], buf);
   for (int l = 0; l < kLanes; ++l) rs::finv_I3(l, w.x[l], buf);
@@ -259,6 +285,28 @@ int emu_blind_rotate_fft(int n, const int32_t* in0, const int32_t* in1, int32_t 
 }  // namespace
 
 extern "C" {
+
+// number of mismatches between (a) the literal twiddles of stages 0-2 and the generated table,
+// (b) odd-indexed table entries and i times their even sibling -- both must be 0
+int rs_emu_fft_twiddle_check() {
+  std::vector<double> tw = rs::make_fft_tables();
+  int bad = 0;
+  const int lit_idx[4] = {1, 2, 4, 6};
+  for (int e = 0; e < 4; ++e) {
+    const int pos = rs::ftw_pos(lit_idx[e]);
+    bad += tw[2 * pos] != rs::kFftTwU[2 * e];
+    bad += tw[2 * pos + 1] != rs::kFftTwU[2 * e + 1];
+  }
+  for (int idx = 2; idx < rs::kM; idx += 2) {
+    const int pe = rs::ftw_pos(idx), po = rs::ftw_pos(idx + 1);
+    bad += tw[2 * po] != -tw[2 * pe + 1];
+    bad += tw[2 * po + 1] != tw[2 * pe];
+  }
+  return bad;
+}
+
+// selects the exchange form emulated by the FFT entry points (0 interleaved, 1 planar)
+void rs_emu_set_planar(int on) { g_planar = on; }
 
 // FFT-mode product of a small polynomial with a torus polynomial; returns the largest distance to
 // the nearest integer seen before rounding in *max_dev.

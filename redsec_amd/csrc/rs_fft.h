@@ -53,17 +53,31 @@ RS_HD int fpos_t1(int j) { return j + 8 * (j >> 7); }
 RS_HD int fpos_t2(int j) { return j + (j >> 3); }
 
 RS_HD void fft_bfly_fwd(double& xr, double& xi, double& yr, double& yi, double wr, double wi) {
-  const double tr = __builtin_fma(-wi, yi, wr * yr);
-  const double ti = __builtin_fma(wr, yi, wi * yr);
-  const double ar = xr, ai = xi;
-  xr = ar + tr; xi = ai + ti;
-  yr = ar - tr; yi = ai - ti;
+  // 6 FP64 ops: x' = x + w*y as two chained FMAs per component, y' = 2x - x' as one more.
+  const double sr = __builtin_fma(-wi, yi, __builtin_fma(wr, yr, xr));
+  const double si = __builtin_fma(wi, yr, __builtin_fma(wr, yi, xi));
+  yr = __builtin_fma(2.0, xr, -sr); yi = __builtin_fma(2.0, xi, -si);
+  xr = sr; xi = si;
+}
+// The same butterfly with the twiddle i*w = (-wi, wr) given as w: bit-identical to fft_bfly_fwd(.., -wi, wr).
+RS_HD void fft_bfly_fwd_i(double& xr, double& xi, double& yr, double& yi, double wr, double wi) {
+  const double sr = __builtin_fma(-wr, yi, __builtin_fma(-wi, yr, xr));
+  const double si = __builtin_fma(wr, yr, __builtin_fma(-wi, yi, xi));
+  yr = __builtin_fma(2.0, xr, -sr); yi = __builtin_fma(2.0, xi, -si);
+  xr = sr; xi = si;
 }
 RS_HD void fft_bfly_inv(double& xr, double& xi, double& yr, double& yi, double wr, double wi) {
   const double dr = xr - yr, di = xi - yi;
   xr = xr + yr; xi = xi + yi;
   yr = __builtin_fma(wi, di, wr * dr);      // conj(w) * d
   yi = __builtin_fma(-wi, dr, wr * di);
+}
+// twiddle i*w given as w: conj(i w) * d, bit-identical to fft_bfly_inv(.., -wi, wr)
+RS_HD void fft_bfly_inv_i(double& xr, double& xi, double& yr, double& yi, double wr, double wi) {
+  const double dr = xr - yr, di = xi - yi;
+  xr = xr + yr; xi = xi + yi;
+  yr = __builtin_fma(wr, di, -(wi * dr));
+  yi = __builtin_fma(-wr, dr, -(wi * di));
 }
 
 // The twiddles depend only on (stage, lane, register index), never on the polynomial, so a wavefront
@@ -100,6 +114,23 @@ RS_HD void fft_tw_get(const FftTw& t, int k, double& wr, double& wi) {
   wi = (S < 3) ? t.ui[(1 << S) - 1 + k] : t.li[lbase + k];
 }
 
+// Stages 0-2 use wave-uniform twiddles (table entries 1, 2, 4, 6; the odd entries are i times their
+// even sibling): literals, so they live in scalar registers instead of costing LDS reads. The values
+// are those make_fft_tables() computes (tests/test_emulator.py checks the two against each other).
+constexpr double kFftTwU[8] = {
+    0x1.6a09e667f3bcdp-1, 0x1.6a09e667f3bcdp-1,   // entry 1: exp(i * 2 pi * 512 / 4096)
+    0x1.d906bcf328d46p-1, 0x1.87de2a6aea963p-2,   // entry 2: exp(i * 2 pi * 256 / 4096)
+    0x1.f6297cff75cbp-1, 0x1.8f8b83c69a60bp-3,    // entry 4: exp(i * 2 pi * 128 / 4096)
+    0x1.1c73b39ae68c8p-1, 0x1.a9b66290ea1a3p-1,   // entry 6: exp(i * 2 pi * 640 / 4096)
+};
+// literal of stage S < 3, EVEN twiddle index k (0 or 2)
+template <int S>
+RS_HD void fft_tw_uniform(int k, double& wr, double& wi) {
+  const int e = (S == 0) ? 0 : (S == 1 ? 1 : 2 + (k >> 1));
+  wr = kFftTwU[2 * e];
+  wi = kFftTwU[2 * e + 1];
+}
+
 // Twiddle source reading the stage-transposed table (in LDS on the device) at every use: costs 21
 // 16-byte LDS reads per transform but no registers. Same values, hence bit-identical results.
 struct FftTwTable {
@@ -114,27 +145,44 @@ RS_HD void fft_tw_get(const FftTwTable& t, int k, double& wr, double& wi) {
 }
 
 // x[e] = re, x[e+8] = im of the lane's e-th complex value. Stage s in [0,9): pairs (e, e+half),
-// half = 4 >> (s % 3); twiddle index within the stage = e >> (3 - s % 3).
+// half = 4 >> (s % 3); twiddle index within the stage = e >> (3 - s % 3). Only the EVEN twiddle
+// indices are fetched: index k+1 is i times index k (theta + pi/2), applied by the _i butterflies.
+template <int S, class TW>
+RS_HD void fft_tw_even(const TW& t, int k, double& wr, double& wi) {
+  if (S < 3) fft_tw_uniform<S>(k, wr, wi); else fft_tw_get<S>(t, k, wr, wi);
+}
 template <int S, class TW>
 RS_HD void fft_stage_fwd(double (&x)[kRegs], const TW& t) {
-  constexpr int g = S % 3, half = 4 >> g, shift = 3 - g;
+  constexpr int g = S % 3, half = 4 >> g, shift = 3 - g, ntw = kCRegs >> shift;
 #pragma unroll
-  for (int e = 0; e < kCRegs; ++e) {
-    if (e & half) continue;
+  for (int k = 0; k < ntw; k += 2) {
     double wr, wi;
-    fft_tw_get<S>(t, e >> shift, wr, wi);
-    fft_bfly_fwd(x[e], x[e + 8], x[e + half], x[e + half + 8], wr, wi);
+    fft_tw_even<S>(t, k, wr, wi);
+    const int e = k << shift;                              // elements [e, e + 2 half) use twiddle k
+#pragma unroll
+    for (int c = 0; c < half; ++c) fft_bfly_fwd(x[e + c], x[e + c + 8], x[e + c + half], x[e + c + half + 8], wr, wi);
+    if (g != 0) {
+      const int o = e + 2 * half;                          // ... and [o, o + 2 half) its sibling k + 1
+#pragma unroll
+      for (int c = 0; c < half; ++c) fft_bfly_fwd_i(x[o + c], x[o + c + 8], x[o + c + half], x[o + c + half + 8], wr, wi);
+    }
   }
 }
 template <int S, class TW>
 RS_HD void fft_stage_inv(double (&x)[kRegs], const TW& t) {
-  constexpr int g = S % 3, half = 4 >> g, shift = 3 - g;
+  constexpr int g = S % 3, half = 4 >> g, shift = 3 - g, ntw = kCRegs >> shift;
 #pragma unroll
-  for (int e = 0; e < kCRegs; ++e) {
-    if (e & half) continue;
+  for (int k = 0; k < ntw; k += 2) {
     double wr, wi;
-    fft_tw_get<S>(t, e >> shift, wr, wi);
-    fft_bfly_inv(x[e], x[e + 8], x[e + half], x[e + half + 8], wr, wi);
+    fft_tw_even<S>(t, k, wr, wi);
+    const int e = k << shift;
+#pragma unroll
+    for (int c = 0; c < half; ++c) fft_bfly_inv(x[e + c], x[e + c + 8], x[e + c + half], x[e + c + half + 8], wr, wi);
+    if (g != 0) {
+      const int o = e + 2 * half;
+#pragma unroll
+      for (int c = 0; c < half; ++c) fft_bfly_inv_i(x[o + c], x[o + c + 8], x[o + c + half], x[o + c + half + 8], wr, wi);
+    }
   }
 }
 
@@ -193,6 +241,127 @@ RS_HD void finv_I4(int lane, double (&x)[kRegs], const TW& t, const double* buf)
 #pragma unroll
   for (int r = 0; r < kCRegs; ++r) fbuf_load(buf, fpos_t1(lane + 64 * r), x[r], x[r + 8]);
   fft_stage_inv<2>(x, t); fft_stage_inv<1>(x, t); fft_stage_inv<0>(x, t);
+}
+
+// ---- planar exchange: the re plane and the im plane pass through the SAME 576-double buffer one after
+// the other, halving the LDS a wavefront needs for its transposes (the workgroup kernel spends the
+// difference on a shared key-row ring). Same data movement as the interleaved form, so the
+// transform values are bit-identical. Paddings chosen for conflict-free 8-byte accesses.
+constexpr int kPlaneDoubles = 576;
+RS_HD int ppos_t1(int j) { return j + 8 * (j >> 6); }
+RS_HD int ppos_t2(int j) { return j + (j >> 3); }
+enum { kLayA = 0, kLayB = 1, kLayC = 2 };   // A' j = L + 64 k; B' j = 64 (L>>3) + 8 k + (L&7); C' j = 8 L + k
+template <int LAY>
+RS_HD int flay_index(int lane, int k) {
+  return LAY == kLayA ? lane + 64 * k : (LAY == kLayB ? 64 * (lane >> 3) + 8 * k + (lane & 7) : 8 * lane + k);
+}
+template <int LAY, int T, int H>
+RS_HD void fpl_store(int lane, const double (&x)[kRegs], double* buf) {
+#pragma unroll
+  for (int k = 0; k < kCRegs; ++k) { const int j = flay_index<LAY>(lane, k); buf[T == 1 ? ppos_t1(j) : ppos_t2(j)] = x[k + 8 * H]; }
+}
+template <int LAY, int T, int H>
+RS_HD void fpl_load(int lane, double (&x)[kRegs], const double* buf) {
+#pragma unroll
+  for (int k = 0; k < kCRegs; ++k) { const int j = flay_index<LAY>(lane, k); x[k + 8 * H] = buf[T == 1 ? ppos_t1(j) : ppos_t2(j)]; }
+}
+// One exchange FROM layout L0 TO layout L1 through padding T; `sync` orders the wavefront's LDS
+// accesses (on the device a compiler-only fence: DS operations of one wavefront execute in order).
+template <int L0, int L1, int T, class Sync>
+RS_HD void fpl_exchange(int lane, double (&x)[kRegs], double* buf, Sync sync) {
+  fpl_store<L0, T, 0>(lane, x, buf); sync();
+  fpl_load<L1, T, 0>(lane, x, buf); sync();
+  fpl_store<L0, T, 1>(lane, x, buf); sync();
+  fpl_load<L1, T, 1>(lane, x, buf); sync();
+}
+template <class TW, class Sync>
+RS_HD void ffwd_planar(int lane, double (&x)[kRegs], const TW& t, double* buf, Sync sync) {
+  fft_stage_fwd<0>(x, t); fft_stage_fwd<1>(x, t); fft_stage_fwd<2>(x, t);
+  fpl_exchange<kLayA, kLayB, 1>(lane, x, buf, sync);
+  fft_stage_fwd<3>(x, t); fft_stage_fwd<4>(x, t); fft_stage_fwd<5>(x, t);
+  fpl_exchange<kLayB, kLayC, 2>(lane, x, buf, sync);
+  fft_stage_fwd<6>(x, t); fft_stage_fwd<7>(x, t); fft_stage_fwd<8>(x, t);
+}
+template <class TW, class Sync>
+RS_HD void finv_planar(int lane, double (&x)[kRegs], const TW& t, double* buf, Sync sync) {
+  fft_stage_inv<8>(x, t); fft_stage_inv<7>(x, t); fft_stage_inv<6>(x, t);
+  fpl_exchange<kLayC, kLayB, 2>(lane, x, buf, sync);
+  fft_stage_inv<5>(x, t); fft_stage_inv<4>(x, t); fft_stage_inv<3>(x, t);
+  fpl_exchange<kLayB, kLayA, 1>(lane, x, buf, sync);
+  fft_stage_inv<2>(x, t); fft_stage_inv<1>(x, t); fft_stage_inv<0>(x, t);
+}
+
+// ---- two transforms in flight ----
+// A wavefront's LDS operations execute in order, so a second transform may push its exchange through
+// the SAME buffer as soon as the first one's loads have been ISSUED: its stores queue behind them.
+// Interleaving two independent transforms phase by phase lets the butterflies of one cover the LDS
+// round trip of the other inside a single wavefront (the kernels run only two wavefronts per SIMD).
+template <int LAY, int T>
+RS_HD void fil_store(int lane, const double (&x)[kRegs], double* buf) {
+#pragma unroll
+  for (int k = 0; k < kCRegs; ++k) { const int j = flay_index<LAY>(lane, k); fbuf_store(buf, T == 1 ? fpos_t1(j) : fpos_t2(j), x[k], x[k + 8]); }
+}
+template <int LAY, int T>
+RS_HD void fil_load(int lane, double (&x)[kRegs], const double* buf) {
+#pragma unroll
+  for (int k = 0; k < kCRegs; ++k) { const int j = flay_index<LAY>(lane, k); fbuf_load(buf, T == 1 ? fpos_t1(j) : fpos_t2(j), x[k], x[k + 8]); }
+}
+// PLANAR: one 8-byte plane at a time through a kPlaneDoubles buffer; else (re, im) pairs through kBufDoubles
+template <bool PLANAR, int L0, int L1, int T, class Sync>
+RS_HD void fft_exchange(int lane, double (&x)[kRegs], double* buf, Sync sync) {
+  if (PLANAR) {
+    fpl_exchange<L0, L1, T>(lane, x, buf, sync);
+  } else {
+    fil_store<L0, T>(lane, x, buf); sync();
+    fil_load<L1, T>(lane, x, buf); sync();
+  }
+}
+template <int G, class TW>
+RS_HD void fft_fwd3(double (&x)[kRegs], const TW& t) { fft_stage_fwd<3 * G>(x, t); fft_stage_fwd<3 * G + 1>(x, t); fft_stage_fwd<3 * G + 2>(x, t); }
+template <int G, class TW>
+RS_HD void fft_inv3(double (&x)[kRegs], const TW& t) { fft_stage_inv<3 * G + 2>(x, t); fft_stage_inv<3 * G + 1>(x, t); fft_stage_inv<3 * G>(x, t); }
+
+// Exchange of x with `work(0..2)` -- three butterfly stages of the OTHER transform -- placed between
+// its LDS phases, so that the vector ALU has independent work while the stores drain (a 16-byte-per-
+// lane store occupies the LDS issue path for ~13 cycles) and the loads return.
+template <bool PLANAR, int L0, int L1, int T, class Sync, class Work>
+RS_HD void fft_exchange_with(int lane, double (&x)[kRegs], double* buf, Sync sync, Work work) {
+  if (PLANAR) {
+    fpl_store<L0, T, 0>(lane, x, buf); work(0); sync();
+    fpl_load<L1, T, 0>(lane, x, buf); work(1); sync();
+    fpl_store<L0, T, 1>(lane, x, buf); work(2); sync();
+    fpl_load<L1, T, 1>(lane, x, buf); sync();
+  } else {
+    fil_store<L0, T>(lane, x, buf); work(0); work(1); sync();
+    fil_load<L1, T>(lane, x, buf); work(2); sync();
+  }
+}
+template <int G, bool INV, class TW>
+RS_HD void fft_group_stage(double (&x)[kRegs], const TW& t, int k) {   // k-th stage (in execution order) of group G
+  if (!INV) {
+    if (k == 0) fft_stage_fwd<3 * G>(x, t); else if (k == 1) fft_stage_fwd<3 * G + 1>(x, t); else fft_stage_fwd<3 * G + 2>(x, t);
+  } else {
+    if (k == 0) fft_stage_inv<3 * G + 2>(x, t); else if (k == 1) fft_stage_inv<3 * G + 1>(x, t); else fft_stage_inv<3 * G>(x, t);
+  }
+}
+
+template <bool PLANAR, class TW, class Sync>
+RS_HD void ffwd_pair(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TW& t, double* buf, Sync sync) {
+  fft_fwd3<0>(xa, t);
+  fft_exchange_with<PLANAR, kLayA, kLayB, 1>(lane, xa, buf, sync, [&](int k) { fft_group_stage<0, false>(xb, t, k); });
+  fft_exchange_with<PLANAR, kLayA, kLayB, 1>(lane, xb, buf, sync, [&](int k) { fft_group_stage<1, false>(xa, t, k); });
+  fft_exchange_with<PLANAR, kLayB, kLayC, 2>(lane, xa, buf, sync, [&](int k) { fft_group_stage<1, false>(xb, t, k); });
+  fft_exchange_with<PLANAR, kLayB, kLayC, 2>(lane, xb, buf, sync, [&](int k) { fft_group_stage<2, false>(xa, t, k); });
+  fft_fwd3<2>(xb, t);
+}
+template <bool PLANAR, class TW, class Sync>
+RS_HD void finv_pair(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TW& t, double* buf, Sync sync) {
+  fft_inv3<2>(xa, t);
+  fft_exchange_with<PLANAR, kLayC, kLayB, 2>(lane, xa, buf, sync, [&](int k) { fft_group_stage<2, true>(xb, t, k); });
+  fft_exchange_with<PLANAR, kLayC, kLayB, 2>(lane, xb, buf, sync, [&](int k) { fft_group_stage<1, true>(xa, t, k); });
+  fft_exchange_with<PLANAR, kLayB, kLayA, 1>(lane, xa, buf, sync, [&](int k) { fft_group_stage<1, true>(xb, t, k); });
+  fft_exchange_with<PLANAR, kLayB, kLayA, 1>(lane, xb, buf, sync, [&](int k) { fft_group_stage<0, true>(xa, t, k); });
+  fft_inv3<0>(xb, t);
 }
 
 // pointwise complex multiply-accumulate: (sr, si) += (xr, xi) * (wr, wi)

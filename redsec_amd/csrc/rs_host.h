@@ -88,13 +88,17 @@ inline std::vector<double> make_fft_tables() {
   for (int s = 0; s < 9; ++s) {
     const int m = 1 << s;
     for (int i = 0; i < m; ++i) {
+      // odd block index: theta + pi/2, stored as EXACTLY i times the even sibling (-im, re): the
+      // device fetches only even entries and applies the i-variant butterflies (rs_fft.h)
+      const int ie = i & ~1;
       int br = 0;
-      for (int b = 0; b < s; ++b) br |= ((i >> b) & 1) << (s - 1 - b);
+      for (int b = 0; b < s; ++b) br |= ((ie >> b) & 1) << (s - 1 - b);
       const long a = (long)(1 + 4 * br) << (9 - s);            // angle in units of 2 pi / 4096
       const long double ang = two_pi * (long double)a / 4096.0L;
       const int pos = ftw_pos(m + i);
-      t[2 * pos] = (double)cosl(ang);
-      t[2 * pos + 1] = (double)sinl(ang);
+      const double re = (double)cosl(ang), im = (double)sinl(ang);
+      t[2 * pos] = (i & 1) ? -im : re;
+      t[2 * pos + 1] = (i & 1) ? re : im;
     }
   }
   return t;

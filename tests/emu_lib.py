@@ -46,6 +46,11 @@ def forward(cfg, poly):
     return out
 
 
+def set_planar(on):
+    """FFT entry points emulate the planar LDS exchange of the workgroup kernel (True) or the interleaved one."""
+    lib().rs_emu_set_planar(1 if on else 0)
+
+
 def polymul_fft(a, b):
     a = np.ascontiguousarray(a, np.int32); b = np.ascontiguousarray(b, np.int32)
     out = np.zeros(1024, np.int32)

@@ -122,6 +122,30 @@ def test_fft_mode_polymul_is_exact_after_rounding(half):
         assert dev < 0.1
 
 
+def test_fft_twiddle_literals_match_generated_table():
+    """rs_fft.h kFftTwU (stages 0-2, scalar-register literals on the device) equals the host-generated
+    table, and every odd table entry is exactly i times its even sibling (the device fetches only the
+    even ones)."""
+    assert emu_lib.lib().rs_emu_fft_twiddle_check() == 0
+
+
+def test_fft_planar_exchange_is_bit_identical_to_interleaved():
+    """The workgroup kernel moves the re and im planes through one half-size LDS buffer in turn
+    (rs_fft.h fpl_exchange); same data movement, so products AND rounding distances are identical."""
+    rng = np.random.default_rng(77)
+    try:
+        for _ in range(4):
+            a = rng.integers(-64, 64, 1024).astype(np.int32); b = rng.integers(-2**31, 2**31, 1024).astype(np.int32)
+            emu_lib.set_planar(False)
+            o0, d0 = emu_lib.polymul_fft(a, b)
+            emu_lib.set_planar(True)
+            o1, d1 = emu_lib.polymul_fft(a, b)
+            assert np.array_equal(o0, o1) and d0 == d1
+            assert np.array_equal(o1, ol.negacyclic_mul(a, b, "schoolbook"))
+    finally:
+        emu_lib.set_planar(False)
+
+
 @pytest.mark.parametrize("cfg,fixture", [(0, "toy_default"), (1, "toy_redsec")])
 def test_fft_mode_blind_rotate_matches_exact_oracle(cfg, fixture, request):
     ks, ctx = request.getfixturevalue(fixture)
