@@ -171,7 +171,8 @@ def main():
             traffic = pmc.get("%s_%d_%s" % (args.params, G, args.mode), {}).get("traffic_bytes")
         except Exception:
             pass
-        roofline = {"bound": "hbm", "kernel": "blind_rotate_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+        wg_form = args.mode == "fft" and G >= 8 * info["num_cus"]   # launcher's choice (rs_bootstrap.hip launch_br_xf)
+        roofline = {"bound": "hbm", "kernel": "blind_rotate_wg_kernel" if wg_form else "blind_rotate_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                     "kernel_ms": round(last_br, 3), "algorithmic_bytes_per_launch": int(alg_bytes),
                     "resident_ciphertexts_per_key_sweep": R}

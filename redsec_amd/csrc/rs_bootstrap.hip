@@ -761,7 +761,9 @@ static hipError_t launch_br_xf(const BlindRotateArgs& a, int wpb, long num_cus, 
     }
   }
   if constexpr (Xf::kWorkgroupForm) {
-    // throughput form for batches that fill the chip twice over: lock-step workgroups, key rows shared in LDS
+    // throughput form once every CU gets a whole 8-ciphertext group: lock-step workgroups, key rows
+    // shared in LDS. (Groups of 2 or 4 waves were measured for 512 < B < 2048 and do not beat the
+    // per-wave kernel there: with one wave per SIMD the single-wave CMUX latency dominates.)
     if (!getenv("RS_NO_WG") && a.B >= 8L * num_cus) {
       const long groups = (a.B + 7) / 8;
       hipLaunchKernelGGL((blind_rotate_wg_kernel<Xf, 8>), dim3((unsigned)(groups < num_cus ? groups : num_cus)), dim3(512), 0, st, a);

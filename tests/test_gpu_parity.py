@@ -202,6 +202,34 @@ def test_large_batch_truth_table_property(be_full_default, full_default):
     assert np.array_equal(sub, got[:37])
 
 
+@pytest.mark.parametrize("which,fix", [("be_toy_default", "toy_default"), ("be_toy_redsec", "toy_redsec")])
+def test_workgroup_kernel_ragged_groups_and_identity_steps(which, fix, request, monkeypatch):
+    """blind_rotate_wg_kernel (FFT mode, B >= 8 x #CUs): a batch whose last 8-ciphertext group is ragged
+    AND spills past one group per workgroup, with mask words forced to 0 so that some CMUX steps are the
+    identity (tfhe_blindRotate_FFT skips them; the lock-step waves must still keep their barriers).
+    Checked word for word against the per-wave kernel (RS_NO_WG) and, on a sample, against the oracle."""
+    import torch
+    be = request.getfixturevalue(which)
+    ks, ctx = request.getfixturevalue(fix)
+    cus = be.info()["num_cus"]
+    B = 8 * cus + 3
+    bits, ct = _bits(ks, B, 4242)
+    ct = ct.copy()
+    ct[5, :3] = 0            # leading identity steps
+    ct[6, 1::2] = 0          # every other step
+    ct[B - 1, -3:-1] = 0     # in the ragged group, trailing steps
+    ct[B - 2, : ks.p.n] = 0  # a ciphertext whose whole blind rotation is the identity
+    mu = ol.to_torus(1, 8)
+    d = _dev(ct)
+    got = be.bootstrap(d, mu)
+    monkeypatch.setenv("RS_NO_WG", "1")
+    ref = be.bootstrap(d, mu)
+    monkeypatch.delenv("RS_NO_WG")
+    assert torch.equal(got, ref)
+    sample = np.r_[0:8, B - 11:B]
+    assert np.array_equal(got.cpu().numpy()[sample], ctx.bootstrap_batch(ct[sample], mu))
+
+
 def test_linear_stage_matches_oracle(be_toy_redsec, toy_redsec):
     be = be_toy_redsec
     ks, _ = toy_redsec

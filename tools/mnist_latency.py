@@ -22,7 +22,7 @@ for _ in range(5):
 print("whole image ms:", [round(t * 1e3, 2) for t in ts])
 be.set_timing(True)
 x = torch.randint(-2**31, 2**31 - 1, (196, be.W), dtype=torch.int64).to(torch.int32).cuda()
-for B in (196, 1024):
+for B in (196, 600, 1024, 2048):
     x = torch.randint(-2**31, 2**31 - 1, (B, be.W), dtype=torch.int64).to(torch.int32).cuda()
     be.bootstrap(x, 1 << 20); torch.cuda.synchronize()
     t0 = time.perf_counter(); be.bootstrap(x, 1 << 20); torch.cuda.synchronize(); wall = time.perf_counter() - t0
