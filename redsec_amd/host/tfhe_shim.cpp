@@ -327,12 +327,20 @@ TFheGateBootstrappingSecretKeySet* new_tfheGateBootstrappingSecretKeySet_fromFil
   read_exact(f, bk->ksk_words, sizeof(int32_t) * ksk_words(p), "keyswitch key");
   return new TFheGateBootstrappingSecretKeySet(p, bk, new_bkfft(p, bk), lk, gk);
 }
+// TFHE v1.1's LweSample record (tfhe_io.cpp write_lweSample): int32 type uid 42, int32 a[n], int32 b,
+// double current_variance = 4n + 16 bytes -- image.ctxt / network_output.ctxt
+// written here are byte-compatible with a TFHE client's.
+static const int32_t kLweSampleTypeUid = 42;
 void export_gate_bootstrapping_ciphertext_toFile(FILE* f, const LweSample* s, const TFheGateBootstrappingParameterSet* p) {
+  fwrite(&kLweSampleTypeUid, sizeof(int32_t), 1, f);
   fwrite(s->a, sizeof(Torus32), (size_t)p->in_out_params->n, f);
   fwrite(&s->b, sizeof(Torus32), 1, f);
   fwrite(&s->current_variance, sizeof(double), 1, f);
 }
 void import_gate_bootstrapping_ciphertext_fromFile(FILE* f, LweSample* s, const TFheGateBootstrappingParameterSet* p) {
+  int32_t uid = 0;
+  read_exact(f, &uid, sizeof(int32_t), "ciphertext type uid");
+  if (uid != kLweSampleTypeUid) { fprintf(stderr, "redsec tfhe shim: not an LweSample record (type uid %d, expected 42)\n", uid); abort(); }
   read_exact(f, s->a, sizeof(Torus32) * (size_t)p->in_out_params->n, "ciphertext a");
   read_exact(f, &s->b, sizeof(Torus32), "ciphertext b");
   read_exact(f, &s->current_variance, sizeof(double), "ciphertext variance");

@@ -49,10 +49,12 @@ def read_secret_key(path):
 
 
 def read_ciphertexts(path, n, count):
-    rec = 4 * n + 4 + 8
+    """TFHE v1.1 LweSample records: int32 type uid (42), int32 a[n], int32 b, double variance."""
+    rec = 4 + 4 * n + 4 + 8
     raw = open(path, "rb").read()
     assert len(raw) == rec * count, (len(raw), rec, count)
     out = np.zeros((count, n + 1), np.int32)
     for i in range(count):
-        out[i] = np.frombuffer(raw[i * rec:i * rec + 4 * (n + 1)], np.int32)
+        assert np.frombuffer(raw[i * rec:i * rec + 4], np.int32)[0] == 42
+        out[i] = np.frombuffer(raw[i * rec + 4:i * rec + 4 + 4 * (n + 1)], np.int32)
     return out
