@@ -498,16 +498,17 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
       auto pair = [&](int compA, int qA, int compB, int qB) {
         double xa[kRegs], xb[kRegs];
         if (work) {
+          // d holds the rotated difference PLUS the gadget offset (added once per component, not per digit row)
           if (qA == 0) {
 #pragma unroll
-            for (int r = 0; r < kRegs; ++r) d[r] = rotated_diff(compA ? acc1 : acc0, lane + 64 * r, bara);
+            for (int r = 0; r < kRegs; ++r) d[r] = (int32_t)((uint32_t)rotated_diff(compA ? acc1 : acc0, lane + 64 * r, bara) + offset);
           }
-          Xf::digits(xa, d, qA, offset);
+          Xf::digits(xa, d, qA, 0u);
           if (qB == 0) {
 #pragma unroll
-            for (int r = 0; r < kRegs; ++r) d[r] = rotated_diff(compB ? acc1 : acc0, lane + 64 * r, bara);
+            for (int r = 0; r < kRegs; ++r) d[r] = (int32_t)((uint32_t)rotated_diff(compB ? acc1 : acc0, lane + 64 * r, bara) + offset);
           }
-          Xf::digits(xb, d, qB, offset);
+          Xf::digits(xb, d, qB, 0u);
           Xf::fwd_pair_wg(lane, xa, xb, tw, buf);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -558,6 +559,159 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
         out[j] = (j == 0) ? acc0[0] : (int32_t)(0u - (uint32_t)acc0[kN - j]);
       }
       if (lane == 0) out[kN] = acc1[0];
+    }
+  }
+  if (Xf::kCertificate) publish_certificate(dev, a.dev_flag, lane);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Blind rotation, "duo" workgroup form (mid-size batches: 2 x #CUs < B < 8 x #CUs, even l).
+// One wave per ciphertext leaves half the wave slots empty there and every wave streams the whole key
+// by itself (the 1,024-neuron MNIST layer was bound by ~10 TB/s of key reads). Here a workgroup is
+// 4 ciphertexts x 2 waves: wave (c, h) owns accumulator component h of ciphertext c -- it transforms
+// the l digit rows of that component (in software-pipelined pairs), accumulates partial sums for both
+// output columns, receives column h's other partial from its partner, runs that column's inverse
+// transform and updates component h. The 8 waves run in lock step and share the key rows through LDS:
+// per pair of rows a "quad" (2 rows of each component, 64 KB) is fetched by direct global->LDS loads,
+// 1/8 per wave. Barriers per CMUX step: 2 per row pair + 2 around the partial exchange, which goes
+// through the (then idle) quad buffer.
+// -------------------------------------------------------------------------------------------------
+template <class Xf>
+__global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a) {
+  using C = typename Xf::Cfg;
+  static_assert(C::L % 2 == 0, "rows are processed in pairs within one component");
+  constexpr int KPL = 2 * C::L;
+  constexpr int kRowDoubles = 2 * kN;
+  constexpr int kCts = 4;
+  __shared__ double s_tw[Xf::kTableDoubles + 1];
+  __shared__ double s_buf[8][Xf::kWgBufDoubles];
+  __shared__ int32_t s_acc[kCts][2][kN];
+  __shared__ __attribute__((aligned(16))) double s_key[4][kRowDoubles];   // slot 2 h + k: row k of the pair, component h
+  __shared__ uint16_t s_bara[kCts][kSmall];
+  stage_tables(s_tw, a.tw, 512, Xf::kTableDoubles);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int c = wave >> 1, h = wave & 1;
+  const Field f = a.f;
+  double* buf = s_buf[wave];
+  int32_t* acc = s_acc[c][h];
+  typename Xf::State tw;
+  Xf::init(tw, lane, s_tw, a.tw);
+  const int n = a.n;
+  constexpr uint32_t offset = gadget_offset<C>();
+  double dev = 0.0;
+  const long n_groups = (a.B + kCts - 1) / kCts;
+
+  // quad (i, p): rows i KPL + hh L + 2 p + k; this wave fetches half of slot (wave >> 1)
+  auto issue_quad = [&](int i, int p) {
+    const int slot = wave >> 1;
+    const long R = (long)i * KPL + (slot >> 1) * C::L + 2 * p + (slot & 1);
+    const double* src = a.bk_x + (size_t)R * kRowDoubles + (size_t)((wave & 1) * 8) * 128 + 2 * lane;
+    double* dst = s_key[slot] + ((wave & 1) * 8) * 128;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) glds16(src + k * 128, dst + k * 128);
+  };
+  auto mac_row = [&](double (&s0)[kRegs], double (&s1)[kRegs], const double (&x)[kRegs], int slot) {
+    const double2* k0 = reinterpret_cast<const double2*>(s_key[slot]);
+    const double2* k1 = k0 + kN / 2;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      double2 w0[4], w1[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) { w0[v] = k0[(4 * hh + v) * 64 + lane]; w1[v] = k1[(4 * hh + v) * 64 + lane]; }
+      Xf::mac(s0, s1, x, w0, w1, 4 * hh, f);
+    }
+  };
+
+  for (long group = blockIdx.x; group < n_groups; group += gridDim.x) {
+    const long ct = group * kCts + c;
+    const bool active = ct < a.B;
+    if (active) {
+      const int32_t* row0 = a.in0 + ct * a.W;
+      const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
+      auto word = [&](int i) -> int32_t {
+        uint32_t v = (uint32_t)a.c0 * (uint32_t)row0[i];
+        if (row1) v += (uint32_t)a.c1 * (uint32_t)row1[i];
+        return (int32_t)v;
+      };
+      for (int i = lane + 64 * h; i < n; i += 128) s_bara[c][i] = (uint16_t)modswitch_2N(word(i));
+      const int32_t barb = modswitch_2N((int32_t)((uint32_t)word(n) + (uint32_t)a.bconst));
+      const int rot = 2 * kN - barb;  // in (0, 2N]
+#pragma unroll
+      for (int r = 0; r < kRegs; ++r) {
+        const int j = lane + 64 * r;
+        acc[j] = h ? rotated_const(a.mu, j, rot) : 0;
+      }
+    }
+    __syncthreads();   // bara complete; previous group's last reads of the quad buffer are over
+    issue_quad(0, 0);
+
+    for (int i = 0; i < n; ++i) {
+      const int32_t bara = active ? __builtin_amdgcn_readfirstlane((int)s_bara[c][i]) : 0;
+      const bool work = bara != 0;   // tfhe_blindRotate_FFT skips the identity CMUX
+      double s0[kRegs], s1[kRegs];
+#pragma unroll
+      for (int u = 0; u < kRegs; ++u) { s0[u] = 0.0; s1[u] = 0.0; }
+      int32_t d[kRegs];
+      if (work) {
+#pragma unroll
+        for (int r = 0; r < kRegs; ++r) d[r] = (int32_t)((uint32_t)rotated_diff(acc, lane + 64 * r, bara) + offset);
+      }
+#pragma unroll 1
+      for (int p = 0; p < C::L / 2; ++p) {
+        double xa[kRegs], xb[kRegs];
+        if (work) {
+          Xf::digits(xa, d, 2 * p, 0u);
+          Xf::digits(xb, d, 2 * p + 1, 0u);
+          Xf::fwd_pair_wg(lane, xa, xb, tw, buf);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                         // quad (i, p) published
+        if (work) {
+          mac_row(s0, s1, xa, 2 * h);
+          mac_row(s0, s1, xb, 2 * h + 1);
+        }
+        __syncthreads();                         // every wave has finished reading it
+        if (p + 1 < C::L / 2) issue_quad(i, p + 1);
+      }
+      // partial exchange through the idle quad buffer: wave (c, h) hands over its partial of column 1 - h
+      double* xchg = &s_key[0][0] + (size_t)wave * kN;
+      if (work) {
+#pragma unroll
+        for (int u = 0; u < kRegs; ++u) xchg[u * 64 + lane] = h ? s0[u] : s1[u];
+      }
+      __syncthreads();
+      double (&mine)[kRegs] = h ? s1 : s0;
+      if (work) {
+        const double* theirs = &s_key[0][0] + (size_t)(wave ^ 1) * kN;
+#pragma unroll
+        for (int u = 0; u < kRegs; ++u) mine[u] += theirs[u * 64 + lane];
+      }
+      __syncthreads();                           // partials consumed: the quad buffer may be refilled
+      if (i + 1 < n) issue_quad(i + 1, 0);
+      if (work) {
+        Xf::inverse_wg(lane, mine, tw, buf, f);
+#pragma unroll
+        for (int r = 0; r < kRegs; ++r) {
+          const int j = lane + 64 * r;
+          acc[j] = (int32_t)((uint32_t)acc[j] + (uint32_t)Xf::to_torus(mine[r], dev));
+        }
+        wave_lds_sync();
+      }
+    }
+
+    if (active) {
+      // tLweExtractLweSampleIndex(index 0): a'[0] = acc_a[0], a'[j] = -acc_a[N-j], b' = acc_b[0]
+      int32_t* out = a.u_out + ct * (kN + 1);
+      if (h == 0) {
+#pragma unroll
+        for (int r = 0; r < kRegs; ++r) {
+          const int j = lane + 64 * r;
+          out[j] = (j == 0) ? acc[0] : (int32_t)(0u - (uint32_t)acc[kN - j]);
+        }
+      } else if (lane == 0) {
+        out[kN] = acc[0];
+      }
     }
   }
   if (Xf::kCertificate) publish_certificate(dev, a.dev_flag, lane);
@@ -767,6 +921,14 @@ static hipError_t launch_br_xf(const BlindRotateArgs& a, int wpb, long num_cus, 
     if (!getenv("RS_NO_WG") && a.B >= 8L * num_cus) {
       const long groups = (a.B + 7) / 8;
       hipLaunchKernelGGL((blind_rotate_wg_kernel<Xf, 8>), dim3((unsigned)(groups < num_cus ? groups : num_cus)), dim3(512), 0, st, a);
+      return hipGetLastError();
+    }
+  }
+  if constexpr (Xf::kWorkgroupForm && Xf::Cfg::L % 2 == 0) {
+    // mid-size batches: 4 ciphertexts x 2 waves per workgroup (RS_NO_DUO falls back to one wave per ciphertext)
+    if (!getenv("RS_NO_WG") && !getenv("RS_NO_DUO") && a.B > 2L * num_cus) {
+      const long groups = (a.B + 3) / 4;
+      hipLaunchKernelGGL((blind_rotate_duo_kernel<Xf>), dim3((unsigned)(groups < num_cus ? groups : num_cus)), dim3(512), 0, st, a);
       return hipGetLastError();
     }
   }

@@ -202,17 +202,20 @@ def test_large_batch_truth_table_property(be_full_default, full_default):
     assert np.array_equal(sub, got[:37])
 
 
+@pytest.mark.parametrize("size", ["wg8", "duo"])
 @pytest.mark.parametrize("which,fix", [("be_toy_default", "toy_default"), ("be_toy_redsec", "toy_redsec")])
-def test_workgroup_kernel_ragged_groups_and_identity_steps(which, fix, request, monkeypatch):
-    """blind_rotate_wg_kernel (FFT mode, B >= 8 x #CUs): a batch whose last 8-ciphertext group is ragged
-    AND spills past one group per workgroup, with mask words forced to 0 so that some CMUX steps are the
-    identity (tfhe_blindRotate_FFT skips them; the lock-step waves must still keep their barriers).
-    Checked word for word against the per-wave kernel (RS_NO_WG) and, on a sample, against the oracle."""
+def test_workgroup_kernel_ragged_groups_and_identity_steps(which, fix, size, request, monkeypatch):
+    """The lock-step workgroup kernels of the FFT mode -- blind_rotate_wg_kernel (B >= 8 x #CUs, 8
+    ciphertexts per group) and blind_rotate_duo_kernel (2 x #CUs < B < 8 x #CUs, even l: 4 ciphertexts
+    x 2 waves) -- on a batch whose last group is ragged AND spills past one group per workgroup, with
+    mask words forced to 0 so that some CMUX steps are the identity (tfhe_blindRotate_FFT skips them;
+    the lock-step waves must still keep their barriers). Checked word for word against the per-wave
+    kernel (RS_NO_WG) and, on a sample, against the oracle."""
     import torch
     be = request.getfixturevalue(which)
     ks, ctx = request.getfixturevalue(fix)
     cus = be.info()["num_cus"]
-    B = 8 * cus + 3
+    B = 8 * cus + 3 if size == "wg8" else 4 * cus + 6
     bits, ct = _bits(ks, B, 4242)
     ct = ct.copy()
     ct[5, :3] = 0            # leading identity steps
