@@ -63,6 +63,7 @@ def main():
                     help="ring arithmetic of the blind rotation: fft = FP64 complex FFT (library default, exact after "
                          "rounding, run-time certificate); exact = NTT over a 51-bit prime (exact by construction)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="gates timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-exact-check", action="store_true", help="skip the full-batch cross-check against the exact-NTT mode")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xC0FFEE)
     args = ap.parse_args()
 
@@ -144,8 +145,18 @@ def main():
     got = out.cpu().numpy()
     decrypt_ok = bool(np.array_equal(sk.decrypt_bits(got), 1 - (bits_a & bits_b)))
 
+    # FFT mode: the WHOLE batch again through the exact-by-construction NTT kernels (outside the timed
+    # region), every output word compared on the device
+    all_equal_exact = None
+    if args.mode == "fft" and not args.no_exact_check:
+        be.set_mode("exact")
+        ref_exact = be.gate("NAND", ca, cb)
+        all_equal_exact = bool(torch.equal(ref_exact, out))
+        del ref_exact
+        be.set_mode("fft")
+
     # FFT mode: largest distance of any inverse-transform output from an integer over the whole run
-    # (exactness needs < 0.5; see DESIGN.md section 3b). None in the exact mode.
+    # (exactness needs < 0.5; see DESIGN.md section 4.1). None in the exact mode.
     certificate = round(be.rounding_certificate(), 6) if args.mode == "fft" else None
 
     total_gates = G * world
@@ -192,7 +203,10 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as ol
             cores = ol.lib().ro_max_threads()
-            sample = args.cpu_sample if args.cpu_sample > 0 else max(32, 2 * cores)
+            # the CPU baseline is an N=1 figure (torch.distributed.run also pins OMP_NUM_THREADS=1);
+            # multi-rank runs only keep a small in-run parity sample
+            timed_baseline = world == 1
+            sample = args.cpu_sample if args.cpu_sample > 0 else (max(32, 2 * cores) if timed_baseline else 4)
             sample = min(sample, G)
             op = ol.params(args.params)
 
@@ -205,9 +219,10 @@ def main():
             ref = octx.gate_batch("NAND", ca_h[:sample], cb_h[:sample])
             cpu_s = time.perf_counter() - t1
             parity = bool(np.array_equal(ref, got[:sample]))
-            cpu = {"value": round(sample / cpu_s, 3), "unit": "bootstraps/s", "cores": int(cores), "kind": "port",
-                   "sample": "%d NAND gates of the same batch (same keys, same inputs), %.1f s wall on %d OpenMP threads; "
-                             "exact-integer oracle, TFHE itself unavailable" % (sample, cpu_s, cores)}
+            if timed_baseline:
+                cpu = {"value": round(sample / cpu_s, 3), "unit": "bootstraps/s", "cores": int(cores), "kind": "port",
+                       "sample": "%d NAND gates of the same batch (same keys, same inputs), %.1f s wall on %d OpenMP threads; "
+                                 "exact-integer oracle, TFHE itself unavailable" % (sample, cpu_s, cores)}
 
         line = {
             "metric": "gate bootstraps/sec (N=1024)", "value": round(value, 1), "unit": "bootstraps/s",
@@ -220,6 +235,7 @@ def main():
             "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu,
             "kernels_ms": {"blind_rotate": round(last_br, 3), "keyswitch": round(last_ks, 3)},
             "checks": {"all_outputs_decrypt_to_nand": decrypt_ok, "bit_exact_vs_oracle_on_sample": parity,
+                       "all_words_equal_exact_ntt_mode_full_batch": all_equal_exact,
                        "fft_rounding_certificate": certificate},
             "setup_s": round(setup_s, 1),
         }
