@@ -95,6 +95,12 @@ int rs_get_mode(rs_ctx* ctx, int* mode);
 /* Largest |x - rint(x)| over every value the FFT path has rounded since the last reset (0 in NTT mode).
  * Anything far below 0.5 certifies that no rounding can have picked a neighbouring integer. */
 int rs_rounding_certificate(rs_ctx* ctx, double* max_distance, int reset);
+/* The synchronous host-pointer calls (rs_bootstrap, rs_gate, rs_mux) certify every call in FFT mode: if a
+ * call's largest rounding distance reaches RS_CERTIFICATE_LIMIT the batch is recomputed with the exact NTT
+ * before anything is returned. *count = how many calls took that fallback (expected: 0). The asynchronous
+ * *_dev calls leave the check to the caller (rs_rounding_certificate at its next synchronisation point). */
+#define RS_CERTIFICATE_LIMIT 0.25
+int rs_fft_fallbacks(rs_ctx* ctx, int64_t* count);
 
 /* Workspace is grown on demand; this pre-sizes it for batches of up to max_batch ciphertexts. */
 int rs_reserve(rs_ctx* ctx, size_t max_batch);

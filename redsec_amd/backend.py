@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "rs_load_keys", "rs_reserve", "rs_bootstrap_dev", "rs_bootstrap", "rs_gate_dev", "rs_gate", "rs_mux_dev", "rs_mux",
     "rs_gate_mu_dev", "rs_gather_rows_dev", "rs_bootstrap_wo_ks_dev", "rs_keyswitch_dev", "rs_debug_polymul", "rs_linear_fc_dev", "rs_conv_ternary_dev",
     "rs_sumpool_dev", "rs_lincomb_dev", "rs_dev_alloc", "rs_dev_free", "rs_copy_to_dev", "rs_copy_to_host", "rs_sync",
-    "rs_set_timing", "rs_last_kernel_ms", "rs_info", "rs_set_mode", "rs_get_mode", "rs_rounding_certificate",
+    "rs_set_timing", "rs_last_kernel_ms", "rs_info", "rs_set_mode", "rs_get_mode", "rs_rounding_certificate", "rs_fft_fallbacks",
 ]
 
 GATES = {"NAND": 0, "OR": 1, "AND": 2, "NOR": 3, "XOR": 4, "XNOR": 5, "ANDNY": 6, "ANDYN": 7, "ORNY": 8, "ORYN": 9}
@@ -97,6 +97,7 @@ def load_library(path=None):
     L.rs_set_mode.argtypes = [vp, C.c_int]
     L.rs_get_mode.argtypes = [vp, C.POINTER(C.c_int)]
     L.rs_rounding_certificate.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
+    L.rs_fft_fallbacks.argtypes = [vp, C.POINTER(C.c_int64)]
     if path is None:
         _lib = L
     return L
@@ -319,6 +320,12 @@ class Backend:
         d = C.c_double()
         _check(self.L, self.L.rs_rounding_certificate(self.h, C.byref(d), 1 if reset else 0))
         return d.value
+
+    def fft_fallbacks(self):
+        """Host-pointer calls that were recomputed in exact mode because their rounding distance reached 0.25."""
+        n = C.c_int64()
+        _check(self.L, self.L.rs_fft_fallbacks(self.h, C.byref(n)))
+        return n.value
 
     # ---- timing / facts ----
     def set_timing(self, on=True):

@@ -41,6 +41,7 @@ int fail(int code, const char* fmt, ...) {
 }  // namespace
 
 struct rs_ctx {
+  int64_t fft_fallbacks = 0;   // host calls recomputed in exact mode after a rounding distance >= RS_CERTIFICATE_LIMIT
   rs_params p{};
   int device = 0;
   int cfg = 0;  // 0 default128-shaped gadget, 1 redsec_v2-shaped gadget
@@ -371,9 +372,31 @@ static int host_roundtrip(rs_ctx* c, int32_t* out, const int32_t* const* ins, in
     if (!ins[i]) return fail(RS_ERR_INVALID, "null ciphertext pointer");
     RS_HIP(hipMemcpy(c->d_io[i], ins[i], bytes, hipMemcpyHostToDevice));
   }
+  // FFT mode: certify THIS call (the device flag is a running maximum: set it aside, restore the maximum after)
+  const bool certify = c->mode == RS_MODE_FFT && c->d_dev_flag;
+  unsigned long long before = 0, call = 0;
+  if (certify) {
+    RS_HIP(hipMemcpy(&before, c->d_dev_flag, sizeof before, hipMemcpyDeviceToHost));
+    RS_HIP(hipMemset(c->d_dev_flag, 0, sizeof before));
+  }
   rc = run(c, c->d_io[3], c->d_io, B, extra);
   if (rc) return rc;
   RS_HIP(hipDeviceSynchronize());
+  if (certify) {
+    RS_HIP(hipMemcpy(&call, c->d_dev_flag, sizeof call, hipMemcpyDeviceToHost));
+    const unsigned long long keep = call > before ? call : before;   // positive doubles order like their bit patterns
+    RS_HIP(hipMemcpy(c->d_dev_flag, &keep, sizeof keep, hipMemcpyHostToDevice));
+    double dist;
+    memcpy(&dist, &call, sizeof dist);
+    if (!(dist < RS_CERTIFICATE_LIMIT)) {   // never observed; recompute exactly rather than return an uncertified result
+      ++c->fft_fallbacks;
+      c->mode = RS_MODE_EXACT_NTT;
+      rc = run(c, c->d_io[3], c->d_io, B, extra);
+      c->mode = RS_MODE_FFT;
+      if (rc) return rc;
+      RS_HIP(hipDeviceSynchronize());
+    }
+  }
   RS_HIP(hipMemcpy(out, c->d_io[3], bytes, hipMemcpyDeviceToHost));
   return RS_OK;
 }
@@ -447,6 +470,12 @@ int rs_rounding_certificate(rs_ctx* c, double* max_distance, int reset) {
   RS_HIP(hipMemcpy(&bits, c->d_dev_flag, sizeof bits, hipMemcpyDeviceToHost));
   memcpy(max_distance, &bits, sizeof bits);
   if (reset) RS_HIP(hipMemset(c->d_dev_flag, 0, sizeof bits));
+  return RS_OK;
+}
+
+int rs_fft_fallbacks(rs_ctx* c, int64_t* count) {
+  if (!c || !count) return fail(RS_ERR_INVALID, "null argument");
+  *count = c->fft_fallbacks;
   return RS_OK;
 }
 

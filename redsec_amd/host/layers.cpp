@@ -527,6 +527,14 @@ DevSlab stage_input(LayerImpl* L, const void* key, const std::vector<const LweSa
 std::vector<int32_t> download(const DevSlab& s, int W) {
   std::vector<int32_t> host(s.rows * (size_t)W);
   RS_CHECK(rs_copy_to_host(s.ctx, host.data(), s.ptr, host.size() * 4));
+  // Layer chains stay on the device and run asynchronously; results become visible to the caller here,
+  // so this is where the FFT mode's running rounding certificate is checked (include/redsec_hip.h).
+  double dist = 0.0;
+  RS_CHECK(rs_rounding_certificate(s.ctx, &dist, 0));
+  if (!(dist < RS_CERTIFICATE_LIMIT)) {
+    fprintf(stderr, "redsec layers: FFT rounding certificate %.3f >= %.2f -- rerun with REDSEC_MODE=exact\n", dist, RS_CERTIFICATE_LIMIT);
+    abort();
+  }
   return host;
 }
 

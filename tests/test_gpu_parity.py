@@ -233,6 +233,23 @@ def test_workgroup_kernel_ragged_groups_and_identity_steps(which, fix, size, req
     assert np.array_equal(got.cpu().numpy()[sample], ctx.bootstrap_batch(ct[sample], mu))
 
 
+def test_host_calls_are_certified_without_fallbacks(be_toy_default, toy_default, arith_mode):
+    """rs_gate / rs_bootstrap with host pointers certify each FFT-mode call (include/redsec_hip.h
+    RS_CERTIFICATE_LIMIT) and keep the context's running maximum intact; no call needs the exact fallback."""
+    be = be_toy_default
+    ks, ctx = toy_default
+    _, ca = _bits(ks, 9, 1)
+    _, cb = _bits(ks, 9, 2)
+    be.rounding_certificate(reset=True)
+    got = be.gate_host("XOR", ca, cb)
+    assert np.array_equal(got, ctx.gate_batch("XOR", ca, cb))
+    first = be.rounding_certificate(reset=False)
+    be.gate_host("AND", ca, cb)
+    assert be.rounding_certificate(reset=False) >= first          # running maximum survives the per-call reset
+    assert (first > 0) == (arith_mode == "fft") and first < 0.25
+    assert be.fft_fallbacks() == 0
+
+
 def test_linear_stage_matches_oracle(be_toy_redsec, toy_redsec):
     be = be_toy_redsec
     ks, _ = toy_redsec
