@@ -396,16 +396,37 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs 
 // (bara == 0) only skip the arithmetic. Groups are assigned round-robin: all groups take the same
 // number of steps, so there is nothing to balance dynamically.
 // -------------------------------------------------------------------------------------------------
-// Direct global -> LDS load of 16 bytes per lane (1 KB per wavefront): the LDS destination is the
-// wave-uniform byte address in M0 plus lane * 16. Written as asm because hipcc puts a vmcnt(0) in front
-// of the next LDS read whenever it knows of a pending LDS-DMA, which would serialise the prefetch;
-// the kernel's own `s_waitcnt vmcnt(0)` + barrier orders the data instead.
-__device__ __forceinline__ void glds16(const double* gsrc_lane, const double* lds_wave_base) {
+// Direct global -> LDS loads, 16 bytes per lane = 1 KB per wave-instruction, NCHUNK consecutive KB:
+// global address = wave-uniform base (SGPR pair) + lane_off (one VGPR, lane * 16) + k KB; LDS address =
+// M0 + k KB + lane * 16 (the instruction offset advances both sides). Written as asm because (a) hipcc
+// puts a vmcnt(0) in front of the next LDS read whenever it knows of a pending LDS-DMA, which would
+// serialise the prefetch -- the kernels' own `s_waitcnt vmcnt(0)` + barrier orders the data instead;
+// (b) with per-lane 64-bit source pointers the compiler spilled around the issue point, and every
+// scratch reload there waits on vmcnt, i.e. on the key rows that were just requested.
+template <int NCHUNK>
+__device__ __forceinline__ void glds_chunks(const double* gsrc_wave_base, unsigned lane_off, const double* lds_wave_base) {
+  static_assert(NCHUNK >= 1 && NCHUNK <= 4, "instruction offsets are 13-bit signed");
   const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane(
       (int)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)lds_wave_base);
+  const unsigned long long base = (unsigned long long)(uintptr_t)gsrc_wave_base;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32));
+  const unsigned long long sbase = ((unsigned long long)hi << 32) | lo;
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_dst) : "memory");
+  if constexpr (NCHUNK == 1) {
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(sbase), "s"(lds_dst) : "memory");
+  } else if constexpr (NCHUNK == 2) {
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(sbase), "s"(lds_dst) : "memory");
+  } else {
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:3072\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(sbase), "s"(lds_dst) : "memory");
+    static_assert(NCHUNK == 4, "1, 2 or 4 chunks");
+  }
 }
 
 template <class Xf, int WPB>
@@ -415,7 +436,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
   constexpr int kRowDoubles = 2 * kN;             // one key row: 2 columns x N doubles = 16 KB
   constexpr int kChunks = kRowDoubles / 128;      // 1 KB pieces = one wave-wide 16-byte load each
   constexpr int kChunksPerWave = kChunks / WPB;
-  static_assert(kChunks % WPB == 0, "waves must split a key row evenly");
+  static_assert(kChunks % WPB == 0 && (kChunksPerWave == 1 || kChunksPerWave == 2 || kChunksPerWave == 4), "waves must split a key row evenly");
   __shared__ double s_tw[Xf::kTableDoubles + 1];
   __shared__ double s_buf[WPB][Xf::kWgBufDoubles];
   __shared__ int32_t s_acc[WPB][2][kN];
@@ -437,11 +458,10 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
   const long total_rows = (long)n * KPL;
 
   // my 1/WPB share of key row R -> ring slot R & 1
+  const unsigned lane_off = (unsigned)lane * 16u;
   auto issue_row = [&](long R) {
-    const double* src = a.bk_x + (size_t)R * kRowDoubles + (size_t)(wave * kChunksPerWave) * 128 + 2 * lane;
-    double* dst = s_key[R & 1] + (wave * kChunksPerWave) * 128;
-#pragma unroll
-    for (int c = 0; c < kChunksPerWave; ++c) glds16(src + c * 128, dst + c * 128);
+    glds_chunks<kChunksPerWave>(a.bk_x + (size_t)R * kRowDoubles + (size_t)(wave * kChunksPerWave) * 128, lane_off,
+                                s_key[R & 1] + (wave * kChunksPerWave) * 128);
   };
   auto mac_row = [&](double (&s0)[kRegs], double (&s1)[kRegs], const double (&x)[kRegs], int slot) {
     const double2* k0 = reinterpret_cast<const double2*>(s_key[slot]);
@@ -602,14 +622,15 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
   double dev = 0.0;
   const long n_groups = (a.B + kCts - 1) / kCts;
 
+  const unsigned lane_off = (unsigned)lane * 16u;
   // quad (i, p): rows i KPL + hh L + 2 p + k; this wave fetches half of slot (wave >> 1)
   auto issue_quad = [&](int i, int p) {
     const int slot = wave >> 1;
     const long R = (long)i * KPL + (slot >> 1) * C::L + 2 * p + (slot & 1);
-    const double* src = a.bk_x + (size_t)R * kRowDoubles + (size_t)((wave & 1) * 8) * 128 + 2 * lane;
+    const double* src = a.bk_x + (size_t)R * kRowDoubles + (size_t)((wave & 1) * 8) * 128;
     double* dst = s_key[slot] + ((wave & 1) * 8) * 128;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) glds16(src + k * 128, dst + k * 128);
+    glds_chunks<4>(src, lane_off, dst);
+    glds_chunks<4>(src + 4 * 128, lane_off, dst + 4 * 128);
   };
   auto mac_row = [&](double (&s0)[kRegs], double (&s1)[kRegs], const double (&x)[kRegs], int slot) {
     const double2* k0 = reinterpret_cast<const double2*>(s_key[slot]);
