@@ -41,6 +41,8 @@ int fail(int code, const char* fmt, ...) {
 }  // namespace
 
 struct rs_ctx {
+  uint32_t* d_conv_scratch = nullptr;   // expanded weights of the tiled convolution (grown on demand)
+  size_t conv_scratch_words = 0;
   int64_t fft_fallbacks = 0;   // host calls recomputed in exact mode after a rounding distance >= RS_CERTIFICATE_LIMIT
   rs_params p{};
   int device = 0;
@@ -239,7 +241,7 @@ int rs_destroy(rs_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   (void)hipFree(c->d_tw); (void)hipFree(c->d_tw_fft); (void)hipFree(c->d_bk_ntt); (void)hipFree(c->d_bk_fft); (void)hipFree(c->d_ksk);
-  (void)hipFree(c->d_dev_flag);
+  (void)hipFree(c->d_dev_flag); (void)hipFree(c->d_conv_scratch);
   (void)hipFree(c->d_u0); (void)hipFree(c->d_u1); (void)hipFree(c->d_counter);
   for (auto& p : c->d_io) (void)hipFree(p);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -511,6 +513,20 @@ int rs_conv_ternary_dev(rs_ctx* c, int32_t* out, const int32_t* in, const uint8_
     return fail(RS_ERR_INVALID, "bad convolution shape");
   if (bias_b && bias_depth < 1) return fail(RS_ERR_INVALID, "bias_depth must be >= 1");
   rs::ConvShape cs{s->H, s->Wd, s->Cin, s->Cout, s->fh, s->fw, s->stride_h, s->stride_w, s->off_h, s->off_w, s->Ho, s->Wo};
+  if (zero_tap_b == 0 && pad_tap_b == 0 && !getenv("RS_NO_CONV_TILED")) {
+    // BinFunc-style convolution (ternary-zero and padding taps contribute nothing): register-tiled kernel.
+    // The expanded weights live in a context-owned scratch buffer, rebuilt on every call (microseconds).
+    const size_t words = rs::conv_tiled_scratch_words(cs);
+    if (words > c->conv_scratch_words) {
+      RS_HIP(hipStreamSynchronize((hipStream_t)stream));   // a previous call may still be reading the old buffer
+      if (c->d_conv_scratch) RS_HIP(hipFree(c->d_conv_scratch));
+      c->d_conv_scratch = nullptr; c->conv_scratch_words = 0;
+      RS_HIP(hipMalloc(&c->d_conv_scratch, words * sizeof(uint32_t)));
+      c->conv_scratch_words = words;
+    }
+    RS_HIP(rs::launch_conv_ternary_tiled(out, in, sign, zero, cs, c->p.n + 1, bias_b, bias_depth, c->d_conv_scratch, (hipStream_t)stream));
+    return RS_OK;
+  }
   RS_HIP(rs::launch_conv_ternary(out, in, sign, zero, cs, c->p.n + 1, zero_tap_b, pad_tap_b, bias_b, bias_depth, (hipStream_t)stream));
   return RS_OK;
 }

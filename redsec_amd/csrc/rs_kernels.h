@@ -52,6 +52,9 @@ hipError_t launch_lincomb(int32_t* out, const int32_t* x, int32_t cx, const int3
 hipError_t launch_gather_rows(int32_t* out, const int32_t* in, const int32_t* idx, int W, long B, hipStream_t st);
 hipError_t launch_linear_fc(int32_t* out, const int32_t* in, const uint8_t* sign, const uint8_t* zero, int K, int M, int W,
                             int32_t zero_tap_b, const int32_t* bias_b, int bias_depth, hipStream_t st);
+size_t conv_tiled_scratch_words(const ConvShape& s);
+hipError_t launch_conv_ternary_tiled(int32_t* out, const int32_t* in, const uint8_t* sign, const uint8_t* zero, const ConvShape& s, int W,
+                                     const int32_t* bias_b, int bias_depth, uint32_t* scratch, hipStream_t st);
 hipError_t launch_conv_ternary(int32_t* out, const int32_t* in, const uint8_t* sign, const uint8_t* zero, const ConvShape& s, int W,
                                int32_t zero_tap_b, int32_t pad_tap_b, const int32_t* bias_b, int bias_depth, hipStream_t st);
 hipError_t launch_sumpool(int32_t* out, const int32_t* in, const PoolShape& s, int W, const int32_t* bias_b, int bias_depth,

@@ -254,6 +254,85 @@ __global__ __launch_bounds__(256) void conv_ternary_kernel(int32_t* __restrict__
   out[(((size_t)oh * s.Wo + ow) * s.Cout + od) * W + w] = (int32_t)acc;
 }
 
+// ---- register-tiled ternary convolution (the throughput form; used when the constant taps are 0) ----
+// The reference's ENCRYPTED convolution (lib/BinFunc.cpp:195-320) is a ternary (+1 / -1 / 0) "GEMM" over
+// LWE words: out[pix][od][w] = sum_taps s(tap, od) * in[tap(pix)][w]. One thread owns one word index w of
+// one output pixel and kConvTile output channels at once, so every input word is loaded ONCE per 32
+// channels (the first kernel re-read it for every channel: L2-bound at 1.5 % of the integer-add rate).
+// Weights are pre-expanded (conv_expand_kernel) to two masks per (tap, channel): nz = 0 for a ternary
+// zero else ~0, ng = ~0 for -1 else 0; they are wave-uniform, live in scalar registers, and
+//   acc += ((v & nz) ^ ng)          -- v_and_b32 + v_xad_u32, 2 vector ops per ternary MAC
+// gives +v, ~v = -v - 1 or 0. The missing "+1" of every negative tap is the per-channel constant
+// negtotal[od]; padding taps run with v = 0 and so stay consistent with it. Integer wrap-around adds are
+// order-independent, hence bit-exact against any other summation order.
+constexpr int kConvTile = 32;
+
+// masks[k][od_padded][2], negtotal[od_padded]; grid over k*od_padded / 256
+__global__ __launch_bounds__(256) void conv_expand_kernel(uint32_t* __restrict__ masks, const uint8_t* __restrict__ sign,
+                                                          const uint8_t* __restrict__ zero, int K, int Cout, int Cpad) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)K * Cpad) return;
+  const int k = (int)(i / Cpad), od = (int)(i % Cpad);
+  uint32_t nz = 0, ng = 0;
+  if (od < Cout) {
+    const size_t fi = (size_t)k * Cout + od;
+    const bool z = zero && zero[fi];
+    nz = z ? 0u : 0xFFFFFFFFu;
+    ng = (!z && !sign[fi]) ? 0xFFFFFFFFu : 0u;
+  }
+  masks[2 * i] = nz;
+  masks[2 * i + 1] = ng;
+}
+__global__ __launch_bounds__(256) void conv_negtotal_kernel(uint32_t* __restrict__ negtotal, const uint32_t* __restrict__ masks, int K, int Cpad) {
+  const int od = blockIdx.x * 256 + threadIdx.x;
+  if (od >= Cpad) return;
+  uint32_t n = 0;
+  for (int k = 0; k < K; ++k) n += masks[2 * ((size_t)k * Cpad + od) + 1] & 1u;
+  negtotal[od] = n;
+}
+
+// grid (ceil(W/128), Cpad/32, Ho*Wo)
+__global__ __launch_bounds__(128) void conv_ternary_tiled_kernel(int32_t* __restrict__ out, const int32_t* __restrict__ in,
+                                                                 const uint32_t* __restrict__ masks, const uint32_t* __restrict__ negtotal,
+                                                                 ConvShape s, int Cpad, int W, const int32_t* __restrict__ bias_b, int bias_depth) {
+  const int w = blockIdx.x * 128 + threadIdx.x;
+  const int od0 = blockIdx.y * kConvTile;
+  const int pix = blockIdx.z;
+  const int oh = pix / s.Wo, ow = pix % s.Wo;
+  const int wc = w < W ? w : W - 1;   // lanes past the row compute a duplicate and do not store
+  uint32_t acc[kConvTile];
+#pragma unroll
+  for (int c = 0; c < kConvTile; ++c) acc[c] = 0;
+  const uint32_t* mrow = masks + 2 * (size_t)od0;
+  for (int fh = 0; fh < s.fh; ++fh) {
+    const int ih = fh + oh * s.stride_h - s.off_h;
+    for (int fw = 0; fw < s.fw; ++fw) {
+      const int iw = fw + ow * s.stride_w - s.off_w;
+      const bool oob = (unsigned)ih >= (unsigned)s.H || (unsigned)iw >= (unsigned)s.Wd;
+      const int32_t* src = in + (((size_t)(oob ? 0 : ih) * s.Wd + (oob ? 0 : iw)) * s.Cin) * W + wc;
+      for (int di = 0; di < s.Cin; ++di) {
+        const uint32_t v = oob ? 0u : (uint32_t)src[(size_t)di * W];
+        const uint32_t* m = mrow + 2 * (size_t)((fh * s.fw + fw) * s.Cin + di) * Cpad;   // wave-uniform: scalar loads
+#pragma unroll
+        for (int c = 0; c < kConvTile; ++c) {
+          const uint32_t t = v & m[2 * c];
+          // acc = (t ^ ng) + acc in one instruction (hipcc emits v_xor + v_add for the C expression)
+          asm("v_xad_u32 %0, %1, %2, %0" : "+v"(acc[c]) : "v"(t), "s"(m[2 * c + 1]));
+        }
+      }
+    }
+  }
+  if (w >= W) return;
+#pragma unroll
+  for (int c = 0; c < kConvTile; ++c) {
+    const int od = od0 + c;
+    if (od >= s.Cout) break;
+    uint32_t r = acc[c] + negtotal[od];
+    if (w == W - 1 && bias_b) r += (uint32_t)bias_b[od % bias_depth];
+    out[(((size_t)oh * s.Wo + ow) * s.Cout + od) * W + w] = (int32_t)r;
+  }
+}
+
 // grid (ceil(W/256), C, Ho*Wo)
 __global__ __launch_bounds__(256) void sumpool_kernel(int32_t* __restrict__ out, const int32_t* __restrict__ in, PoolShape s, int W,
                                                       const int32_t* __restrict__ bias_b, int bias_depth) {
@@ -333,6 +412,24 @@ hipError_t launch_conv_ternary(int32_t* out, const int32_t* in, const uint8_t* s
                                int32_t zero_tap_b, int32_t pad_tap_b, const int32_t* bias_b, int bias_depth, hipStream_t st) {
   hipLaunchKernelGGL(conv_ternary_kernel, dim3((W + 255) / 256, s.Cout, s.Ho * s.Wo), dim3(256), 0, st, out, in, sign, zero, s, W,
                      zero_tap_b, pad_tap_b, bias_b, bias_depth);
+  return hipGetLastError();
+}
+
+// scratch: uint32[2 * K * Cpad + Cpad] with Cpad = Cout rounded up to kConvTile (conv_tiled_scratch_words)
+size_t conv_tiled_scratch_words(const ConvShape& s) {
+  const size_t K = (size_t)s.fh * s.fw * s.Cin, Cpad = (size_t)(s.Cout + kConvTile - 1) / kConvTile * kConvTile;
+  return 2 * K * Cpad + Cpad;
+}
+hipError_t launch_conv_ternary_tiled(int32_t* out, const int32_t* in, const uint8_t* sign, const uint8_t* zero, const ConvShape& s, int W,
+                                     const int32_t* bias_b, int bias_depth, uint32_t* scratch, hipStream_t st) {
+  const int K = s.fh * s.fw * s.Cin, Cpad = (s.Cout + kConvTile - 1) / kConvTile * kConvTile;
+  uint32_t* masks = scratch;
+  uint32_t* negtotal = scratch + 2 * (size_t)K * Cpad;
+  const long n = (long)K * Cpad;
+  hipLaunchKernelGGL(conv_expand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, masks, sign, zero, K, s.Cout, Cpad);
+  hipLaunchKernelGGL(conv_negtotal_kernel, dim3((Cpad + 255) / 256), dim3(256), 0, st, negtotal, masks, K, Cpad);
+  hipLaunchKernelGGL(conv_ternary_tiled_kernel, dim3((W + 127) / 128, Cpad / kConvTile, s.Ho * s.Wo), dim3(128), 0, st, out, in, masks,
+                     negtotal, s, Cpad, W, bias_b, bias_depth);
   return hipGetLastError();
 }
 

@@ -103,6 +103,24 @@ def test_linear_kernels_against_numpy():
                     acc[-1] += int(bias[od])
                     ref[oh, ow, od] = acc
         assert np.array_equal(got, (ref & 0xFFFFFFFF).astype(np.uint32).view(np.int32)), stride
+    # register-tiled form (32 channels per thread, constants 0) vs the one-output-per-thread kernel: a
+    # channel count that is not a multiple of the tile, a word count that is not a multiple of the block
+    import os
+    be2 = redsec_amd.Backend(redsec_amd.params("redsec_small_v2"), 0)
+    H2, Wd2, Cin2, Cout2 = 5, 4, 6, 70
+    x2 = torch.from_numpy(rng.integers(-2**31, 2**31, (H2, Wd2, Cin2, be2.W)).astype(np.int32)).cuda()
+    sign2 = torch.from_numpy(rng.integers(0, 2, (3, 3, Cin2, Cout2)).astype(np.uint8)).cuda()
+    zero2 = torch.from_numpy((rng.random((3, 3, Cin2, Cout2)) < 0.3).astype(np.uint8)).cuda()
+    bias2 = torch.from_numpy(rng.integers(-2**31, 2**31, Cout2).astype(np.int32)).cuda()
+    shape2 = dict(H=H2, Wd=Wd2, Cin=Cin2, Cout=Cout2, fh=3, fw=3, stride_h=1, stride_w=1, off_h=1, off_w=1, Ho=H2, Wo=Wd2)
+    tiled = be2.conv_ternary(x2, sign2, zero2, shape2, bias_b=bias2)
+    os.environ["RS_NO_CONV_TILED"] = "1"
+    try:
+        plain = be2.conv_ternary(x2, sign2, zero2, shape2, bias_b=bias2)
+    finally:
+        del os.environ["RS_NO_CONV_TILED"]
+    assert torch.equal(tiled, plain)
+    be2.close()
     # sum pooling 2x2 stride 2 (valid) and 3x3 stride 1 same-pad
     for win, stride, off, Ho, Wo in ((2, 2, 0, 3, 3), (3, 1, 1, 7, 6)):
         shape = dict(H=H, Wd=Wd, C=Cin, win_h=win, win_w=win, stride_h=stride, stride_w=stride, off_h=off, off_w=off, Ho=Ho, Wo=Wo)
