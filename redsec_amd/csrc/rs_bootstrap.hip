@@ -201,12 +201,6 @@ struct XfFft {
 
   // workgroup kernel: planar exchanges through a half-size per-wave buffer
   static constexpr int kWgBufDoubles = kPlaneDoubles;
-  __device__ static __forceinline__ void fwd_digits_wg(int lane, double (&x)[kRegs], const int32_t (&d)[kRegs], int q, uint32_t offset,
-                                                       const State& st, double* buf, const Field&) {
-#pragma unroll
-    for (int r = 0; r < kRegs; ++r) x[r] = (double)gadget_digit<C>(d[r], q, offset);
-    ffwd_planar(lane, x, st, buf, [] { wave_lds_sync(); });
-  }
   __device__ static __forceinline__ void inverse_wg(int lane, double (&x)[kRegs], const State& st, double* buf, const Field&) {
     finv_planar(lane, x, st, buf, [] { wave_lds_sync(); });
   }

@@ -282,14 +282,6 @@ RS_HD void fpl_exchange(int lane, double (&x)[kRegs], double* buf, Sync sync) {
   fpl_load<L1, T, 1>(lane, x, buf); sync();
 }
 template <class TW, class Sync>
-RS_HD void ffwd_planar(int lane, double (&x)[kRegs], const TW& t, double* buf, Sync sync) {
-  fft_stage_fwd<0>(x, t); fft_stage_fwd<1>(x, t); fft_stage_fwd<2>(x, t);
-  fpl_exchange<kLayA, kLayB, 1>(lane, x, buf, sync);
-  fft_stage_fwd<3>(x, t); fft_stage_fwd<4>(x, t); fft_stage_fwd<5>(x, t);
-  fpl_exchange<kLayB, kLayC, 2>(lane, x, buf, sync);
-  fft_stage_fwd<6>(x, t); fft_stage_fwd<7>(x, t); fft_stage_fwd<8>(x, t);
-}
-template <class TW, class Sync>
 RS_HD void finv_planar(int lane, double (&x)[kRegs], const TW& t, double* buf, Sync sync) {
   fft_stage_inv<8>(x, t); fft_stage_inv<7>(x, t); fft_stage_inv<6>(x, t);
   fpl_exchange<kLayC, kLayB, 2>(lane, x, buf, sync);
@@ -313,21 +305,12 @@ RS_HD void fil_load(int lane, double (&x)[kRegs], const double* buf) {
 #pragma unroll
   for (int k = 0; k < kCRegs; ++k) { const int j = flay_index<LAY>(lane, k); fbuf_load(buf, T == 1 ? fpos_t1(j) : fpos_t2(j), x[k], x[k + 8]); }
 }
-// PLANAR: one 8-byte plane at a time through a kPlaneDoubles buffer; else (re, im) pairs through kBufDoubles
-template <bool PLANAR, int L0, int L1, int T, class Sync>
-RS_HD void fft_exchange(int lane, double (&x)[kRegs], double* buf, Sync sync) {
-  if (PLANAR) {
-    fpl_exchange<L0, L1, T>(lane, x, buf, sync);
-  } else {
-    fil_store<L0, T>(lane, x, buf); sync();
-    fil_load<L1, T>(lane, x, buf); sync();
-  }
-}
 template <int G, class TW>
 RS_HD void fft_fwd3(double (&x)[kRegs], const TW& t) { fft_stage_fwd<3 * G>(x, t); fft_stage_fwd<3 * G + 1>(x, t); fft_stage_fwd<3 * G + 2>(x, t); }
 template <int G, class TW>
 RS_HD void fft_inv3(double (&x)[kRegs], const TW& t) { fft_stage_inv<3 * G + 2>(x, t); fft_stage_inv<3 * G + 1>(x, t); fft_stage_inv<3 * G>(x, t); }
 
+// PLANAR: one 8-byte plane at a time through a kPlaneDoubles buffer; else (re, im) pairs through kBufDoubles.
 // Exchange of x with `work(0..2)` -- three butterfly stages of the OTHER transform -- placed between
 // its LDS phases, so that the vector ALU has independent work while the stores drain (a 16-byte-per-
 // lane store occupies the LDS issue path for ~13 cycles) and the loads return.
