@@ -113,6 +113,38 @@ def test_toy_all_gates_and_mux(which, fix, request):
     assert np.array_equal(got, ctx.mux_batch(ca, cb, cc))
 
 
+def test_batched_ripple_carry_adder(be_full_default, full_default):
+    """BinOps::add (lib/BinOps_enc.cpp:55-119: per bit 2 XOR + 2 AND + 1 OR, the full-adder popcount
+    pattern) with every gate level run as ONE batch over all the additions: 96 independent 4-bit sums,
+    each gate batch equal to the oracle's word for word, the decrypted sums equal to a + b mod 16."""
+    be = be_full_default
+    ks, ctx = full_default
+    B, bits = 96, 4
+    rng = np.random.default_rng(99)
+    xa, xb = rng.integers(0, 16, B), rng.integers(0, 16, B)
+    e8 = ol.to_torus(1, 8)
+    enc = lambda v, seed: [ks.encrypt(np.where((v >> i) & 1, e8, -e8), ALPHA, seed + i) for i in range(bits)]
+    ca, cb = enc(xa, 1000), enc(xb, 2000)
+
+    def gate(op, u, v):
+        got = be.gate(op, _dev(u), _dev(v)).cpu().numpy()
+        assert np.array_equal(got, ctx.gate_batch(op, u, v)), op
+        return got
+    out = []
+    carry = None
+    for i in range(bits):
+        t0 = gate("XOR", ca[i], cb[i])
+        if carry is None:                      # carry-in is the constant 0 (bootsCONSTANT): sum = a ^ b, carry = a & b
+            out.append(t0)
+            carry = gate("AND", ca[i], cb[i])
+            continue
+        out.append(gate("XOR", carry, t0))
+        if i + 1 < bits:
+            carry = gate("OR", gate("AND", carry, t0), gate("AND", ca[i], cb[i]))
+    total = sum(((ks.phase(o) > 0).astype(int) << i) for i, o in enumerate(out))
+    assert np.array_equal(total, (xa + xb) % 16)
+
+
 @pytest.mark.parametrize("which,fix", [("be_toy_default", "toy_default"), ("be_toy_redsec", "toy_redsec")])
 def test_keyswitch_tile_boundaries(which, fix, request):
     """Tiled keyswitch: 256-ciphertext tiles, 32-word chunks (W = 25 / 21 here: one partial chunk);
