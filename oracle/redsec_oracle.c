@@ -341,6 +341,9 @@ struct ro_ctx {
   gl_tables* tb;
   uint64_t* bk_ntt;    /* [n][kpl][k+1][N] forward transforms of BK rows */
   int use_schoolbook;
+  int use_fft;
+  double* bk_fft;      /* [n][kpl][k+1][N/2][2] folded complex FFT of BK rows, scaled by 2/N (built on demand) */
+  double* fft_tw;      /* [N/2][2] exp(2 pi i j / (N/2)); [N/2][2] twist exp(i pi j / N) after it */
   uint32_t offset;     /* gadget rounding offset */
 };
 
@@ -366,9 +369,70 @@ ro_ctx* ro_ctx_create(const ro_params* p, const int32_t* bk, const int32_t* ksk)
 }
 void ro_ctx_destroy(ro_ctx* c) {
   if (!c) return;
-  gl_tables_destroy(c->tb); free(c->bk_ntt); free(c);
+  gl_tables_destroy(c->tb); free(c->bk_ntt); free(c->bk_fft); free(c->fft_tw); free(c);
 }
 void ro_ctx_set_schoolbook(ro_ctx* c, int use_schoolbook) { c->use_schoolbook = use_schoolbook; }
+
+/* ---- double-precision path (ro_ctx_set_fft) ----------------------------------------------------
+ * Negacyclic product of real polynomials through an M = N/2 point complex FFT: fold z_j = a_j + i a_{j+M},
+ * twist by zeta^j (zeta = exp(i pi / N)), cyclic DFT; then products are pointwise. Plain iterative
+ * radix-2 (decimation in frequency forward, decimation in time inverse, so no bit reversal is needed
+ * between them). */
+static void fft_tables(ro_ctx* c) {
+  const int32_t M = c->p.N / 2;
+  c->fft_tw = (double*)malloc(sizeof(double) * 4 * (size_t)M);
+  const long double pi = 3.141592653589793238462643383279502884L;
+  for (int32_t j = 0; j < M; ++j) {
+    c->fft_tw[2 * j] = (double)cosl(2 * pi * j / M);
+    c->fft_tw[2 * j + 1] = (double)sinl(2 * pi * j / M);
+    c->fft_tw[2 * M + 2 * j] = (double)cosl(pi * j / c->p.N);
+    c->fft_tw[2 * M + 2 * j + 1] = (double)sinl(pi * j / c->p.N);
+  }
+}
+/* in-place forward DFT (e^{+2 pi i jk/M}), output in bit-reversed order */
+static void fft_dif(double* z, int32_t M, const double* tw) {
+  for (int32_t half = M / 2, step = 1; half >= 1; half >>= 1, step <<= 1)
+    for (int32_t base = 0; base < M; base += 2 * half)
+      for (int32_t j = 0; j < half; ++j) {
+        double* a = z + 2 * (base + j); double* b = z + 2 * (base + j + half);
+        const double wr = tw[2 * j * step], wi = tw[2 * j * step + 1];
+        const double dr = a[0] - b[0], di = a[1] - b[1];
+        a[0] += b[0]; a[1] += b[1];
+        b[0] = dr * wr - di * wi; b[1] = dr * wi + di * wr;
+      }
+}
+/* in-place inverse (conjugate twiddles) from bit-reversed order back to natural order, unscaled */
+static void fft_dit_inv(double* z, int32_t M, const double* tw) {
+  for (int32_t half = 1, step = M / 2; half < M; half <<= 1, step >>= 1)
+    for (int32_t base = 0; base < M; base += 2 * half)
+      for (int32_t j = 0; j < half; ++j) {
+        double* a = z + 2 * (base + j); double* b = z + 2 * (base + j + half);
+        const double wr = tw[2 * j * step], wi = -tw[2 * j * step + 1];
+        const double tr = b[0] * wr - b[1] * wi, ti = b[0] * wi + b[1] * wr;
+        b[0] = a[0] - tr; b[1] = a[1] - ti;
+        a[0] += tr; a[1] += ti;
+      }
+}
+static void fft_forward_i32(double* z, const int32_t* poly, const ro_ctx* c, double scale) {
+  const int32_t M = c->p.N / 2;
+  const double* twist = c->fft_tw + 2 * M;
+  for (int32_t j = 0; j < M; ++j) {
+    const double re = scale * (double)poly[j], im = scale * (double)poly[j + M];
+    z[2 * j] = re * twist[2 * j] - im * twist[2 * j + 1];
+    z[2 * j + 1] = re * twist[2 * j + 1] + im * twist[2 * j];
+  }
+  fft_dif(z, M, c->fft_tw);
+}
+void ro_ctx_set_fft(ro_ctx* c, int use_fft) {
+  c->use_fft = use_fft;
+  if (!use_fft || c->bk_fft) return;
+  fft_tables(c);
+  const size_t polys = ro_bk_words(&c->p) / (size_t)c->p.N;
+  c->bk_fft = (double*)malloc(sizeof(double) * polys * (size_t)c->p.N);
+#pragma omp parallel for schedule(static)
+  for (long long q = 0; q < (long long)polys; ++q)
+    fft_forward_i32(c->bk_fft + (size_t)q * c->p.N, c->bk + (size_t)q * c->p.N, c, 2.0 / c->p.N);   /* 1/M folded into the key */
+}
 
 /* TFHE polynomials.cpp torusPolynomialMulByXaiMinusOne: result = (X^a - 1) * source, 0 <= a < 2N. */
 static void mul_by_xai_minus_one(int32_t* out, int32_t a, const int32_t* in, int32_t N) {
@@ -427,6 +491,36 @@ static void cmux_step(const ro_ctx* c, int32_t* acc, int32_t i, int32_t barai, i
         int32_t* dst = acc + (size_t)col * N;
         for (int32_t j = 0; j < N; ++j) dst[j] = (int32_t)((uint32_t)dst[j] + (uint32_t)prod[j]);
       }
+    return;
+  }
+  if (c->use_fft) {
+    const int32_t M = N / 2;
+    double* zd = (double*)scratch_u64;                /* [N] one digit transform (M complex) */
+    double* zacc = zd + N;                            /* [k+1][N] */
+    memset(zacc, 0, sizeof(double) * (size_t)(k + 1) * N);
+    for (int32_t row = 0; row < kpl; ++row) {
+      fft_forward_i32(zd, digits + (size_t)row * N, c, 1.0);
+      for (int32_t col = 0; col <= k; ++col) {
+        const double* kp = c->bk_fft + ((((size_t)i * kpl + row) * (size_t)(k + 1)) + col) * (size_t)N;
+        double* dst = zacc + (size_t)col * N;
+        for (int32_t j = 0; j < M; ++j) {
+          dst[2 * j] += zd[2 * j] * kp[2 * j] - zd[2 * j + 1] * kp[2 * j + 1];
+          dst[2 * j + 1] += zd[2 * j] * kp[2 * j + 1] + zd[2 * j + 1] * kp[2 * j];
+        }
+      }
+    }
+    const double* twist = c->fft_tw + 2 * M;
+    for (int32_t col = 0; col <= k; ++col) {
+      double* z = zacc + (size_t)col * N;
+      fft_dit_inv(z, M, c->fft_tw);
+      int32_t* dst = acc + (size_t)col * N;
+      for (int32_t j = 0; j < M; ++j) {                /* untwist by conj(zeta^j), round to the integer */
+        const double re = z[2 * j] * twist[2 * j] + z[2 * j + 1] * twist[2 * j + 1];
+        const double im = z[2 * j + 1] * twist[2 * j] - z[2 * j] * twist[2 * j + 1];
+        dst[j] = (int32_t)((uint32_t)dst[j] + (uint32_t)(uint64_t)(int64_t)llrint(re));
+        dst[j + M] = (int32_t)((uint32_t)dst[j + M] + (uint32_t)(uint64_t)(int64_t)llrint(im));
+      }
+    }
     return;
   }
   uint64_t* fd = scratch_u64;                         /* [N] one digit transform */

@@ -96,6 +96,12 @@ ro_ctx* ro_ctx_create(const ro_params* p, const int32_t* bk, const int32_t* ksk)
 void ro_ctx_destroy(ro_ctx* c);
 /* use_schoolbook != 0 switches the external product to the O(N^2) definitional path (slow). */
 void ro_ctx_set_schoolbook(ro_ctx* c, int use_schoolbook);
+/* use_fft != 0 switches the external product to a double-precision folded complex FFT rounded to the
+ * nearest integer -- the arithmetic CLASS of TFHE's own CPU library (Lagrange half-complex FFT), and
+ * the fast CPU path bench.py times as `cpu_baseline`. Exact after rounding with overwhelming
+ * probability (checked against the exact NTT path in tests/test_oracle_kat.py); the PARITY CHECKS
+ * always use the exact paths. The first call transforms the bootstrapping key (not thread-safe). */
+void ro_ctx_set_fft(ro_ctx* c, int use_fft);
 
 /* tfhe_bootstrap_woKS_FFT semantics, exact: in [n+1] -> out [k*N+1] under the extracted key. */
 void ro_bootstrap_wo_ks(const ro_ctx* c, int32_t* out_extracted, int32_t mu, const int32_t* in);

@@ -68,6 +68,7 @@ def lib():
     L.ro_ctx_create.argtypes = [P, _i32p, _i32p]; L.ro_ctx_create.restype = C.c_void_p
     L.ro_ctx_destroy.argtypes = [C.c_void_p]
     L.ro_ctx_set_schoolbook.argtypes = [C.c_void_p, C.c_int]
+    L.ro_ctx_set_fft.argtypes = [C.c_void_p, C.c_int]
     L.ro_bootstrap_wo_ks.argtypes = [C.c_void_p, _i32p, C.c_int32, _i32p]
     L.ro_keyswitch.argtypes = [C.c_void_p, _i32p, _i32p]
     L.ro_bootstrap.argtypes = [C.c_void_p, _i32p, C.c_int32, _i32p]
@@ -187,6 +188,10 @@ class Ctx:
 
     def set_schoolbook(self, flag):
         lib().ro_ctx_set_schoolbook(self.h, int(flag))
+
+    def set_fft(self, flag):
+        """Double-precision FFT products (fast; the cpu_baseline path). Parity checks use the exact default."""
+        lib().ro_ctx_set_fft(self.h, int(flag))
 
     def bootstrap_batch(self, x, mu):
         x = np.ascontiguousarray(x, np.int32)

@@ -75,6 +75,21 @@ def test_bootstrap_ntt_path_equals_schoolbook_path(toy_default, toy_redsec):
         assert np.array_equal(fast, slow)
 
 
+def test_bootstrap_fft_path_equals_exact_path(toy_default, toy_redsec):
+    """ro_ctx_set_fft: the double-precision folded FFT (the class of arithmetic TFHE's CPU library uses,
+    timed by bench.py as cpu_baseline) rounds to exactly the integer products of the exact NTT path."""
+    for ks, ctx in (toy_default, toy_redsec):
+        mu = ol.to_torus(1, 8)
+        ct = ks.encrypt([mu, -mu, mu, -mu, mu], ALPHA, 6)
+        exact = ctx.gate_batch("XOR", ct, ct[::-1].copy())
+        ctx.set_fft(True)
+        try:
+            fast = ctx.gate_batch("XOR", ct, ct[::-1].copy())
+        finally:
+            ctx.set_fft(False)
+        assert np.array_equal(fast, exact)
+
+
 TRUTH = {
     "NAND": lambda a, b: 1 - (a & b), "AND": lambda a, b: a & b, "OR": lambda a, b: a | b,
     "NOR": lambda a, b: 1 - (a | b), "XOR": lambda a, b: a ^ b, "XNOR": lambda a, b: 1 - (a ^ b),
