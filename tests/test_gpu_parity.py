@@ -282,6 +282,34 @@ def test_host_calls_are_certified_without_fallbacks(be_toy_default, toy_default,
     assert be.fft_fallbacks() == 0
 
 
+@pytest.mark.parametrize("which", ["be_full_default", "be_full_redsec"])
+def test_structured_inputs_fft_equals_exact_mode(which, request):
+    """Adversarially regular ciphertext words (all 0, all ~0, 0x80000000, alternating, one-hot masks): the
+    FFT mode's rounded products must still equal the exact-NTT mode's word for word -- the key, not the
+    input, randomises the products -- and the rounding certificate stays far from 1/2."""
+    import torch
+    be = request.getfixturevalue(which)
+    n, W = be.p.n, be.W
+    pats = [np.zeros(W, np.int64), np.full(W, -1), np.full(W, -2**31), np.full(W, 2**31 - 1),
+            np.where(np.arange(W) % 2 == 0, 0x55555555, -0x55555556), (np.arange(W) * 0x01010101) & 0xFFFFFFFF]
+    for hot in (0, n // 2, n - 1):
+        v = np.zeros(W, np.int64); v[hot] = 1 << 21; pats.append(v)          # exactly one CMUX step with bara = 1
+    x = np.stack([(p & 0xFFFFFFFF).astype(np.uint32).view(np.int32) for p in pats])
+    x = np.concatenate([x, x[::-1] ^ 0x0F0F0F0F])
+    d = _dev(x)
+    prev = be.mode()
+    try:
+        be.set_mode("fft"); be.rounding_certificate(reset=True)
+        a = be.bootstrap(d, 1 << 29); g = be.gate("XNOR", d, torch.flip(d, [0]).contiguous())
+        cert = be.rounding_certificate(reset=True)
+        be.set_mode("exact")
+        assert torch.equal(a, be.bootstrap(d, 1 << 29))
+        assert torch.equal(g, be.gate("XNOR", d, torch.flip(d, [0]).contiguous()))
+    finally:
+        be.set_mode(prev)
+    assert cert < 0.2
+
+
 def test_linear_stage_matches_oracle(be_toy_redsec, toy_redsec):
     be = be_toy_redsec
     ks, _ = toy_redsec
