@@ -64,6 +64,37 @@ def test_sign1024x1_encrypted_inference_layerwise():
     assert agree >= 2      # statistical; the reference itself is not deterministic here
 
 
+def test_sign1024x1_encrypted_inference_equals_cpu_oracle_chain_word_for_word():
+    """BASELINE configs[2] against configs[0]: the WHOLE encrypted sign1024x1 inference (1,220 bootstraps)
+    on the GPU and on the CPU oracle chain (tests/oracle_net.py), same key, same encrypted image -- every
+    intermediate tensor and the 10 logit ciphertexts must be equal word for word."""
+    import torch
+    import redsec_amd
+    from redsec_amd import client, nets
+    import oracle_lib as ol
+    import oracle_net
+    sk = client.SecretKeySet("redsec_small_v2", seed=11)
+    be = redsec_amd.Backend(redsec_amd.params("redsec_small_v2"), 0)
+    be.load_keys(sk.bk, sk.ksk)
+    net = pm.load_net("sign1024x1")
+    labels, pixels = pm.load_images()
+    ct = sk.encrypt_image(pixels[3], seed=8)
+
+    class _K:
+        pass
+    k = _K(); k.p = ol.params("redsec_small_v2"); k.bk = sk.bk.ravel(); k.ksk = sk.ksk.ravel()
+    octx = ol.Ctx(k)
+    octx.set_fft(True)          # the fast CPU path; bit-equal to the exact paths (tests/test_oracle_kat.py)
+    cpu_taps, gpu_taps = {}, {}
+    cpu = oracle_net.run(octx, net, ct, cpu_taps)
+    gpu = nets.EncryptedMnist(be, net).run(torch.from_numpy(ct).cuda(), gpu_taps)
+    for name in ("pre0", "bits0", "pre1", "bits1"):
+        assert np.array_equal(gpu_taps[name].cpu().numpy().reshape(cpu_taps[name].shape), cpu_taps[name]), name
+    assert np.array_equal(gpu.cpu().numpy(), cpu)
+    assert be.rounding_certificate() < 0.2
+    be.close()
+
+
 def test_linear_kernels_against_numpy():
     """sumpool / conv_ternary index math (get_input_i / get_filter_i / get_output_i of
     lib/BinFunc.cpp:373-402) on random words, incl. same-padding, stride 2 and the IntFunc constants."""
