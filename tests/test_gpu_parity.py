@@ -310,6 +310,31 @@ def test_structured_inputs_fft_equals_exact_mode(which, request):
     assert cert < 0.2
 
 
+def test_two_contexts_interleaved_on_a_side_stream(be_toy_default, toy_default, be_toy_redsec, toy_redsec):
+    """Two contexts (different parameter sets, different keys) alive at once, their calls interleaved on a
+    non-default HIP stream: every result still equals its own oracle's (no shared mutable state besides the
+    per-context workspaces; the launch stream is the caller's)."""
+    import torch
+    ks_a, ctx_a = toy_default
+    ks_b, ctx_b = toy_redsec
+    _, a0 = _bits(ks_a, 70, 5); _, a1 = _bits(ks_a, 70, 6)
+    _, b0 = _bits(ks_b, 41, 7); _, b1 = _bits(ks_b, 41, 8)
+    side = torch.cuda.Stream()
+    da0, da1, db0, db1 = _dev(a0), _dev(a1), _dev(b0), _dev(b1)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        ra = be_toy_default.gate("XOR", da0, da1)
+        rb = be_toy_redsec.gate("ORYN", db0, db1)
+        ra2 = be_toy_default.gate("NOR", ra, da1)         # consumes the first result on the same stream
+        rb2 = be_toy_redsec.bootstrap(rb, ol.to_torus(1, 8))
+    side.synchronize()
+    ea = ctx_a.gate_batch("XOR", a0, a1)
+    eb = ctx_b.gate_batch("ORYN", b0, b1)
+    assert np.array_equal(ra.cpu().numpy(), ea) and np.array_equal(rb.cpu().numpy(), eb)
+    assert np.array_equal(ra2.cpu().numpy(), ctx_a.gate_batch("NOR", ea, a1))
+    assert np.array_equal(rb2.cpu().numpy(), ctx_b.bootstrap_batch(eb, ol.to_torus(1, 8)))
+
+
 def test_linear_stage_matches_oracle(be_toy_redsec, toy_redsec):
     be = be_toy_redsec
     ks, _ = toy_redsec
