@@ -48,6 +48,7 @@ struct XfNtt {
   static constexpr bool kCertificate = false;
   static constexpr bool kSplitKeyLoads = false;   // whole key row prefetched across the transform
   static constexpr bool kWorkgroupForm = false;
+  static constexpr bool kPreparedDigits = false;  // digits extracted from the raw rotated difference
   struct State { const double* tw; };
   __device__ static __forceinline__ void init(State& st, int, const double* tw_lds, const double*) { st.tw = tw_lds; }
 
@@ -137,6 +138,7 @@ struct XfFft {
   static constexpr bool kCertificate = true;
   static constexpr bool kSplitKeyLoads = true;    // second half of the key row fetched after the transform
   static constexpr bool kWorkgroupForm = true;    // blind_rotate_wg_kernel available
+  static constexpr bool kPreparedDigits = true;   // d[] = gadget_prepare(rotated difference): one v_bfe_i32 per digit
   // Twiddles are read from the LDS table at every use: keeping the 21 complex values of a lane in
   // registers (FftTw) spilled 250 B/lane to scratch at the 256-VGPR budget and cost 40 % (scratch
   // reloads share vmcnt with the in-flight key-row loads).
@@ -156,7 +158,7 @@ struct XfFft {
   __device__ static __forceinline__ void fwd_digits(int lane, double (&x)[kRegs], const int32_t (&d)[kRegs], int q, uint32_t offset,
                                                     const State& st, double* buf, const Field& f) {
 #pragma unroll
-    for (int r = 0; r < kRegs; ++r) x[r] = (double)gadget_digit<C>(d[r], q, offset);
+    for (int r = 0; r < kRegs; ++r) x[r] = (double)gadget_digit_prepared<C>(d[r], q);
     fwd_generic(lane, x, st, buf, f);
   }
   // key values scaled by 1/M (exact power of two); stored as (re, im) of position 8 lane + v
@@ -204,9 +206,9 @@ struct XfFft {
   __device__ static __forceinline__ void inverse_wg(int lane, double (&x)[kRegs], const State& st, double* buf, const Field&) {
     finv_planar(lane, x, st, buf, [] { wave_lds_sync(); });
   }
-  __device__ static __forceinline__ void digits(double (&x)[kRegs], const int32_t (&d)[kRegs], int q, uint32_t offset) {
+  __device__ static __forceinline__ void digits(double (&x)[kRegs], const int32_t (&d)[kRegs], int q) {
 #pragma unroll
-    for (int r = 0; r < kRegs; ++r) x[r] = (double)gadget_digit<C>(d[r], q, offset);
+    for (int r = 0; r < kRegs; ++r) x[r] = (double)gadget_digit_prepared<C>(d[r], q);
   }
   __device__ static __forceinline__ void fwd_pair_wg(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const State& st, double* buf) {
     ffwd_pair<true>(lane, xa, xb, st, buf, [] { wave_lds_sync(); });
@@ -318,7 +320,10 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs 
         const int32_t* accc = comp ? acc1 : acc0;
         int32_t d[kRegs];
 #pragma unroll
-        for (int r = 0; r < kRegs; ++r) d[r] = rotated_diff(accc, lane + 64 * r, bara);
+        for (int r = 0; r < kRegs; ++r) {
+          d[r] = rotated_diff(accc, lane + 64 * r, bara);
+          if (Xf::kPreparedDigits) d[r] = gadget_prepare<C>(d[r]);
+        }
 #pragma unroll 1
         for (int q = 0; q < C::L; ++q) {
           const int row = comp * C::L + q;
@@ -512,17 +517,18 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
       auto pair = [&](int compA, int qA, int compB, int qB) {
         double xa[kRegs], xb[kRegs];
         if (work) {
-          // d holds the rotated difference PLUS the gadget offset (added once per component, not per digit row)
+          // d holds the PREPARED rotated difference (gadget offset added and field sign bits flipped once
+          // per component, not per digit row)
           if (qA == 0) {
 #pragma unroll
-            for (int r = 0; r < kRegs; ++r) d[r] = (int32_t)((uint32_t)rotated_diff(compA ? acc1 : acc0, lane + 64 * r, bara) + offset);
+            for (int r = 0; r < kRegs; ++r) d[r] = gadget_prepare<C>(rotated_diff(compA ? acc1 : acc0, lane + 64 * r, bara));
           }
-          Xf::digits(xa, d, qA, 0u);
+          Xf::digits(xa, d, qA);
           if (qB == 0) {
 #pragma unroll
-            for (int r = 0; r < kRegs; ++r) d[r] = (int32_t)((uint32_t)rotated_diff(compB ? acc1 : acc0, lane + 64 * r, bara) + offset);
+            for (int r = 0; r < kRegs; ++r) d[r] = gadget_prepare<C>(rotated_diff(compB ? acc1 : acc0, lane + 64 * r, bara));
           }
-          Xf::digits(xb, d, qB, 0u);
+          Xf::digits(xb, d, qB);
           Xf::fwd_pair_wg(lane, xa, xb, tw, buf);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -670,14 +676,14 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
       int32_t d[kRegs];
       if (work) {
 #pragma unroll
-        for (int r = 0; r < kRegs; ++r) d[r] = (int32_t)((uint32_t)rotated_diff(acc, lane + 64 * r, bara) + offset);
+        for (int r = 0; r < kRegs; ++r) d[r] = gadget_prepare<C>(rotated_diff(acc, lane + 64 * r, bara));
       }
 #pragma unroll 1
       for (int p = 0; p < C::L / 2; ++p) {
         double xa[kRegs], xb[kRegs];
         if (work) {
-          Xf::digits(xa, d, 2 * p, 0u);
-          Xf::digits(xb, d, 2 * p + 1, 0u);
+          Xf::digits(xa, d, 2 * p);
+          Xf::digits(xb, d, 2 * p + 1);
           Xf::fwd_pair_wg(lane, xa, xb, tw, buf);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -788,7 +794,10 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateAr
     const double* bk_i = a.bk_x + (size_t)i * KPL * 2 * kN;
     int32_t d[kRegs];
 #pragma unroll
-    for (int r = 0; r < kRegs; ++r) d[r] = rotated_diff(s_acc[comp], lane + 64 * r, bara);
+    for (int r = 0; r < kRegs; ++r) {
+      d[r] = rotated_diff(s_acc[comp], lane + 64 * r, bara);
+      if (Xf::kPreparedDigits) d[r] = gadget_prepare<C>(d[r]);
+    }
 #pragma unroll 1
     for (int rr = 0; rr < R; ++rr) {
       const int row = row_begin + rr;

@@ -251,7 +251,7 @@ int emu_blind_rotate_fft(int n, const int32_t* in0, const int32_t* in1, int32_t 
         const double* bp0 = bk_i + (size_t)(row * 2) * kN;
         const double* bp1 = bp0 + kN;
         for (int l = 0; l < kLanes; ++l)
-          for (int r = 0; r < kRegs; ++r) x.x[l][r] = (double)rs::gadget_digit<C>(rs::rotated_diff(accc, l + 64 * r, bara), q, offset);
+          for (int r = 0; r < kRegs; ++r) x.x[l][r] = (double)rs::gadget_digit_prepared<C>(rs::gadget_prepare<C>(rs::rotated_diff(accc, l + 64 * r, bara)), q);
         emu_fft_forward(x, tw.data(), buf.data());
         for (int l = 0; l < kLanes; ++l)
           for (int v = 0; v < 8; ++v) {
@@ -400,6 +400,25 @@ int rs_emu_forward_digits(int cfg, const int32_t* coef, int q, double* out) {
   for (int lane = 0; lane < kLanes; ++lane)
     for (int u = 0; u < kRegs; ++u) out[16 * lane + u] = w.x[lane][u];
   return 0;
+}
+
+// Number of inputs d = start + t * step (t < count, mod 2^32) for which the one-instruction digit
+// (gadget_prepare + gadget_digit_prepared, FFT-mode kernels) differs from TFHE's formula (gadget_digit).
+long rs_emu_digit_mismatches(int cfg, uint32_t start, uint32_t step, long count) {
+  long bad = 0;
+  uint32_t d = start;
+  for (long t = 0; t < count; ++t, d += step) {
+    if (cfg == 0) {
+      using C = rs::CfgDefault128;
+      const int32_t dx = rs::gadget_prepare<C>((int32_t)d);
+      for (int q = 0; q < C::L; ++q) bad += rs::gadget_digit_prepared<C>(dx, q) != rs::gadget_digit<C>((int32_t)d, q, rs::gadget_offset<C>());
+    } else {
+      using C = rs::CfgRedsecV2;
+      const int32_t dx = rs::gadget_prepare<C>((int32_t)d);
+      for (int q = 0; q < C::L; ++q) bad += rs::gadget_digit_prepared<C>(dx, q) != rs::gadget_digit<C>((int32_t)d, q, rs::gadget_offset<C>());
+    }
+  }
+  return bad;
 }
 
 uint64_t rs_emu_prime(int cfg) {

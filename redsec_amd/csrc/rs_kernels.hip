@@ -195,27 +195,46 @@ __global__ void gather_rows_kernel(int32_t* __restrict__ out, const int32_t* __r
   }
 }
 
-// out[m][w] = sum_k s(k,m) in[k][w] (+ constants on the b word). grid (ceil(W/256), M).
-__global__ __launch_bounds__(256) void linear_fc_kernel(int32_t* __restrict__ out, const int32_t* __restrict__ in,
-                                                        const uint8_t* __restrict__ sign, const uint8_t* __restrict__ zero, int K,
-                                                        int M, int W, int32_t zero_tap_b, const int32_t* __restrict__ bias_b,
-                                                        int bias_depth) {
-  const int w = blockIdx.x * 256 + threadIdx.x;
+// out[m][w] = sum_k s(k,m) in[k][w] (+ constants on the b word). A workgroup is 64 words x 4 k-lanes
+// (one wave per k-lane, so the weight bytes are wave-uniform), grid (ceil(W/64), M, S): with few
+// outputs (the 10 logits of a final layer: K = 1024 serial taps per thread took 0.41 ms) the K taps
+// are also cut into S slices whose partial sums meet by integer atomics in a zeroed output -- exact
+// and order-independent, like every other sum of this stage.
+constexpr int FC_WORDS = 64, FC_KL = 4;
+__global__ __launch_bounds__(FC_WORDS * FC_KL) void linear_fc_kernel(int32_t* __restrict__ out, const int32_t* __restrict__ in,
+                                                                      const uint8_t* __restrict__ sign, const uint8_t* __restrict__ zero,
+                                                                      int K, int M, int W, int32_t zero_tap_b,
+                                                                      const int32_t* __restrict__ bias_b, int bias_depth, int kslice) {
+  __shared__ uint32_t s_acc[FC_KL][FC_WORDS];
+  __shared__ uint32_t s_nz[FC_KL][FC_WORDS];
+  const int wl = threadIdx.x & (FC_WORDS - 1);
+  const int kl = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / FC_WORDS));
+  const int w = blockIdx.x * FC_WORDS + wl;
   const int m = blockIdx.y;
-  if (w >= W) return;
+  const int k0 = blockIdx.z * kslice;
+  const int k1 = (k0 + kslice < K) ? k0 + kslice : K;
   uint32_t acc = 0;
   uint32_t nzero = 0;
-  for (int k = 0; k < K; ++k) {
-    const size_t fi = (size_t)k * M + m;
-    if (zero && zero[fi]) { ++nzero; continue; }
-    const uint32_t v = (uint32_t)in[(size_t)k * W + w];
-    acc += sign[fi] ? v : (0u - v);
+  if (w < W) {
+    for (int k = k0 + kl; k < k1; k += FC_KL) {
+      const size_t fi = (size_t)k * M + m;
+      if (zero && zero[fi]) { ++nzero; continue; }
+      const uint32_t v = (uint32_t)in[(size_t)k * W + w];
+      acc += sign[fi] ? v : (0u - v);
+    }
   }
+  s_acc[kl][wl] = acc;
+  s_nz[kl][wl] = nzero;
+  __syncthreads();
+  if (kl != 0 || w >= W) return;
+#pragma unroll
+  for (int j = 1; j < FC_KL; ++j) { acc += s_acc[j][wl]; nzero += s_nz[j][wl]; }
   if (w == W - 1) {
     acc += nzero * (uint32_t)zero_tap_b;
-    if (bias_b) acc += (uint32_t)bias_b[m % bias_depth];
+    if (bias_b && blockIdx.z == 0) acc += (uint32_t)bias_b[m % bias_depth];
   }
-  out[(size_t)m * W + w] = (int32_t)acc;
+  if (gridDim.z > 1) atomicAdd(reinterpret_cast<unsigned int*>(out) + (size_t)m * W + w, acc);
+  else out[(size_t)m * W + w] = (int32_t)acc;
 }
 
 // out[oh][ow][od][w]; grid (ceil(W/256), Cout, Ho*Wo)
@@ -403,8 +422,23 @@ hipError_t launch_gather_rows(int32_t* out, const int32_t* in, const int32_t* id
 
 hipError_t launch_linear_fc(int32_t* out, const int32_t* in, const uint8_t* sign, const uint8_t* zero, int K, int M, int W,
                             int32_t zero_tap_b, const int32_t* bias_b, int bias_depth, hipStream_t st) {
-  hipLaunchKernelGGL(linear_fc_kernel, dim3((W + 255) / 256, M), dim3(256), 0, st, out, in, sign, zero, K, M, W, zero_tap_b, bias_b,
-                     bias_depth);
+  // enough workgroups to fill the chip: slice K when (words x outputs) alone gives fewer than ~1024 of them
+  const int wblocks = (W + FC_WORDS - 1) / FC_WORDS;
+  long S = (1024 + (long)wblocks * M - 1) / ((long)wblocks * M);
+  const long max_s = (K + 4 * FC_KL - 1) / (4 * FC_KL);           // at least 4 taps per thread
+  if (S > max_s) S = max_s;
+  if (S < 1) S = 1;
+  int kslice = (int)((K + S - 1) / S);
+  kslice = (kslice + FC_KL - 1) / FC_KL * FC_KL;
+  if (kslice < FC_KL) kslice = FC_KL;                              // K == 0: one (empty) slice writes the constants
+  S = (K + kslice - 1) / kslice;
+  if (S < 1) S = 1;
+  if (S > 1) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(int32_t) * (size_t)M * W, st);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(linear_fc_kernel, dim3(wblocks, M, (unsigned)S), dim3(FC_WORDS * FC_KL), 0, st, out, in, sign, zero, K, M, W,
+                     zero_tap_b, bias_b, bias_depth, kslice);
   return hipGetLastError();
 }
 

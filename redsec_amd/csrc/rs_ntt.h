@@ -305,4 +305,23 @@ constexpr uint32_t gadget_offset() {
   return off;
 }
 
+// The same digits with one operation less per digit: flipping the top bit of every Bgbit-wide field of
+// u = d + offset (the bit pattern of that mask IS the offset) turns "field - Bg/2" into the field read
+// as a SIGNED Bgbit-bit number, i.e. one v_bfe_i32 (or one arithmetic shift for q = 0):
+//   signed(field ^ Bg/2) = ((field + Bg/2 + Bg/2) mod Bg) - Bg/2 = field - Bg/2.
+// gadget_prepare runs once per coefficient, gadget_digit_prepared once per (coefficient, q).
+template <class C>
+RS_HD int32_t gadget_prepare(int32_t d) {
+  constexpr uint32_t off = gadget_offset<C>();
+  return (int32_t)(((uint32_t)d + off) ^ off);
+}
+template <class C>
+RS_HD int32_t gadget_digit_prepared(int32_t dx, int q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_sbfe(dx, (unsigned)(32 - (q + 1) * C::BGBIT), (unsigned)C::BGBIT);   // v_bfe_i32, also for a run-time q
+#else
+  return (int32_t)((uint32_t)dx << (q * C::BGBIT)) >> (32 - C::BGBIT);
+#endif
+}
+
 }  // namespace rs

@@ -15,6 +15,8 @@ def lib():
         L = C.CDLL(_build.build_emulator())
         L.rs_emu_prime.restype = C.c_uint64
         L.rs_emu_forward.argtypes = [C.c_int, _i32p, C.POINTER(C.c_double)]
+        L.rs_emu_digit_mismatches.restype = C.c_long
+        L.rs_emu_digit_mismatches.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_long]
         _lib = L
     return _lib
 
@@ -81,3 +83,7 @@ def validate(cfg):
     msg = C.create_string_buffer(256)
     rc = lib().rs_emu_validate(cfg, msg, 256)
     return rc, msg.value.decode()
+
+
+def digit_mismatches(cfg, start, step, count):
+    return lib().rs_emu_digit_mismatches(int(cfg), int(start) & 0xFFFFFFFF, int(step) & 0xFFFFFFFF, int(count))

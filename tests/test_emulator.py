@@ -156,3 +156,15 @@ def test_fft_mode_blind_rotate_matches_exact_oracle(cfg, fixture, request):
         u, _, dev = emu_lib.blind_rotate_fft(cfg, ks.p.n, ct[i], None, 1, 0, 0, mu, ks.bk)
         assert np.array_equal(u, ref[i])
         assert dev < 0.05
+
+
+@pytest.mark.parametrize("cfg", [0, 1])
+def test_signed_field_digits_equal_tfhe_decomposition(cfg):
+    """FFT-mode kernels read each gadget digit as a signed bit field of (d + offset) ^ offset (one
+    v_bfe_i32); it must equal tGswTorus32PolynomialDecompH's ((d + offset) >> decal & mask) - Bg/2
+    for every digit level: an odd stride visits 2^24 values spread over the whole word, plus both
+    ends of the range and the carry boundaries around the offset."""
+    assert emu_lib.digit_mismatches(cfg, 0, 0x01000193, 1 << 24) == 0
+    assert emu_lib.digit_mismatches(cfg, 0, 1, 1 << 16) == 0
+    assert emu_lib.digit_mismatches(cfg, 0xFFFF0000, 1, 1 << 17) == 0
+    assert emu_lib.digit_mismatches(cfg, 0x7FFF0000, 1, 1 << 17) == 0

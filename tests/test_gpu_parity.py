@@ -350,6 +350,17 @@ def test_linear_stage_matches_oracle(be_toy_redsec, toy_redsec):
     assert np.array_equal(got, ref)
     got = be.linear_fc(_dev(x), torch.from_numpy(sign).cuda(), None).cpu().numpy()
     assert np.array_equal(got, ol.linear_fc(x, sign, None, 0))
+    # K-sliced form (few outputs: partial sums meet by integer atomics), one-slice form, bias on the b word
+    for K2, M2 in ((1024, 10), (196, 300), (3, 5), (70, 1)):
+        x2 = rng.integers(-2**31, 2**31, (K2, W)).astype(np.int32)
+        sign2 = rng.integers(0, 2, (K2, M2)).astype(np.uint8)
+        zero2 = (rng.random((K2, M2)) < 0.3).astype(np.uint8)
+        bias2 = rng.integers(-2**31, 2**31, M2).astype(np.int32)
+        ref2 = ol.linear_fc(x2, sign2, zero2, zb).astype(np.int64)
+        ref2[:, -1] += bias2
+        got2 = be.linear_fc(_dev(x2), torch.from_numpy(sign2).cuda(), torch.from_numpy(zero2).cuda(), zero_tap_b=zb,
+                            bias_b=torch.from_numpy(bias2).cuda()).cpu().numpy()
+        assert np.array_equal(got2, (ref2 & 0xFFFFFFFF).astype(np.uint32).view(np.int32)), (K2, M2)
     # lincomb: lweSubTo / lweAddMulTo shapes
     y = rng.integers(-2**31, 2**31, (K, W)).astype(np.int32)
     got = be.lincomb(_dev(x), 3, _dev(y), -1, bconst=12345).cpu().numpy()
