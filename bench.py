@@ -52,6 +52,24 @@ def fp64_ops_per_bootstrap_fft(n, l):
     return n * per_lane * 64
 
 
+def host_cpu_share():
+    """CPUs granted to this process: the affinity mask, capped by the cgroup v2 / v1 CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except Exception:
+            pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,7 +228,11 @@ def main():
         if args.cpu_sample != 0:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as ol
-            cores = ol.lib().ro_max_threads()
+            # threads = the CPUs this process may actually use: affinity mask capped by the cgroup CPU quota
+            # (a GPU box grants 16 CPUs of its 256 hardware threads; 128 OpenMP threads on that share ran
+            # 25 % slower than 16) -- and `cores` reports exactly that number
+            cores = host_cpu_share()
+            ol.lib().ro_set_threads(cores)
             # the CPU baseline is an N=1 figure (torch.distributed.run also pins OMP_NUM_THREADS=1);
             # multi-rank runs only keep a small in-run parity sample
             timed_baseline = world == 1

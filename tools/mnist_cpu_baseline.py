@@ -21,6 +21,9 @@ ct = sk.encrypt_image(pixels[i], seed=5)
 class K:
     pass
 k = K(); k.p = ol.params("redsec_small_v2"); k.bk = sk.bk.ravel(); k.ksk = sk.ksk.ravel()
+sys.path.insert(0, ROOT)
+import bench
+ol.lib().ro_set_threads(bench.host_cpu_share())   # the CPU share actually granted (cgroup quota), not the host's thread count
 ctx = ol.Ctx(k)
 ctx.set_fft(True)
 t0 = time.perf_counter()
