@@ -1,0 +1,20 @@
+#!/bin/bash
+# Round-end measurement set on ONE MI355X box -> gpurun_out/final/ (copy what is judged into profiles/).
+# usage: tools/final_profile.sh PREFIX      (e.g. h)
+set -o pipefail
+P="${1:-h}"; OUT=gpurun_out/final; mkdir -p $OUT
+export TMPDIR=/tmp
+python bench.py > $OUT/${P}_wg_fft_bench.json 2> $OUT/bench_default.err && tail -c 400 $OUT/${P}_wg_fft_bench.json && echo
+python bench.py --params redsec_small_v2 > $OUT/${P}_wg_fft_bench_redsec_params.json 2>> $OUT/bench_default.err
+python bench.py --mode exact --cpu-sample 0 > $OUT/${P}_exact_ntt_bench.json 2>> $OUT/bench_default.err
+python bench.py --mode exact --cpu-sample 0 --params redsec_small_v2 > $OUT/${P}_exact_ntt_bench_redsec_params.json 2>> $OUT/bench_default.err
+echo "benches done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-exact-check > $OUT/prof_bench.log 2>&1
+find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/${P}_wg_fft_kernel_stats.csv \;
+head -4 $OUT/${P}_wg_fft_kernel_stats.csv
+python tools/mnist_latency.py > $OUT/${P}_mnist_latency.txt 2>&1; head -1 $OUT/${P}_mnist_latency.txt
+python tools/mnist_cpu_baseline.py > $OUT/${P}_mnist_cpu_baseline.txt 2>&1; tail -2 $OUT/${P}_mnist_cpu_baseline.txt
+python tools/cifar_profile.py binarynet $OUT/cifar_prof > $OUT/${P}_cifar_binarynet_driver.txt 2>&1; grep -E "wall|Classification" $OUT/${P}_cifar_binarynet_driver.txt
+find $OUT/cifar_prof -name "*kernel_stats.csv" -exec cp {} $OUT/${P}_cifar_binarynet_driver_kernel_stats.csv \;
+rm -rf $OUT/prof $OUT/cifar_prof
+echo "final profile set done"
