@@ -94,20 +94,121 @@ class EncryptedMnist:
         self.final = (t(s), t(z), t(MnistSignNet.bias_to_torus(b)))
         self.pool = dict(H=28, Wd=28, C=1, win_h=2, win_w=2, stride_h=2, stride_w=2, off_h=0, off_w=0, Ho=14, Wo=14)
 
-    def run(self, image_ct, taps=None):
+    def run(self, image_ct, taps=None, shard=False):
         """image_ct: int32 CUDA tensor [784][W] (encrypt_image.cpp order: row-major pixels).
-        Returns int32 [10][W]. `taps` (dict) receives the intermediate ciphertext tensors."""
+        Returns int32 [10][W]. `taps` (dict) receives the intermediate ciphertext tensors.
+        shard=True (inside an initialised torch.distributed job, one process per GPU, keys loaded on
+        every rank): gate-parallel evaluation of ONE image -- every rank bootstraps a contiguous slice
+        of each stage's ciphertexts and the slices are all-gathered before the next linear stage, which
+        needs the whole bit vector (partitioning 2). The linear stages are
+        recomputed on every rank (< 2 % of the image). Results are identical to the unsharded run word
+        for word: a bootstrap's output depends on its own input ciphertext only."""
         be = self.be
+        if shard:
+            from . import sharding
+            boot = lambda pre: sharding.sharded_stage(lambda rows: be.bootstrap(rows, MU_SIGN), pre)
+        else:
+            boot = lambda pre: be.bootstrap(pre, MU_SIGN)
         x = image_ct.view(28, 28, 1, be.W)
         # IntLayer: SumPooling::execute + Quantize::execute (bias folded into the pooling kernel)
         pre0 = be.sumpool(x, self.pool, bias_b=self.bias0).view(196, be.W)
-        bits = be.bootstrap(pre0, MU_SIGN)
+        bits = boot(pre0)
         if taps is not None:
             taps["pre0"], taps["bits0"] = pre0, bits
         for li, (sign, zero, bias) in enumerate(self.fc):
             pre = be.linear_fc(bits, sign, zero, zero_tap_b=0, bias_b=bias)   # BinFunc: zero taps add nothing
-            bits = be.bootstrap(pre, MU_SIGN)
+            bits = boot(pre)
             if taps is not None:
                 taps["pre%d" % (li + 1)], taps["bits%d" % (li + 1)] = pre, bits
         sign, zero, bias = self.final
         return be.linear_fc(bits, sign, zero, zero_tap_b=0, bias_b=bias)      # Quantize::add_bias, no bootstrap
+
+
+class EncryptedCifar:
+    """nets/cifar/binarynet{,_small}/net.cpp:96-209 on a redsec_amd.Backend, device-resident:
+    IntLayer(NO_CONV, SIGN); 6 x BinLayer(CONV 3x3 same, SIGN), a 2x2 max-pool after every second one;
+    2 x BinLayer(FC, SIGN); BinLayer(FC_FINAL). Same stage order and the same max-pool semantics as the
+    C++ layer mirror (redsec_amd/host/layers.cpp, DESIGN.md "Max-pool semantics"): the sign bootstrap
+    ahead of a max-pool emits +-1/8, the window is OR-ed in (fh, fw) order starting from a copy of the
+    first tap, the last OR re-encodes to +-1/4096.
+
+    `net`: weights as plain arrays -- bias0 int32[3]; convs [(sign, zero uint8[3][3][Cin][Cout], bias
+    int32[Cout])]; fcs [(sign, zero uint8[K][M], bias int32[M])], the last one being the logits layer
+    (layouts of lib/BinFunc.cpp:388). shard=True: gate-parallel over the ranks of an initialised
+    torch.distributed job as in EncryptedMnist.run (693,248 bootstraps per binarynet image, the
+    largest all_gather 131,072 x 351 words)."""
+
+    MU8 = 1 << 29   # modSwitchToTorus32(1, 8): the encoding bootsOR assumes
+
+    def __init__(self, backend, net):
+        import torch
+        self.be = backend
+        dev = "cuda:%d" % backend.device
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        tor = MnistSignNet.bias_to_torus
+        self.bias0 = t(tor(net.bias0))
+        self.convs = [(t(s), t(z), t(tor(b))) for s, z, b in net.convs]
+        self.fcs = [(t(s), t(z), t(tor(b))) for s, z, b in net.fcs]
+        self._pool_index = {}
+        self._t = t
+
+    def _pool(self, H, Wd, C):
+        """[tap][out] input rows of a 2x2 stride-2 window over [H][Wd][C] (MaxPooling::prep index math)."""
+        key = (H, Wd, C)
+        if key not in self._pool_index:
+            Ho, Wo = H // 2, Wd // 2
+            oh, ow, c = np.meshgrid(np.arange(Ho), np.arange(Wo), np.arange(C), indexing="ij")
+            taps = [((2 * oh + fh) * Wd + (2 * ow + fw)) * C + c for fh in range(2) for fw in range(2)]
+            self._pool_index[key] = self._t(np.stack([a.reshape(-1) for a in taps]).astype(np.int32))
+        return self._pool_index[key]
+
+    def run(self, image_ct, shard=False):
+        """image_ct: int32 CUDA tensor [32*32*3][W] in (row, column, channel) order. Returns int32 [10][W]."""
+        be = self.be
+        if shard:
+            from . import sharding
+            stage = lambda fn, *xs: sharding.sharded_stage(lambda rows: fn(*[rows[k] for k in range(len(xs))]), _Rows(xs))
+        else:
+            stage = lambda fn, *xs: fn(*xs)
+        W = be.W
+        H = Wd = 32
+        one = dict(H=H, Wd=Wd, C=3, win_h=1, win_w=1, stride_h=1, stride_w=1, off_h=0, off_w=0, Ho=H, Wo=Wd)
+        pre = be.sumpool(image_ct.view(H, Wd, 3, W), one, bias_b=self.bias0).view(-1, W)     # Quantize: x + bias[i % depth]
+        bits = stage(lambda r: be.bootstrap(r, MU_SIGN), pre)
+        C = 3
+        for li, (sign, zero, bias) in enumerate(self.convs):
+            Cout = sign.shape[3]
+            shape = dict(H=H, Wd=Wd, Cin=C, Cout=Cout, fh=3, fw=3, stride_h=1, stride_w=1, off_h=1, off_w=1, Ho=H, Wo=Wd)
+            pre = be.conv_ternary(bits.view(H, Wd, C, W), sign, zero, shape, zero_tap_b=0, pad_tap_b=0, bias_b=bias).view(-1, W)
+            C = Cout
+            pooled = li % 2 == 1
+            bits = stage(lambda r: be.bootstrap(r, self.MU8 if pooled else MU_SIGN), pre)
+            if pooled:
+                idx = self._pool(H, Wd, C)
+                acc = be.gather_rows(bits, idx[0])
+                for tp in range(1, 4):
+                    tap = be.gather_rows(bits, idx[tp])
+                    mu = MU_SIGN if tp == 3 else self.MU8
+                    acc = stage(lambda a, b: be.gate_mu("OR", a, b, mu), acc, tap)
+                bits = acc
+                H //= 2; Wd //= 2
+        v = bits
+        for i, (sign, zero, bias) in enumerate(self.fcs):
+            pre = be.linear_fc(v, sign, zero, zero_tap_b=0, bias_b=bias)
+            if i == len(self.fcs) - 1:
+                return pre
+            v = stage(lambda r: be.bootstrap(r, MU_SIGN), pre)
+
+
+class _Rows:
+    """Several equally long row batches sliced together (the operands of a two-input gate stage)."""
+
+    def __init__(self, xs):
+        self.xs = xs
+        self.shape = xs[0].shape
+
+    def __getitem__(self, sl):
+        return _Rows([x[sl] for x in self.xs]) if isinstance(sl, slice) else self.xs[sl]
+
+    def contiguous(self):
+        return _Rows([x.contiguous() for x in self.xs])

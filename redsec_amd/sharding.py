@@ -26,11 +26,15 @@ def all_gather_rows(local, total, group=None):
         return local
     sizes = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
     width = max(sizes)
-    pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
+    # gloo (CPU tests, one-GPU rehearsals) moves host tensors; nccl (= RCCL over xGMI) device tensors
+    via_host = local.is_cuda and dist.get_backend(group) == "gloo"
+    src = local.cpu() if via_host else local
+    pad = torch.zeros((width,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    pad[: src.shape[0]] = src
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad, group=group)
-    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
+    out = torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
+    return out.to(local.device) if via_host else out
 
 
 def sharded_stage(fn, batch, group=None):
