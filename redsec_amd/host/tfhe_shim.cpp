@@ -70,12 +70,28 @@ size_t ksk_words(const TFheGateBootstrappingParameterSet* p) {
   return (size_t)tp->N * tp->k * p->ks_t * ((size_t)1 << p->ks_basebit) * (p->in_out_params->n + 1);
 }
 
+void write_exact(FILE* f, const void* src, size_t bytes, const char* what) {
+  if (fwrite(src, 1, bytes, f) != bytes) { fprintf(stderr, "redsec tfhe shim: short write (%s)\n", what); abort(); }
+}
+int32_t* alloc_words(size_t words, const char* what) {
+  int32_t* p = (int32_t*)malloc(sizeof(int32_t) * (words ? words : 1));
+  if (!p) { fprintf(stderr, "redsec tfhe shim: out of memory (%s, %zu words)\n", what, words); abort(); }
+  return p;
+}
+// a key file's header decides allocation sizes: refuse anything outside what the backend supports
+// before allocating (a truncated or foreign file must not turn into a multi-gigabyte malloc)
+void check_header(const ParamHeader& h, const char* what) {
+  const bool ok = h.N == 1024 && h.k == 1 && h.n >= 1 && h.n <= 1023 && h.l >= 1 && h.l <= 16 && h.Bgbit >= 1 &&
+                  h.l * h.Bgbit <= 32 && h.ks_t >= 1 && h.ks_basebit >= 1 && h.ks_t * h.ks_basebit <= 31;
+  if (!ok) { fprintf(stderr, "redsec tfhe shim: implausible parameters in %s header\n", what); abort(); }
+}
+
 LweBootstrappingKey* new_bk(const TFheGateBootstrappingParameterSet* p) {
   LweBootstrappingKey* bk = new LweBootstrappingKey;
   bk->in_out_params = p->in_out_params;
   bk->bk_params = p->tgsw_params;
-  bk->bk_words = (int32_t*)malloc(sizeof(int32_t) * bk_words(p));
-  bk->ksk_words = (int32_t*)malloc(sizeof(int32_t) * ksk_words(p));
+  bk->bk_words = alloc_words(bk_words(p), "bootstrapping key");
+  bk->ksk_words = alloc_words(ksk_words(p), "keyswitch key");
   return bk;
 }
 
@@ -103,7 +119,6 @@ rs_ctx* ctx_of_fft(const LweBootstrappingKeyFFT* cf) {
 void read_exact(FILE* f, void* dst, size_t bytes, const char* what) {
   if (fread(dst, 1, bytes, f) != bytes) { fprintf(stderr, "redsec tfhe shim: short read (%s)\n", what); abort(); }
 }
-
 // b += s * a in Z[X]/(X^N+1), s binary
 void addmul_binary(int32_t* b, const int32_t* s, const int32_t* a, int32_t N) {
   for (int32_t i = 0; i < N; ++i) {
@@ -237,8 +252,8 @@ TFheGateBootstrappingSecretKeySet* new_random_gate_bootstrapping_secret_keyset(c
   const int32_t n = p->in_out_params->n, N = tp->N, k = tp->k, l = gp->l, kpl = gp->kpl;
   const int32_t t = p->ks_t, basebit = p->ks_basebit, base = 1 << basebit, W = n + 1;
   if (k != 1) { fprintf(stderr, "redsec tfhe shim: k = %d unsupported\n", k); abort(); }
-  LweKey* lk = new LweKey{p->in_out_params, (int32_t*)malloc(sizeof(int32_t) * n)};
-  TGswKey* gk = new TGswKey{gp, (int32_t*)malloc(sizeof(int32_t) * (size_t)k * N)};
+  LweKey* lk = new LweKey{p->in_out_params, alloc_words((size_t)n, "lwe key")};
+  TGswKey* gk = new TGswKey{gp, alloc_words((size_t)k * N, "tlwe key")};
   for (int32_t i = 0; i < n; ++i) lk->key[i] = (int32_t)(uniform32() & 1u);
   for (int32_t i = 0; i < k * N; ++i) gk->key[i] = (int32_t)(uniform32() & 1u);
   LweBootstrappingKey* bk = new_bk(p);
@@ -291,22 +306,23 @@ void delete_gate_bootstrapping_parameters(TFheGateBootstrappingParameterSet*) {}
 // ---- files ----
 void export_tfheGateBootstrappingCloudKeySet_toFile(FILE* f, const TFheGateBootstrappingCloudKeySet* key) {
   const ParamHeader h = header_from_params(kMagicCloud, key->params);
-  fwrite(&h, sizeof h, 1, f);
-  fwrite(key->bk->bk_words, sizeof(int32_t), bk_words(key->params), f);
-  fwrite(key->bk->ksk_words, sizeof(int32_t), ksk_words(key->params), f);
+  write_exact(f, &h, sizeof h, "cloud key header");
+  write_exact(f, key->bk->bk_words, sizeof(int32_t) * bk_words(key->params), "bootstrapping key");
+  write_exact(f, key->bk->ksk_words, sizeof(int32_t) * ksk_words(key->params), "keyswitch key");
 }
 void export_tfheGateBootstrappingSecretKeySet_toFile(FILE* f, const TFheGateBootstrappingSecretKeySet* key) {
   const ParamHeader h = header_from_params(kMagicSecret, key->params);
-  fwrite(&h, sizeof h, 1, f);
-  fwrite(key->lwe_key->key, sizeof(int32_t), (size_t)h.n, f);
-  fwrite(key->tgsw_key->key, sizeof(int32_t), (size_t)h.k * h.N, f);
-  fwrite(key->cloud.bk->bk_words, sizeof(int32_t), bk_words(key->params), f);
-  fwrite(key->cloud.bk->ksk_words, sizeof(int32_t), ksk_words(key->params), f);
+  write_exact(f, &h, sizeof h, "secret key header");
+  write_exact(f, key->lwe_key->key, sizeof(int32_t) * (size_t)h.n, "lwe key");
+  write_exact(f, key->tgsw_key->key, sizeof(int32_t) * (size_t)h.k * h.N, "tlwe key");
+  write_exact(f, key->cloud.bk->bk_words, sizeof(int32_t) * bk_words(key->params), "bootstrapping key");
+  write_exact(f, key->cloud.bk->ksk_words, sizeof(int32_t) * ksk_words(key->params), "keyswitch key");
 }
 TFheGateBootstrappingCloudKeySet* new_tfheGateBootstrappingCloudKeySet_fromFile(FILE* f) {
   ParamHeader h;
   read_exact(f, &h, sizeof h, "cloud key header");
   if (h.magic != kMagicCloud) { fprintf(stderr, "redsec tfhe shim: not a cloud key file\n"); abort(); }
+  check_header(h, "cloud key");
   TFheGateBootstrappingParameterSet* p = params_from_header(h);
   LweBootstrappingKey* bk = new_bk(p);
   read_exact(f, bk->bk_words, sizeof(int32_t) * bk_words(p), "bootstrapping key");
@@ -317,9 +333,10 @@ TFheGateBootstrappingSecretKeySet* new_tfheGateBootstrappingSecretKeySet_fromFil
   ParamHeader h;
   read_exact(f, &h, sizeof h, "secret key header");
   if (h.magic != kMagicSecret) { fprintf(stderr, "redsec tfhe shim: not a secret key file\n"); abort(); }
+  check_header(h, "secret key");
   TFheGateBootstrappingParameterSet* p = params_from_header(h);
-  LweKey* lk = new LweKey{p->in_out_params, (int32_t*)malloc(sizeof(int32_t) * h.n)};
-  TGswKey* gk = new TGswKey{p->tgsw_params, (int32_t*)malloc(sizeof(int32_t) * (size_t)h.k * h.N)};
+  LweKey* lk = new LweKey{p->in_out_params, alloc_words((size_t)h.n, "lwe key")};
+  TGswKey* gk = new TGswKey{p->tgsw_params, alloc_words((size_t)h.k * h.N, "tlwe key")};
   read_exact(f, lk->key, sizeof(int32_t) * h.n, "lwe key");
   read_exact(f, gk->key, sizeof(int32_t) * (size_t)h.k * h.N, "tlwe key");
   LweBootstrappingKey* bk = new_bk(p);
@@ -332,10 +349,10 @@ TFheGateBootstrappingSecretKeySet* new_tfheGateBootstrappingSecretKeySet_fromFil
 // written here are byte-compatible with a TFHE client's.
 static const int32_t kLweSampleTypeUid = 42;
 void export_gate_bootstrapping_ciphertext_toFile(FILE* f, const LweSample* s, const TFheGateBootstrappingParameterSet* p) {
-  fwrite(&kLweSampleTypeUid, sizeof(int32_t), 1, f);
-  fwrite(s->a, sizeof(Torus32), (size_t)p->in_out_params->n, f);
-  fwrite(&s->b, sizeof(Torus32), 1, f);
-  fwrite(&s->current_variance, sizeof(double), 1, f);
+  write_exact(f, &kLweSampleTypeUid, sizeof(int32_t), "sample type uid");
+  write_exact(f, s->a, sizeof(Torus32) * (size_t)p->in_out_params->n, "sample mask");
+  write_exact(f, &s->b, sizeof(Torus32), "sample body");
+  write_exact(f, &s->current_variance, sizeof(double), "sample variance");
 }
 void import_gate_bootstrapping_ciphertext_fromFile(FILE* f, LweSample* s, const TFheGateBootstrappingParameterSet* p) {
   int32_t uid = 0;
