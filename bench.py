@@ -251,7 +251,7 @@ def main():
                 # (2) CPU baseline: the oracle's double-precision FFT path (the arithmetic class of TFHE's CPU
                 # library; ~8x faster than the exact path and bit-equal to it) on a larger sample of the batch
                 octx.set_fft(True)
-                bsample = min(G, 64 * cores)
+                bsample = min(G, 1024 * cores)     # ~16 s of CPU work at ~16 ms per gate and core
                 octx.gate_batch("NAND", ca_h[:min(cores, bsample)], cb_h[:min(cores, bsample)])  # warm caches / threads
                 t1 = time.perf_counter()
                 ref_fft = octx.gate_batch("NAND", ca_h[:bsample], cb_h[:bsample])

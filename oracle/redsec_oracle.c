@@ -377,51 +377,106 @@ void ro_ctx_set_schoolbook(ro_ctx* c, int use_schoolbook) { c->use_schoolbook = 
  * Negacyclic product of real polynomials through an M = N/2 point complex FFT: fold z_j = a_j + i a_{j+M},
  * twist by zeta^j (zeta = exp(i pi / N)), cyclic DFT; then products are pointwise. Plain iterative
  * radix-2 (decimation in frequency forward, decimation in time inverse, so no bit reversal is needed
- * between them). */
+ * between them). Planar layout (re[M] then im[M]) and one contiguous twiddle run per stage, so that
+ * the compiler vectorises the butterflies; the hot loops are cloned for AVX2+FMA hosts (run-time
+ * dispatch, the baseline build stays x86-64-v2). This is the timed CPU baseline: it should not be
+ * slower than it has to be. */
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+#define RO_CLONES __attribute__((target_clones("avx2,fma", "default")))
+#else
+#define RO_CLONES
+#endif
+/* fft_tw: [stage s = 0 .. log2(M)-1] runs of half_s = M >> (s+1) entries (re run, then im run) at offset
+ * 2 * (M - 2 * half_s) = stages laid out back to back; after them (offset 2M) the twist: re[M], im[M]. */
 static void fft_tables(ro_ctx* c) {
   const int32_t M = c->p.N / 2;
   c->fft_tw = (double*)malloc(sizeof(double) * 4 * (size_t)M);
   const long double pi = 3.141592653589793238462643383279502884L;
+  size_t off = 0;
+  for (int32_t half = M / 2, step = 1; half >= 1; half >>= 1, step <<= 1) {
+    for (int32_t j = 0; j < half; ++j) {
+      c->fft_tw[off + j] = (double)cosl(2 * pi * (long double)(j * step) / M);
+      c->fft_tw[off + half + j] = (double)sinl(2 * pi * (long double)(j * step) / M);
+    }
+    off += 2 * (size_t)half;
+  }
   for (int32_t j = 0; j < M; ++j) {
-    c->fft_tw[2 * j] = (double)cosl(2 * pi * j / M);
-    c->fft_tw[2 * j + 1] = (double)sinl(2 * pi * j / M);
-    c->fft_tw[2 * M + 2 * j] = (double)cosl(pi * j / c->p.N);
-    c->fft_tw[2 * M + 2 * j + 1] = (double)sinl(pi * j / c->p.N);
+    c->fft_tw[2 * M + j] = (double)cosl(pi * j / c->p.N);
+    c->fft_tw[3 * M + j] = (double)sinl(pi * j / c->p.N);
   }
 }
-/* in-place forward DFT (e^{+2 pi i jk/M}), output in bit-reversed order */
-static void fft_dif(double* z, int32_t M, const double* tw) {
-  for (int32_t half = M / 2, step = 1; half >= 1; half >>= 1, step <<= 1)
-    for (int32_t base = 0; base < M; base += 2 * half)
+/* in-place forward DFT (e^{+2 pi i jk/M}) of re[M], im[M]; output in bit-reversed order */
+RO_CLONES static void fft_dif(double* restrict re, double* restrict im, int32_t M, const double* restrict tw) {
+  for (int32_t half = M / 2; half >= 1; half >>= 1) {
+    const double* restrict wr = tw; const double* restrict wi = tw + half;
+    for (int32_t base = 0; base < M; base += 2 * half) {
+      double* restrict ar = re + base; double* restrict ai = im + base;
+      double* restrict br = ar + half; double* restrict bi = ai + half;
       for (int32_t j = 0; j < half; ++j) {
-        double* a = z + 2 * (base + j); double* b = z + 2 * (base + j + half);
-        const double wr = tw[2 * j * step], wi = tw[2 * j * step + 1];
-        const double dr = a[0] - b[0], di = a[1] - b[1];
-        a[0] += b[0]; a[1] += b[1];
-        b[0] = dr * wr - di * wi; b[1] = dr * wi + di * wr;
+        const double dr = ar[j] - br[j], di = ai[j] - bi[j];
+        ar[j] += br[j]; ai[j] += bi[j];
+        br[j] = dr * wr[j] - di * wi[j]; bi[j] = dr * wi[j] + di * wr[j];
       }
+    }
+    tw += 2 * half;
+  }
 }
 /* in-place inverse (conjugate twiddles) from bit-reversed order back to natural order, unscaled */
-static void fft_dit_inv(double* z, int32_t M, const double* tw) {
-  for (int32_t half = 1, step = M / 2; half < M; half <<= 1, step >>= 1)
-    for (int32_t base = 0; base < M; base += 2 * half)
+RO_CLONES static void fft_dit_inv(double* restrict re, double* restrict im, int32_t M, const double* restrict tw_end) {
+  const double* tw = tw_end;                    /* stage tables are walked backwards: half = 1, 2, ... */
+  for (int32_t half = 1; half < M; half <<= 1) {
+    tw -= 2 * half;
+    const double* restrict wr = tw; const double* restrict wi = tw + half;
+    for (int32_t base = 0; base < M; base += 2 * half) {
+      double* restrict ar = re + base; double* restrict ai = im + base;
+      double* restrict br = ar + half; double* restrict bi = ai + half;
       for (int32_t j = 0; j < half; ++j) {
-        double* a = z + 2 * (base + j); double* b = z + 2 * (base + j + half);
-        const double wr = tw[2 * j * step], wi = -tw[2 * j * step + 1];
-        const double tr = b[0] * wr - b[1] * wi, ti = b[0] * wi + b[1] * wr;
-        b[0] = a[0] - tr; b[1] = a[1] - ti;
-        a[0] += tr; a[1] += ti;
+        const double tr = br[j] * wr[j] + bi[j] * wi[j], ti = bi[j] * wr[j] - br[j] * wi[j];
+        br[j] = ar[j] - tr; bi[j] = ai[j] - ti;
+        ar[j] += tr; ai[j] += ti;
       }
-}
-static void fft_forward_i32(double* z, const int32_t* poly, const ro_ctx* c, double scale) {
-  const int32_t M = c->p.N / 2;
-  const double* twist = c->fft_tw + 2 * M;
-  for (int32_t j = 0; j < M; ++j) {
-    const double re = scale * (double)poly[j], im = scale * (double)poly[j + M];
-    z[2 * j] = re * twist[2 * j] - im * twist[2 * j + 1];
-    z[2 * j + 1] = re * twist[2 * j + 1] + im * twist[2 * j];
+    }
   }
-  fft_dif(z, M, c->fft_tw);
+}
+/* z = planar (re[M], im[M]) transform of the folded, twisted integer polynomial */
+RO_CLONES static void fft_forward_i32(double* restrict z, const int32_t* restrict poly, int32_t M, const double* restrict tw, double scale) {
+  const double* restrict tr = tw + 2 * M; const double* restrict ti = tw + 3 * M;
+  double* restrict re = z; double* restrict im = z + M;
+  for (int32_t j = 0; j < M; ++j) {
+    const double a = scale * (double)poly[j], b = scale * (double)poly[j + M];
+    re[j] = a * tr[j] - b * ti[j];
+    im[j] = a * ti[j] + b * tr[j];
+  }
+  fft_dif(re, im, M, tw);
+}
+/* dst += x (.) k, all planar */
+RO_CLONES static void fft_mac(double* restrict dst, const double* restrict x, const double* restrict k, int32_t M) {
+  const double* restrict xr = x; const double* restrict xi = x + M;
+  const double* restrict kr = k; const double* restrict ki = k + M;
+  double* restrict dr = dst; double* restrict di = dst + M;
+  for (int32_t j = 0; j < M; ++j) {
+    dr[j] += xr[j] * kr[j] - xi[j] * ki[j];
+    di[j] += xr[j] * ki[j] + xi[j] * kr[j];
+  }
+}
+/* untwist by conj(zeta^j): out_re[j] -> coefficient j, out_im[j] -> coefficient j + M (still doubles) */
+RO_CLONES static void fft_untwist(double* restrict z, int32_t M, const double* restrict tw) {
+  const double* restrict tr = tw + 2 * M; const double* restrict ti = tw + 3 * M;
+  double* restrict re = z; double* restrict im = z + M;
+  for (int32_t j = 0; j < M; ++j) {
+    const double a = re[j] * tr[j] + im[j] * ti[j];
+    const double b = im[j] * tr[j] - re[j] * ti[j];
+    re[j] = a; im[j] = b;
+  }
+}
+/* dst[j] += rint(z[j]) mod 2^32 for |z[j]| < 2^51: the low mantissa bits of z + 1.5 * 2^52 are rint(z)
+ * (round-to-nearest-even, as llrint under the default rounding mode) -- no libm call, vectorisable */
+RO_CLONES static void fft_round_add(int32_t* restrict dst, const double* restrict z, int32_t N) {
+  for (int32_t j = 0; j < N; ++j) {
+    union { double d; uint64_t u; } t;
+    t.d = z[j] + 6755399441055744.0;
+    dst[j] = (int32_t)((uint32_t)dst[j] + (uint32_t)t.u);
+  }
 }
 void ro_ctx_set_fft(ro_ctx* c, int use_fft) {
   c->use_fft = use_fft;
@@ -431,7 +486,7 @@ void ro_ctx_set_fft(ro_ctx* c, int use_fft) {
   c->bk_fft = (double*)malloc(sizeof(double) * polys * (size_t)c->p.N);
 #pragma omp parallel for schedule(static)
   for (long long q = 0; q < (long long)polys; ++q)
-    fft_forward_i32(c->bk_fft + (size_t)q * c->p.N, c->bk + (size_t)q * c->p.N, c, 2.0 / c->p.N);   /* 1/M folded into the key */
+    fft_forward_i32(c->bk_fft + (size_t)q * c->p.N, c->bk + (size_t)q * c->p.N, c->p.N / 2, c->fft_tw, 2.0 / c->p.N);   /* 1/M folded into the key */
 }
 
 /* TFHE polynomials.cpp torusPolynomialMulByXaiMinusOne: result = (X^a - 1) * source, 0 <= a < 2N. */
@@ -495,31 +550,20 @@ static void cmux_step(const ro_ctx* c, int32_t* acc, int32_t i, int32_t barai, i
   }
   if (c->use_fft) {
     const int32_t M = N / 2;
-    double* zd = (double*)scratch_u64;                /* [N] one digit transform (M complex) */
+    double* zd = (double*)scratch_u64;                /* [N] one digit transform (planar: re[M], im[M]) */
     double* zacc = zd + N;                            /* [k+1][N] */
     memset(zacc, 0, sizeof(double) * (size_t)(k + 1) * N);
     for (int32_t row = 0; row < kpl; ++row) {
-      fft_forward_i32(zd, digits + (size_t)row * N, c, 1.0);
-      for (int32_t col = 0; col <= k; ++col) {
-        const double* kp = c->bk_fft + ((((size_t)i * kpl + row) * (size_t)(k + 1)) + col) * (size_t)N;
-        double* dst = zacc + (size_t)col * N;
-        for (int32_t j = 0; j < M; ++j) {
-          dst[2 * j] += zd[2 * j] * kp[2 * j] - zd[2 * j + 1] * kp[2 * j + 1];
-          dst[2 * j + 1] += zd[2 * j] * kp[2 * j + 1] + zd[2 * j + 1] * kp[2 * j];
-        }
-      }
+      fft_forward_i32(zd, digits + (size_t)row * N, M, c->fft_tw, 1.0);
+      for (int32_t col = 0; col <= k; ++col)
+        fft_mac(zacc + (size_t)col * N, zd, c->bk_fft + ((((size_t)i * kpl + row) * (size_t)(k + 1)) + col) * (size_t)N, M);
     }
-    const double* twist = c->fft_tw + 2 * M;
     for (int32_t col = 0; col <= k; ++col) {
       double* z = zacc + (size_t)col * N;
-      fft_dit_inv(z, M, c->fft_tw);
+      fft_dit_inv(z, z + M, M, c->fft_tw + 2 * M - 2);   /* the last stage run (half = 1) ends at 2M - 2 */
+      fft_untwist(z, M, c->fft_tw);
       int32_t* dst = acc + (size_t)col * N;
-      for (int32_t j = 0; j < M; ++j) {                /* untwist by conj(zeta^j), round to the integer */
-        const double re = z[2 * j] * twist[2 * j] + z[2 * j + 1] * twist[2 * j + 1];
-        const double im = z[2 * j + 1] * twist[2 * j] - z[2 * j] * twist[2 * j + 1];
-        dst[j] = (int32_t)((uint32_t)dst[j] + (uint32_t)(uint64_t)(int64_t)llrint(re));
-        dst[j + M] = (int32_t)((uint32_t)dst[j + M] + (uint32_t)(uint64_t)(int64_t)llrint(im));
-      }
+      fft_round_add(dst, z, N);                        /* planar re[] = coefficients 0..M-1, im[] = M..N-1 */
     }
     return;
   }
