@@ -293,6 +293,11 @@ struct LayerImpl {
   // device copies
   uint8_t *d_sign = nullptr, *d_zero = nullptr;
   int32_t *d_bias = nullptr, *d_pool_index = nullptr;
+  // fused max-pool (every window inside the image): the window's w sign bits are emitted as +-pool_mu =
+  // +-1/(4w), summed, and ONE bootstrap of  sum + (w-1)/(4w)  is their OR (d_pool_bias holds that constant)
+  bool pool_fused = false;
+  int32_t pool_mu = 0;
+  int32_t* d_pool_bias = nullptr;
 
   rs_ctx* ctx() const { return redsec_ctx_of(bk); }
   int W() const { return bk->params->in_out_params->n + 1; }
@@ -428,6 +433,16 @@ void upload_weights(LayerImpl* L) {
   if (!L->pool_index.empty()) {
     RS_CHECK(rs_dev_alloc(c, (void**)&L->d_pool_index, L->pool_index.size() * 4));
     RS_CHECK(rs_copy_to_dev(c, L->d_pool_index, L->pool_index.data(), L->pool_index.size() * 4));
+    bool full = L->pool_taps >= 2;
+    for (int32_t v : L->pool_index) full = full && v >= 0;
+    const char* mode = getenv("REDSEC_MAXPOOL");          // "chain" selects the OR chain of BinOps::max calls
+    L->pool_fused = full && !(mode && strcmp(mode, "chain") == 0);
+    if (L->pool_fused) {
+      L->pool_mu = (int32_t)((1ull << 32) / (4ull * (unsigned)L->pool_taps));
+      const int32_t b = (int32_t)((uint32_t)(L->pool_taps - 1) * (uint32_t)L->pool_mu);
+      RS_CHECK(rs_dev_alloc(c, (void**)&L->d_pool_bias, 4));
+      RS_CHECK(rs_copy_to_dev(c, L->d_pool_bias, &b, 4));
+    }
   }
 }
 
@@ -479,11 +494,25 @@ DevSlab run_layer(LayerImpl* L, DevSlab x) {
     // Quantize::execute: one sign bootstrap per neuron (BinOps_enc.cpp:182-186). Ahead of a max-pool
     // the bits are emitted as +-1/8 so that the OR gates see the encoding they assume.
     int32_t* y = dev_rows(c, x.rows, W);
-    RS_CHECK(rs_bootstrap_dev(c, y, x.ptr, maxpool ? mu8 : mu4096, x.rows, nullptr));
+    RS_CHECK(rs_bootstrap_dev(c, y, x.ptr, !maxpool ? mu4096 : (L->pool_fused ? L->pool_mu : mu8), x.rows, nullptr));
     RS_CHECK(rs_sync(c));
     RS_CHECK(rs_dev_free(c, x.ptr));
     x.ptr = y;
-    if (maxpool) {
+    if (maxpool && L->pool_fused) {
+      // OR over a full window of w bits in ONE bootstrap: with the bits at +-1/(4w) the windowed LWE sum
+      // plus (w-1)/(4w) is >= +1/(4w) unless every bit is false (then -1/(4w)) and stays below 1/2 - 1/(4w):
+      // its sign bootstrap IS the OR, emitted at +-1/4096 for the next linear stage (SURVEY.md hard part 6).
+      const Geometry& g = L->pool;
+      const size_t out = (size_t)L->out_count;
+      int32_t* z = dev_rows(c, out, W);
+      int32_t* o = dev_rows(c, out, W);
+      rs_pool_shape s{g.H, g.Wd, g.C, g.win_h, g.win_w, g.st_h, g.st_w, 0, 0, g.Ho, g.Wo};
+      RS_CHECK(rs_sumpool_dev(c, z, x.ptr, &s, L->d_pool_bias, 1, nullptr));
+      RS_CHECK(rs_bootstrap_dev(c, o, z, mu4096, out, nullptr));
+      RS_CHECK(rs_sync(c));
+      RS_CHECK(rs_dev_free(c, z)); RS_CHECK(rs_dev_free(c, x.ptr));
+      x.ptr = o; x.rows = out;
+    } else if (maxpool) {
       // MaxPooling::execute: OR over the window in (fh, fw) order; the first tap is copied (the
       // reference ORs into an uninitialised accumulator, BinFunc.cpp:891,917), the last OR re-encodes
       // to +-1/4096 for the next linear stage.

@@ -128,9 +128,11 @@ class EncryptedCifar:
     """nets/cifar/binarynet{,_small}/net.cpp:96-209 on a redsec_amd.Backend, device-resident:
     IntLayer(NO_CONV, SIGN); 6 x BinLayer(CONV 3x3 same, SIGN), a 2x2 max-pool after every second one;
     2 x BinLayer(FC, SIGN); BinLayer(FC_FINAL). Same stage order and the same max-pool semantics as the
-    C++ layer mirror (redsec_amd/host/layers.cpp, DESIGN.md "Max-pool semantics"): the sign bootstrap
-    ahead of a max-pool emits +-1/8, the window is OR-ed in (fh, fw) order starting from a copy of the
-    first tap, the last OR re-encodes to +-1/4096.
+    C++ layer mirror (redsec_amd/host/layers.cpp, DESIGN.md "Max-pool semantics"). maxpool="fused" (the
+    default): the sign bootstrap ahead of a max-pool emits +-1/16 and ONE bootstrap of the windowed sum
+    + 3/16 is the OR of the 2x2 window; maxpool="chain": the bits are emitted as +-1/8 and OR-ed by
+    bootsOR gates in (fh, fw) order starting from a copy of the first tap, the last OR re-encoding to
+    +-1/4096.
 
     `net`: weights as plain arrays -- bias0 int32[3]; convs [(sign, zero uint8[3][3][Cin][Cout], bias
     int32[Cout])]; fcs [(sign, zero uint8[K][M], bias int32[M])], the last one being the logits layer
@@ -140,13 +142,16 @@ class EncryptedCifar:
 
     MU8 = 1 << 29   # modSwitchToTorus32(1, 8): the encoding bootsOR assumes
 
-    def __init__(self, backend, net):
+    def __init__(self, backend, net, maxpool="fused"):
         import torch
+        assert maxpool in ("fused", "chain")
         self.be = backend
+        self.maxpool = maxpool
         dev = "cuda:%d" % backend.device
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         tor = MnistSignNet.bias_to_torus
         self.bias0 = t(tor(net.bias0))
+        self.pool_bias = t(np.array([3 << 28], np.int64).astype(np.uint32).view(np.int32))   # (w - 1) / (4 w), w = 4
         self.convs = [(t(s), t(z), t(tor(b))) for s, z, b in net.convs]
         self.fcs = [(t(s), t(z), t(tor(b))) for s, z, b in net.fcs]
         self._pool_index = {}
@@ -182,8 +187,15 @@ class EncryptedCifar:
             pre = be.conv_ternary(bits.view(H, Wd, C, W), sign, zero, shape, zero_tap_b=0, pad_tap_b=0, bias_b=bias).view(-1, W)
             C = Cout
             pooled = li % 2 == 1
-            bits = stage(lambda r: be.bootstrap(r, self.MU8 if pooled else MU_SIGN), pre)
-            if pooled:
+            fused = pooled and self.maxpool == "fused"
+            mu = MU_SIGN if not pooled else ((1 << 28) if fused else self.MU8)
+            bits = stage(lambda r: be.bootstrap(r, mu), pre)
+            if fused:
+                win = dict(H=H, Wd=Wd, C=C, win_h=2, win_w=2, stride_h=2, stride_w=2, off_h=0, off_w=0, Ho=H // 2, Wo=Wd // 2)
+                pre = be.sumpool(bits.view(H, Wd, C, W), win, bias_b=self.pool_bias).view(-1, W)
+                bits = stage(lambda r: be.bootstrap(r, MU_SIGN), pre)
+                H //= 2; Wd //= 2
+            elif pooled:
                 idx = self._pool(H, Wd, C)
                 acc = be.gather_rows(bits, idx[0])
                 for tp in range(1, 4):

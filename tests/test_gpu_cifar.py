@@ -31,3 +31,8 @@ def test_binarynet_small_python_chain_matches_plaintext_model():
     assert be.rounding_certificate() < 0.2
     # unsharded call of the sharded entry point (no process group): identical ciphertexts
     assert torch.equal(enc.run(ct, shard=False), out)
+    # the OR-chain form of the max-pool computes the same bits: logits decrypt to the same class and stay
+    # close (the two forms differ only in noise, which moves weak-margin units of the following layers)
+    chain = sk.decrypt_ints(nets.EncryptedCifar(be, net, maxpool="chain").run(ct).cpu().numpy())
+    assert int(np.argmax(chain)) == int(labels[i])
+    assert np.corrcoef(chain, logits)[0, 1] > 0.5
