@@ -428,6 +428,45 @@ __device__ __forceinline__ void glds_chunks(const double* gsrc_wave_base, unsign
   }
 }
 
+// Pointwise multiply-accumulate of a transform PAIR against its two key rows in LDS (FFT policies), as one
+// stream: 8 steps of two complex positions (4 ds_read_b128: both columns), the reads of step k+1 issued
+// before the FMAs of step k. Read in four blocks of 8 with the FMAs after each block (mac_row), every
+// block exposed a fresh LDS latency because the FMAs of a block drain its reads (in-order return).
+#if defined(RS_NO_MAC_STREAM)
+#define RS_MAC_FENCE() ((void)0)
+#else
+#define RS_MAC_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+__device__ __forceinline__ void mac_pair_stream(double (&s0)[kRegs], double (&s1)[kRegs], const double (&xa)[kRegs], const double (&xb)[kRegs],
+                                                const double* keyA, const double* keyB, int lane) {
+  const double2* ka = reinterpret_cast<const double2*>(keyA);
+  const double2* kb = reinterpret_cast<const double2*>(keyB);
+  double2 u[2][4];
+  auto issue = [&](int step, double2 (&w)[4]) {
+    const double2* k0 = step < 4 ? ka : kb;
+    const double2* k1 = k0 + kN / 2;
+    const int v = 2 * (step & 3);
+    w[0] = k0[v * 64 + lane]; w[1] = k0[(v + 1) * 64 + lane];
+    w[2] = k1[v * 64 + lane]; w[3] = k1[(v + 1) * 64 + lane];
+  };
+  auto fma = [&](int step, const double2 (&w)[4]) {
+    const double (&x)[kRegs] = step < 4 ? xa : xb;
+    const int v = 2 * (step & 3);
+    fft_cmac(s0[v], s0[v + 8], x[v], x[v + 8], w[0].x, w[0].y);
+    fft_cmac(s0[v + 1], s0[v + 9], x[v + 1], x[v + 9], w[1].x, w[1].y);
+    fft_cmac(s1[v], s1[v + 8], x[v], x[v + 8], w[2].x, w[2].y);
+    fft_cmac(s1[v + 1], s1[v + 9], x[v + 1], x[v + 9], w[3].x, w[3].y);
+  };
+  issue(0, u[0]);
+#pragma unroll
+  for (int step = 0; step < 8; ++step) {
+    if (step + 1 < 8) issue(step + 1, u[(step + 1) & 1]);
+    RS_MAC_FENCE();
+    fma(step, u[step & 1]);
+    RS_MAC_FENCE();
+  }
+}
+
 template <class Xf, int WPB>
 __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateArgs a) {
   using C = typename Xf::Cfg;
@@ -534,8 +573,12 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (work) {
+#ifdef RS_NO_MAC_STREAM
           mac_row(s0, s1, xa, 0);
           mac_row(s0, s1, xb, 1);
+#else
+          mac_pair_stream(s0, s1, xa, xb, s_key[0], s_key[1], lane);
+#endif
         }
         __syncthreads();
         R += 2;
@@ -689,8 +732,12 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                         // quad (i, p) published
         if (work) {
+#ifdef RS_NO_MAC_STREAM
           mac_row(s0, s1, xa, 2 * h);
           mac_row(s0, s1, xb, 2 * h + 1);
+#else
+          mac_pair_stream(s0, s1, xa, xb, s_key[2 * h], s_key[2 * h + 1], lane);
+#endif
         }
         __syncthreads();                         // every wave has finished reading it
         if (p + 1 < C::L / 2) issue_quad(i, p + 1);

@@ -151,13 +151,24 @@ template <int S, class TW>
 RS_HD void fft_tw_even(const TW& t, int k, double& wr, double& wi) {
   if (S < 3) fft_tw_uniform<S>(k, wr, wi); else fft_tw_get<S>(t, k, wr, wi);
 }
+// The (at most two) EVEN twiddles one lane needs for stage S, fetched ahead of their use. A wavefront's
+// LDS operations return in order: a twiddle read issued AFTER an exchange's burst of plane loads/stores
+// can only be waited for by draining that whole burst (s_waitcnt lgkmcnt(0) in front of every butterfly
+// stage), whereas one issued BEFORE the burst is waited for with a counted lgkmcnt(N) and the burst
+// stays in flight behind the butterflies.
+struct FftStageTw { double wr[2], wi[2]; };
 template <int S, class TW>
-RS_HD void fft_stage_fwd(double (&x)[kRegs], const TW& t) {
+RS_HD void fft_stage_tw(const TW& t, FftStageTw& w) {
+  constexpr int g = S % 3, shift = 3 - g, ntw = kCRegs >> shift;
+#pragma unroll
+  for (int k = 0; k < ntw; k += 2) fft_tw_even<S>(t, k, w.wr[k >> 1], w.wi[k >> 1]);
+}
+template <int S>
+RS_HD void fft_stage_fwd_tw(double (&x)[kRegs], const FftStageTw& w) {
   constexpr int g = S % 3, half = 4 >> g, shift = 3 - g, ntw = kCRegs >> shift;
 #pragma unroll
   for (int k = 0; k < ntw; k += 2) {
-    double wr, wi;
-    fft_tw_even<S>(t, k, wr, wi);
+    const double wr = w.wr[k >> 1], wi = w.wi[k >> 1];
     const int e = k << shift;                              // elements [e, e + 2 half) use twiddle k
 #pragma unroll
     for (int c = 0; c < half; ++c) fft_bfly_fwd(x[e + c], x[e + c + 8], x[e + c + half], x[e + c + half + 8], wr, wi);
@@ -168,13 +179,12 @@ RS_HD void fft_stage_fwd(double (&x)[kRegs], const TW& t) {
     }
   }
 }
-template <int S, class TW>
-RS_HD void fft_stage_inv(double (&x)[kRegs], const TW& t) {
+template <int S>
+RS_HD void fft_stage_inv_tw(double (&x)[kRegs], const FftStageTw& w) {
   constexpr int g = S % 3, half = 4 >> g, shift = 3 - g, ntw = kCRegs >> shift;
 #pragma unroll
   for (int k = 0; k < ntw; k += 2) {
-    double wr, wi;
-    fft_tw_even<S>(t, k, wr, wi);
+    const double wr = w.wr[k >> 1], wi = w.wi[k >> 1];
     const int e = k << shift;
 #pragma unroll
     for (int c = 0; c < half; ++c) fft_bfly_inv(x[e + c], x[e + c + 8], x[e + c + half], x[e + c + half + 8], wr, wi);
@@ -184,6 +194,18 @@ RS_HD void fft_stage_inv(double (&x)[kRegs], const TW& t) {
       for (int c = 0; c < half; ++c) fft_bfly_inv_i(x[o + c], x[o + c + 8], x[o + c + half], x[o + c + half + 8], wr, wi);
     }
   }
+}
+template <int S, class TW>
+RS_HD void fft_stage_fwd(double (&x)[kRegs], const TW& t) {
+  FftStageTw w;
+  fft_stage_tw<S>(t, w);
+  fft_stage_fwd_tw<S>(x, w);
+}
+template <int S, class TW>
+RS_HD void fft_stage_inv(double (&x)[kRegs], const TW& t) {
+  FftStageTw w;
+  fft_stage_tw<S>(t, w);
+  fft_stage_inv_tw<S>(x, w);
 }
 
 RS_HD void fbuf_store(double* buf, int pos, double re, double im) { buf[2 * pos] = re; buf[2 * pos + 1] = im; }
@@ -314,43 +336,92 @@ RS_HD void fft_inv3(double (&x)[kRegs], const TW& t) { fft_stage_inv<3 * G + 2>(
 // Exchange of x with `work(0..2)` -- three butterfly stages of the OTHER transform -- placed between
 // its LDS phases, so that the vector ALU has independent work while the stores drain (a 16-byte-per-
 // lane store occupies the LDS issue path for ~13 cycles) and the loads return.
-template <bool PLANAR, int L0, int L1, int T, class Sync, class Work>
-RS_HD void fft_exchange_with(int lane, double (&x)[kRegs], double* buf, Sync sync, Work work) {
+// The burst must be ISSUED before the butterflies it overlaps with: the instruction scheduler is free to
+// hoist run(k)'s vector instructions (no memory operands) above the LDS instructions of the burst, which
+// keeps the LDS pipe idle during the butterflies and exposes the burst's latency afterwards.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RS_ISSUE_FENCE_ON)
+#define RS_ISSUE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define RS_ISSUE_FENCE() ((void)0)
+#endif
+template <bool PLANAR, int L0, int L1, int T, class Sync, class Pre, class Run>
+RS_HD void fft_exchange_with(int lane, double (&x)[kRegs], double* buf, Sync sync, Pre pre, Run run) {
+  // pre(k) issues the twiddle reads of work chunk k, run(k) is its butterflies. Every pre() is issued a
+  // whole LDS burst AHEAD of its run() (see FftStageTw): wherever the scheduler then puts the burst that
+  // run(k) overlaps with, the twiddles of run(k) are older than it and are waited for with a counted lgkmcnt.
   if (PLANAR) {
-    fpl_store<L0, T, 0>(lane, x, buf); work(0); sync();
-    fpl_load<L1, T, 0>(lane, x, buf); work(1); sync();
-    fpl_store<L0, T, 1>(lane, x, buf); work(2); sync();
+    pre(0); pre(1); sync(); fpl_store<L0, T, 0>(lane, x, buf); RS_ISSUE_FENCE(); run(0); sync();
+    pre(2); sync(); fpl_load<L1, T, 0>(lane, x, buf); RS_ISSUE_FENCE(); run(1); sync();
+    fpl_store<L0, T, 1>(lane, x, buf); RS_ISSUE_FENCE(); run(2); sync();
     fpl_load<L1, T, 1>(lane, x, buf); sync();
   } else {
-    fil_store<L0, T>(lane, x, buf); work(0); work(1); sync();
-    fil_load<L1, T>(lane, x, buf); work(2); sync();
+    pre(0); pre(1); sync(); fil_store<L0, T>(lane, x, buf); RS_ISSUE_FENCE(); run(0); pre(2); run(1); sync();
+    fil_load<L1, T>(lane, x, buf); RS_ISSUE_FENCE(); run(2); sync();
   }
 }
+// k-th stage (in execution order) of group G: twiddle fetch and butterflies
 template <int G, bool INV, class TW>
-RS_HD void fft_group_stage(double (&x)[kRegs], const TW& t, int k) {   // k-th stage (in execution order) of group G
+RS_HD void fft_group_tw(const TW& t, int k, FftStageTw& w) {
   if (!INV) {
-    if (k == 0) fft_stage_fwd<3 * G>(x, t); else if (k == 1) fft_stage_fwd<3 * G + 1>(x, t); else fft_stage_fwd<3 * G + 2>(x, t);
+    if (k == 0) fft_stage_tw<3 * G>(t, w); else if (k == 1) fft_stage_tw<3 * G + 1>(t, w); else fft_stage_tw<3 * G + 2>(t, w);
   } else {
-    if (k == 0) fft_stage_inv<3 * G + 2>(x, t); else if (k == 1) fft_stage_inv<3 * G + 1>(x, t); else fft_stage_inv<3 * G>(x, t);
+    if (k == 0) fft_stage_tw<3 * G + 2>(t, w); else if (k == 1) fft_stage_tw<3 * G + 1>(t, w); else fft_stage_tw<3 * G>(t, w);
   }
+}
+template <int G, bool INV>
+RS_HD void fft_group_run(double (&x)[kRegs], const FftStageTw& w, int k) {
+  if (!INV) {
+    if (k == 0) fft_stage_fwd_tw<3 * G>(x, w); else if (k == 1) fft_stage_fwd_tw<3 * G + 1>(x, w); else fft_stage_fwd_tw<3 * G + 2>(x, w);
+  } else {
+    if (k == 0) fft_stage_inv_tw<3 * G + 2>(x, w); else if (k == 1) fft_stage_inv_tw<3 * G + 1>(x, w); else fft_stage_inv_tw<3 * G>(x, w);
+  }
+}
+// one exchange of x (layout L0 -> L1) overlapped with the three stages of group G of the other transform y
+template <bool PLANAR, int L0, int L1, int T, int G, bool INV, class TW, class Sync>
+RS_HD void fft_exchange_over(int lane, double (&x)[kRegs], double (&y)[kRegs], const TW& t, double* buf, Sync sync) {
+  FftStageTw w[3];
+  fft_exchange_with<PLANAR, L0, L1, T>(lane, x, buf, sync, [&](int k) { fft_group_tw<G, INV>(t, k, w[k]); },
+                                       [&](int k) { fft_group_run<G, INV>(y, w[k], k); });
 }
 
+// three stages of group G with all their twiddle reads issued up front (no LDS burst to hide behind here:
+// fetched stage by stage, each read's latency would be exposed in turn)
+template <int G, class TW>
+RS_HD void fft_fwd3_ahead(double (&x)[kRegs], const TW& t) {
+  FftStageTw w0, w1, w2;
+  fft_stage_tw<3 * G>(t, w0); fft_stage_tw<3 * G + 1>(t, w1); fft_stage_tw<3 * G + 2>(t, w2);
+  fft_stage_fwd_tw<3 * G>(x, w0); fft_stage_fwd_tw<3 * G + 1>(x, w1); fft_stage_fwd_tw<3 * G + 2>(x, w2);
+}
+template <int G, class TW>
+RS_HD void fft_inv3_ahead(double (&x)[kRegs], const TW& t) {
+  FftStageTw w0, w1, w2;
+  fft_stage_tw<3 * G + 2>(t, w0); fft_stage_tw<3 * G + 1>(t, w1); fft_stage_tw<3 * G>(t, w2);
+  fft_stage_inv_tw<3 * G + 2>(x, w0); fft_stage_inv_tw<3 * G + 1>(x, w1); fft_stage_inv_tw<3 * G>(x, w2);
+}
 template <bool PLANAR, class TW, class Sync>
 RS_HD void ffwd_pair(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TW& t, double* buf, Sync sync) {
   fft_fwd3<0>(xa, t);
-  fft_exchange_with<PLANAR, kLayA, kLayB, 1>(lane, xa, buf, sync, [&](int k) { fft_group_stage<0, false>(xb, t, k); });
-  fft_exchange_with<PLANAR, kLayA, kLayB, 1>(lane, xb, buf, sync, [&](int k) { fft_group_stage<1, false>(xa, t, k); });
-  fft_exchange_with<PLANAR, kLayB, kLayC, 2>(lane, xa, buf, sync, [&](int k) { fft_group_stage<1, false>(xb, t, k); });
-  fft_exchange_with<PLANAR, kLayB, kLayC, 2>(lane, xb, buf, sync, [&](int k) { fft_group_stage<2, false>(xa, t, k); });
+  fft_exchange_over<PLANAR, kLayA, kLayB, 1, 0, false>(lane, xa, xb, t, buf, sync);
+  fft_exchange_over<PLANAR, kLayA, kLayB, 1, 1, false>(lane, xb, xa, t, buf, sync);
+  fft_exchange_over<PLANAR, kLayB, kLayC, 2, 1, false>(lane, xa, xb, t, buf, sync);
+  fft_exchange_over<PLANAR, kLayB, kLayC, 2, 2, false>(lane, xb, xa, t, buf, sync);
+#ifdef RS_NO_TW_AHEAD
   fft_fwd3<2>(xb, t);
+#else
+  fft_fwd3_ahead<2>(xb, t);
+#endif
 }
 template <bool PLANAR, class TW, class Sync>
 RS_HD void finv_pair(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TW& t, double* buf, Sync sync) {
+#ifdef RS_NO_TW_AHEAD
   fft_inv3<2>(xa, t);
-  fft_exchange_with<PLANAR, kLayC, kLayB, 2>(lane, xa, buf, sync, [&](int k) { fft_group_stage<2, true>(xb, t, k); });
-  fft_exchange_with<PLANAR, kLayC, kLayB, 2>(lane, xb, buf, sync, [&](int k) { fft_group_stage<1, true>(xa, t, k); });
-  fft_exchange_with<PLANAR, kLayB, kLayA, 1>(lane, xa, buf, sync, [&](int k) { fft_group_stage<1, true>(xb, t, k); });
-  fft_exchange_with<PLANAR, kLayB, kLayA, 1>(lane, xb, buf, sync, [&](int k) { fft_group_stage<0, true>(xa, t, k); });
+#else
+  fft_inv3_ahead<2>(xa, t);
+#endif
+  fft_exchange_over<PLANAR, kLayC, kLayB, 2, 2, true>(lane, xa, xb, t, buf, sync);
+  fft_exchange_over<PLANAR, kLayC, kLayB, 2, 1, true>(lane, xb, xa, t, buf, sync);
+  fft_exchange_over<PLANAR, kLayB, kLayA, 1, 1, true>(lane, xa, xb, t, buf, sync);
+  fft_exchange_over<PLANAR, kLayB, kLayA, 1, 0, true>(lane, xb, xa, t, buf, sync);
   fft_inv3<0>(xb, t);
 }
 
