@@ -545,8 +545,10 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
     // says every wave has finished reading them, after which the next pair's loads are issued and
     // have the whole next transform pair to land.
     long R = 0;
+    unsigned bara_next = active ? s_bara[wave][0] : 0;   // read one step ahead: its LDS latency is not exposed
     for (int i = 0; i < n; ++i) {
-      const int32_t bara = active ? __builtin_amdgcn_readfirstlane((int)s_bara[wave][i]) : 0;
+      const int32_t bara = __builtin_amdgcn_readfirstlane((int)bara_next);
+      bara_next = (active && i + 1 < n) ? s_bara[wave][i + 1] : 0;
       const bool work = bara != 0;   // tfhe_blindRotate_FFT skips the identity CMUX
       double s0[kRegs], s1[kRegs];
 #pragma unroll
@@ -602,6 +604,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
       }
 
       if (work) {
+#ifdef RS_NO_ACC_AHEAD
         Xf::inverse_pair_wg(lane, s0, s1, tw, buf);
 #pragma unroll
         for (int r = 0; r < kRegs; ++r) {
@@ -609,6 +612,22 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
           acc0[j] = (int32_t)((uint32_t)acc0[j] + (uint32_t)Xf::to_torus(s0[r], dev));
           acc1[j] = (int32_t)((uint32_t)acc1[j] + (uint32_t)Xf::to_torus(s1[r], dev));
         }
+#else
+        // the accumulator words are read BEFORE the inverse pair (the digit transforms are dead, there
+        // are registers to spare): read after it, every read-modify-write of the update exposed an LDS
+        // round trip behind the store in front of it
+        uint32_t a0[kRegs], a1[kRegs];
+#pragma unroll
+        for (int r = 0; r < kRegs; ++r) { a0[r] = (uint32_t)acc0[lane + 64 * r]; a1[r] = (uint32_t)acc1[lane + 64 * r]; }
+        wave_lds_sync();
+        Xf::inverse_pair_wg(lane, s0, s1, tw, buf);
+#pragma unroll
+        for (int r = 0; r < kRegs; ++r) {
+          const int j = lane + 64 * r;
+          acc0[j] = (int32_t)(a0[r] + (uint32_t)Xf::to_torus(s0[r], dev));
+          acc1[j] = (int32_t)(a1[r] + (uint32_t)Xf::to_torus(s1[r], dev));
+        }
+#endif
         wave_lds_sync();
       }
     }
@@ -710,8 +729,10 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
     __syncthreads();   // bara complete; previous group's last reads of the quad buffer are over
     issue_quad(0, 0);
 
+    unsigned bara_next = active ? s_bara[c][0] : 0;   // read one step ahead
     for (int i = 0; i < n; ++i) {
-      const int32_t bara = active ? __builtin_amdgcn_readfirstlane((int)s_bara[c][i]) : 0;
+      const int32_t bara = __builtin_amdgcn_readfirstlane((int)bara_next);
+      bara_next = (active && i + 1 < n) ? s_bara[c][i + 1] : 0;
       const bool work = bara != 0;   // tfhe_blindRotate_FFT skips the identity CMUX
       double s0[kRegs], s1[kRegs];
 #pragma unroll
@@ -758,12 +779,13 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
       __syncthreads();                           // partials consumed: the quad buffer may be refilled
       if (i + 1 < n) issue_quad(i + 1, 0);
       if (work) {
+        uint32_t a0[kRegs];   // accumulator words read ahead of the inverse transform (see the workgroup kernel)
+#pragma unroll
+        for (int r = 0; r < kRegs; ++r) a0[r] = (uint32_t)acc[lane + 64 * r];
+        wave_lds_sync();
         Xf::inverse_wg(lane, mine, tw, buf, f);
 #pragma unroll
-        for (int r = 0; r < kRegs; ++r) {
-          const int j = lane + 64 * r;
-          acc[j] = (int32_t)((uint32_t)acc[j] + (uint32_t)Xf::to_torus(mine[r], dev));
-        }
+        for (int r = 0; r < kRegs; ++r) acc[lane + 64 * r] = (int32_t)(a0[r] + (uint32_t)Xf::to_torus(mine[r], dev));
         wave_lds_sync();
       }
     }

@@ -208,6 +208,20 @@ RS_HD void fft_stage_inv(double (&x)[kRegs], const TW& t) {
   fft_stage_inv_tw<S>(x, w);
 }
 
+// three stages of group G with all their twiddle reads issued up front (no LDS burst to hide behind here:
+// fetched stage by stage, each read's latency would be exposed in turn)
+template <int G, class TW>
+RS_HD void fft_fwd3_ahead(double (&x)[kRegs], const TW& t) {
+  FftStageTw w0, w1, w2;
+  fft_stage_tw<3 * G>(t, w0); fft_stage_tw<3 * G + 1>(t, w1); fft_stage_tw<3 * G + 2>(t, w2);
+  fft_stage_fwd_tw<3 * G>(x, w0); fft_stage_fwd_tw<3 * G + 1>(x, w1); fft_stage_fwd_tw<3 * G + 2>(x, w2);
+}
+template <int G, class TW>
+RS_HD void fft_inv3_ahead(double (&x)[kRegs], const TW& t) {
+  FftStageTw w0, w1, w2;
+  fft_stage_tw<3 * G + 2>(t, w0); fft_stage_tw<3 * G + 1>(t, w1); fft_stage_tw<3 * G>(t, w2);
+  fft_stage_inv_tw<3 * G + 2>(x, w0); fft_stage_inv_tw<3 * G + 1>(x, w1); fft_stage_inv_tw<3 * G>(x, w2);
+}
 RS_HD void fbuf_store(double* buf, int pos, double re, double im) { buf[2 * pos] = re; buf[2 * pos + 1] = im; }
 RS_HD void fbuf_load(const double* buf, int pos, double& re, double& im) { re = buf[2 * pos]; im = buf[2 * pos + 1]; }
 
@@ -223,7 +237,7 @@ RS_HD void ffwd_F2(int lane, double (&x)[kRegs], const TW& t, const double* buf)
   const int b = lane >> 3, q = lane & 7;
 #pragma unroll
   for (int s = 0; s < kCRegs; ++s) fbuf_load(buf, fpos_t1(64 * b + 8 * s + q), x[s], x[s + 8]);
-  fft_stage_fwd<3>(x, t); fft_stage_fwd<4>(x, t); fft_stage_fwd<5>(x, t);
+  fft_fwd3_ahead<1>(x, t);
 }
 RS_HD void ffwd_F3(int lane, const double (&x)[kRegs], double* buf) {
   const int b = lane >> 3, q = lane & 7;
@@ -235,13 +249,13 @@ template <class TW>
 RS_HD void ffwd_F4(int lane, double (&x)[kRegs], const TW& t, const double* buf) {
 #pragma unroll
   for (int u = 0; u < kCRegs; ++u) fbuf_load(buf, fpos_t2(8 * lane + u), x[u], x[u + 8]);
-  fft_stage_fwd<6>(x, t); fft_stage_fwd<7>(x, t); fft_stage_fwd<8>(x, t);
+  fft_fwd3_ahead<2>(x, t);
 }
 
 // ---- inverse (mirror) ----
 template <class TW>
 RS_HD void finv_I1(int lane, double (&x)[kRegs], const TW& t, double* buf) {
-  fft_stage_inv<8>(x, t); fft_stage_inv<7>(x, t); fft_stage_inv<6>(x, t);
+  fft_inv3_ahead<2>(x, t);
 #pragma unroll
   for (int u = 0; u < kCRegs; ++u) fbuf_store(buf, fpos_t2(8 * lane + u), x[u], x[u + 8]);
 }
@@ -250,7 +264,7 @@ RS_HD void finv_I2(int lane, double (&x)[kRegs], const TW& t, const double* buf)
   const int b = lane >> 3, q = lane & 7;
 #pragma unroll
   for (int s = 0; s < kCRegs; ++s) fbuf_load(buf, fpos_t2(64 * b + 8 * s + q), x[s], x[s + 8]);
-  fft_stage_inv<5>(x, t); fft_stage_inv<4>(x, t); fft_stage_inv<3>(x, t);
+  fft_inv3_ahead<1>(x, t);
 }
 RS_HD void finv_I3(int lane, const double (&x)[kRegs], double* buf) {
   const int b = lane >> 3, q = lane & 7;
@@ -303,15 +317,6 @@ RS_HD void fpl_exchange(int lane, double (&x)[kRegs], double* buf, Sync sync) {
   fpl_store<L0, T, 1>(lane, x, buf); sync();
   fpl_load<L1, T, 1>(lane, x, buf); sync();
 }
-template <class TW, class Sync>
-RS_HD void finv_planar(int lane, double (&x)[kRegs], const TW& t, double* buf, Sync sync) {
-  fft_stage_inv<8>(x, t); fft_stage_inv<7>(x, t); fft_stage_inv<6>(x, t);
-  fpl_exchange<kLayC, kLayB, 2>(lane, x, buf, sync);
-  fft_stage_inv<5>(x, t); fft_stage_inv<4>(x, t); fft_stage_inv<3>(x, t);
-  fpl_exchange<kLayB, kLayA, 1>(lane, x, buf, sync);
-  fft_stage_inv<2>(x, t); fft_stage_inv<1>(x, t); fft_stage_inv<0>(x, t);
-}
-
 // ---- two transforms in flight ----
 // A wavefront's LDS operations execute in order, so a second transform may push its exchange through
 // the SAME buffer as soon as the first one's loads have been ISSUED: its stores queue behind them.
@@ -384,19 +389,14 @@ RS_HD void fft_exchange_over(int lane, double (&x)[kRegs], double (&y)[kRegs], c
                                        [&](int k) { fft_group_run<G, INV>(y, w[k], k); });
 }
 
-// three stages of group G with all their twiddle reads issued up front (no LDS burst to hide behind here:
-// fetched stage by stage, each read's latency would be exposed in turn)
-template <int G, class TW>
-RS_HD void fft_fwd3_ahead(double (&x)[kRegs], const TW& t) {
-  FftStageTw w0, w1, w2;
-  fft_stage_tw<3 * G>(t, w0); fft_stage_tw<3 * G + 1>(t, w1); fft_stage_tw<3 * G + 2>(t, w2);
-  fft_stage_fwd_tw<3 * G>(x, w0); fft_stage_fwd_tw<3 * G + 1>(x, w1); fft_stage_fwd_tw<3 * G + 2>(x, w2);
-}
-template <int G, class TW>
-RS_HD void fft_inv3_ahead(double (&x)[kRegs], const TW& t) {
-  FftStageTw w0, w1, w2;
-  fft_stage_tw<3 * G + 2>(t, w0); fft_stage_tw<3 * G + 1>(t, w1); fft_stage_tw<3 * G>(t, w2);
-  fft_stage_inv_tw<3 * G + 2>(x, w0); fft_stage_inv_tw<3 * G + 1>(x, w1); fft_stage_inv_tw<3 * G>(x, w2);
+// single inverse transform, planar exchanges (duo kernel): each group's twiddles fetched up front
+template <class TW, class Sync>
+RS_HD void finv_planar(int lane, double (&x)[kRegs], const TW& t, double* buf, Sync sync) {
+  fft_inv3_ahead<2>(x, t);
+  fpl_exchange<kLayC, kLayB, 2>(lane, x, buf, sync);
+  fft_inv3_ahead<1>(x, t);
+  fpl_exchange<kLayB, kLayA, 1>(lane, x, buf, sync);
+  fft_stage_inv<2>(x, t); fft_stage_inv<1>(x, t); fft_stage_inv<0>(x, t);
 }
 template <bool PLANAR, class TW, class Sync>
 RS_HD void ffwd_pair(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TW& t, double* buf, Sync sync) {
