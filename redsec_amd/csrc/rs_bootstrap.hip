@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "rs_fft.h"
 #include "rs_kernels.h"
@@ -555,19 +556,24 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
       for (int u = 0; u < kRegs; ++u) { s0[u] = 0.0; s1[u] = 0.0; }
       int32_t d[kRegs];
 
+      // d holds the PREPARED rotated difference of one component (gadget offset added and field sign bits
+      // flipped once per component, not per digit row). Written as straight-line code with a
+      // compile-time component: inside the rolled pair loop (run-time component) the compiler issued
+      // its 32 LDS reads one at a time, each followed by a full wait.
+      auto load_d = [&](auto comp_c) {
+        const int32_t* accc = decltype(comp_c)::value ? acc1 : acc0;
+#pragma unroll
+        for (int r = 0; r < kRegs; ++r) d[r] = gadget_prepare<C>(rotated_diff(accc, lane + 64 * r, bara));
+      };
       auto pair = [&](int compA, int qA, int compB, int qB) {
         double xa[kRegs], xb[kRegs];
         if (work) {
-          // d holds the PREPARED rotated difference (gadget offset added and field sign bits flipped once
-          // per component, not per digit row)
-          if (qA == 0) {
-#pragma unroll
-            for (int r = 0; r < kRegs; ++r) d[r] = gadget_prepare<C>(rotated_diff(compA ? acc1 : acc0, lane + 64 * r, bara));
+          if constexpr (C::L % 2 != 0) {
+            if (qA == 0) { if (compA) load_d(std::true_type{}); else load_d(std::false_type{}); }
           }
           Xf::digits(xa, d, qA);
-          if (qB == 0) {
-#pragma unroll
-            for (int r = 0; r < kRegs; ++r) d[r] = gadget_prepare<C>(rotated_diff(compB ? acc1 : acc0, lane + 64 * r, bara));
+          if constexpr (C::L % 2 != 0) {
+            if (qB == 0) { if (compB) load_d(std::true_type{}); else load_d(std::false_type{}); }
           }
           Xf::digits(xb, d, qB);
           Xf::fwd_pair_wg(lane, xa, xb, tw, buf);
@@ -587,12 +593,12 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
         if (R < total_rows) { issue_row(R); issue_row(R + 1); }
       };
       if constexpr (C::L % 2 == 0) {
+        if (work) load_d(std::false_type{});
 #pragma unroll 1
-        for (int comp = 0; comp < 2; ++comp) {
+        for (int q = 0; q < C::L; q += 2) pair(0, q, 0, q + 1);
+        if (work) { Xf::mid(s0, s1, f); load_d(std::true_type{}); }
 #pragma unroll 1
-          for (int q = 0; q < C::L; q += 2) pair(comp, q, comp, q + 1);
-          if (comp == 0 && work) Xf::mid(s0, s1, f);
-        }
+        for (int q = 0; q < C::L; q += 2) pair(1, q, 1, q + 1);
       } else {
         // odd l: the middle pair straddles the two accumulator components (no place for Xf::mid:
         // the workgroup form is only instantiated for policies whose mid() is empty)
