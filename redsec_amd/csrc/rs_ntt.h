@@ -128,11 +128,81 @@ RS_HD void fwd_stage_regs(double (&x)[kRegs], int s, int half, const double* tw,
   }
 }
 
+// A wavefront's LDS reads return in order: a twiddle read issued right before its butterflies is waited
+// for with everything older still in flight drained, and at one or two waves per SIMD its own latency is
+// exposed every time (the exact-NTT blind rotation had ~40 such waits per transform). The phases below
+// therefore fetch the twiddles of stage s+1 BEFORE the butterflies of stage s (RS_LDS_FENCE pins the
+// reads there; it is a compiler-only fence). Same operations on the same values: bit-identical.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RS_LDS_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#else
+#define RS_LDS_FENCE() ((void)0)
+#endif
+// the 16 >> SHIFT twiddles of a stage whose pairs are (e, e + half), half = 1 << (SHIFT - 1)
+template <int SHIFT>
+RS_HD void stage_tw_load(double (&w)[kRegs >> SHIFT], const double* tw, int tw_base, int stride) {
+#pragma unroll
+  for (int k = 0; k < (kRegs >> SHIFT); ++k) w[k] = tw[tw_base + k * stride];
+}
+template <class C, int SHIFT>
+RS_HD void fwd_stage_tw(double (&x)[kRegs], int s, const double (&w)[kRegs >> SHIFT], const Field& f) {
+  constexpr int half = 1 << (SHIFT - 1);
+#pragma unroll
+  for (int e = 0; e < kRegs; ++e) {
+    if (e & half) continue;
+    const double v = f_mulmod(x[e + half], w[e >> SHIFT], f);
+    const double u = x[e];
+    x[e] = u + v;
+    x[e + half] = u - v;
+  }
+  if (C::FWD_MASK & (1u << s)) {
+#pragma unroll
+    for (int e = 0; e < kRegs; ++e) x[e] = f_reduce(x[e], f);
+  }
+}
+template <class C, int SHIFT>
+RS_HD void inv_stage_tw(double (&x)[kRegs], int s, const double (&w)[kRegs >> SHIFT], const Field& f) {
+  constexpr int half = 1 << (SHIFT - 1);
+#pragma unroll
+  for (int e = 0; e < kRegs; ++e) {
+    if (e & half) continue;
+    const double u = x[e], v = x[e + half];
+    x[e] = u + v;
+    x[e + half] = f_mulmod(u - v, w[e >> SHIFT], f);
+  }
+  if (C::INV_MASK & (1u << s)) {
+#pragma unroll
+    for (int e = 0; e < kRegs; ++e) x[e] = f_reduce(x[e], f);
+  }
+}
+// four consecutive stages with shifts 4, 3, 2, 1 (halves 8, 4, 2, 1): forward order / inverse order
+template <class C>
+RS_HD void fwd_four_stages(double (&x)[kRegs], int s0, const double* tw, int base0, int base1, int base2, int base3, int stride, const Field& f) {
+  double w0[1], w1[2], w2[4], w3[8];
+  stage_tw_load<4>(w0, tw, base0, stride); stage_tw_load<3>(w1, tw, base1, stride); RS_LDS_FENCE();
+  fwd_stage_tw<C, 4>(x, s0, w0, f);
+  stage_tw_load<2>(w2, tw, base2, stride); RS_LDS_FENCE();
+  fwd_stage_tw<C, 3>(x, s0 + 1, w1, f);
+  stage_tw_load<1>(w3, tw, base3, stride); RS_LDS_FENCE();
+  fwd_stage_tw<C, 2>(x, s0 + 2, w2, f);
+  fwd_stage_tw<C, 1>(x, s0 + 3, w3, f);
+}
+template <class C>
+RS_HD void inv_four_stages(double (&x)[kRegs], int s0, const double* twi, int base0, int base1, int base2, int base3, int stride, const Field& f) {
+  // halves 1, 2, 4, 8 = shifts 1, 2, 3, 4
+  double w0[8], w1[4], w2[2], w3[1];
+  stage_tw_load<1>(w0, twi, base0, stride); stage_tw_load<2>(w1, twi, base1, stride); RS_LDS_FENCE();
+  inv_stage_tw<C, 1>(x, s0, w0, f);
+  stage_tw_load<3>(w2, twi, base2, stride); stage_tw_load<4>(w3, twi, base3, stride); RS_LDS_FENCE();
+  inv_stage_tw<C, 2>(x, s0 + 1, w1, f);
+  inv_stage_tw<C, 3>(x, s0 + 2, w2, f);
+  inv_stage_tw<C, 4>(x, s0 + 3, w3, f);
+}
+
 // F1: stages 0..3 on layout A, then store for transpose 1.
 template <class C>
 RS_HD void fwd_F1(int lane, double (&x)[kRegs], const double* tw, double* buf, const Field& f) {
-#pragma unroll
-  for (int s = 0; s < 4; ++s) fwd_stage_regs<C>(x, s, 8 >> s, tw, 1 << s, 4 - s, 1, f);
+  fwd_four_stages<C>(x, 0, tw, 1, 2, 4, 8, 1, f);
 #pragma unroll
   for (int r = 0; r < kRegs; ++r) buf[lane + 68 * r] = x[r];
 }
@@ -179,8 +249,12 @@ RS_HD void fwd_F1_digits(int lane, double (&x)[kRegs], const int32_t (&d)[kRegs]
     x[g + 8] = b + e;
     x[g + 12] = b - e;
   }
-#pragma unroll
-  for (int s = 2; s < 4; ++s) fwd_stage_regs<C>(x, s, 8 >> s, tw, 1 << s, 4 - s, 1, f);
+  {
+    double w2[4], w3[8];
+    stage_tw_load<2>(w2, tw, 4, 1); stage_tw_load<1>(w3, tw, 8, 1); RS_LDS_FENCE();
+    fwd_stage_tw<C, 2>(x, 2, w2, f);
+    fwd_stage_tw<C, 1>(x, 3, w3, f);
+  }
 #pragma unroll
   for (int r = 0; r < kRegs; ++r) buf[lane + 68 * r] = x[r];
 }
@@ -190,8 +264,7 @@ RS_HD void fwd_F2(int lane, double (&x)[kRegs], const double* tw, const double* 
   const int b = lane >> 2, q = lane & 3;
 #pragma unroll
   for (int s = 0; s < kRegs; ++s) x[s] = buf[68 * b + 4 * s + q];
-#pragma unroll
-  for (int s = 4; s < 8; ++s) fwd_stage_regs<C>(x, s, 8 >> (s - 4), tw, (1 << s) + b, 8 - s, 16, f);
+  fwd_four_stages<C>(x, 4, tw, 16 + b, 32 + b, 64 + b, 128 + b, 16, f);
 }
 // F3: store for transpose 2.
 RS_HD void fwd_F3(int lane, const double (&x)[kRegs], double* buf) {
@@ -204,8 +277,12 @@ template <class C>
 RS_HD void fwd_F4(int lane, double (&x)[kRegs], const double* tw, const double* buf, const Field& f) {
 #pragma unroll
   for (int u = 0; u < kRegs; ++u) x[u] = buf[18 * lane + u];
-  fwd_stage_regs<C>(x, 8, 2, tw, 256 + lane, 2, 64, f);
-  fwd_stage_regs<C>(x, 9, 1, tw, 512 + lane, 1, 64, f);
+  {
+    double w8[4], w9[8];
+    stage_tw_load<2>(w8, tw, 256 + lane, 64); stage_tw_load<1>(w9, tw, 512 + lane, 64); RS_LDS_FENCE();
+    fwd_stage_tw<C, 2>(x, 8, w8, f);
+    fwd_stage_tw<C, 1>(x, 9, w9, f);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -232,8 +309,12 @@ template <class C>
 RS_HD void inv_I1(int lane, double (&x)[kRegs], const double* twi, double* buf, const Field& f) {
 #pragma unroll
   for (int u = 0; u < kRegs; ++u) x[u] = f_reduce(x[u], f);
-  inv_stage_regs<C>(x, 0, 1, twi, 512 + lane, 1, 64, f);
-  inv_stage_regs<C>(x, 1, 2, twi, 256 + lane, 2, 64, f);
+  {
+    double w0[8], w1[4];
+    stage_tw_load<1>(w0, twi, 512 + lane, 64); stage_tw_load<2>(w1, twi, 256 + lane, 64); RS_LDS_FENCE();
+    inv_stage_tw<C, 1>(x, 0, w0, f);
+    inv_stage_tw<C, 2>(x, 1, w1, f);
+  }
 #pragma unroll
   for (int u = 0; u < kRegs; ++u) buf[18 * lane + u] = x[u];
 }
@@ -243,8 +324,7 @@ RS_HD void inv_I2(int lane, double (&x)[kRegs], const double* twi, const double*
   const int b = lane >> 2, q = lane & 3;
 #pragma unroll
   for (int s = 0; s < kRegs; ++s) x[s] = buf[72 * b + 4 * s + q + 2 * (s >> 2)];
-#pragma unroll
-  for (int s = 2; s < 6; ++s) inv_stage_regs<C>(x, s, 1 << (s - 2), twi, (512 >> s) + b, s - 1, 16, f);
+  inv_four_stages<C>(x, 2, twi, 128 + b, 64 + b, 32 + b, 16 + b, 16, f);
 }
 // I3: store (transpose 1 positions).
 RS_HD void inv_I3(int lane, const double (&x)[kRegs], double* buf) {
@@ -257,8 +337,7 @@ template <class C>
 RS_HD void inv_I4(int lane, double (&x)[kRegs], const double* twi, const double* buf, const Field& f) {
 #pragma unroll
   for (int r = 0; r < kRegs; ++r) x[r] = buf[lane + 68 * r];
-#pragma unroll
-  for (int s = 6; s < 10; ++s) inv_stage_regs<C>(x, s, 1 << (s - 6), twi, 512 >> s, s - 5, 1, f);
+  inv_four_stages<C>(x, 6, twi, 8, 4, 2, 1, 1, f);
 #pragma unroll
   for (int r = 0; r < kRegs; ++r) x[r] = f_reduce(x[r], f);
 }
