@@ -540,6 +540,10 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
     __syncthreads();
     issue_row(0);
     issue_row(1);
+#ifdef RS_T_STAGGER   // timing experiments only: start the waves RS_T_STAGGER x 64 cycles apart
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int w = 0; w < wave * RS_T_STAGGER; ++w) __builtin_amdgcn_s_sleep(1);
+#endif
 
     // Rows are processed in PAIRS (R, R+1), the two digit transforms interleaved phase by phase.
     // Barrier 1 of a pair publishes both rows (each wave first waits for its own shares); barrier 2
@@ -578,8 +582,10 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
           Xf::digits(xb, d, qB);
           Xf::fwd_pair_wg(lane, xa, xb, tw, buf);
         }
+#ifndef RS_T_NOBAR   // timing experiments only (results are wrong without the barriers)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#endif
         if (work) {
 #ifdef RS_NO_MAC_STREAM
           mac_row(s0, s1, xa, 0);
@@ -588,9 +594,11 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
           mac_pair_stream(s0, s1, xa, xb, s_key[0], s_key[1], lane);
 #endif
         }
+#ifndef RS_T_NOBAR
         __syncthreads();
         R += 2;
         if (R < total_rows) { issue_row(R); issue_row(R + 1); }
+#endif
       };
       if constexpr (C::L % 2 == 0) {
         if (work) load_d(std::false_type{});
