@@ -15,6 +15,11 @@
 // LDS transposes, multiplied against the coalesced-streamed key row and accumulated in registers,
 // and two inverse transforms update the accumulator. Waves never synchronise with each other after
 // the twiddle tables are staged.
+//
+// Build-time switches, all OFF in the product build (tools/build_variant.sh passes them for same-box A/B runs):
+//   RS_NO_MAC_STREAM, RS_NO_TW_AHEAD, RS_NO_ACC_AHEAD, RS_NO_SPLIT_STORES   the previous form of one optimisation
+//   RS_ISSUE_FENCE_ON                                   sched_barrier after every exchange burst (measured: -0.5 %)
+//   RS_NO_CERT, RS_T_NOBAR, RS_T_STAGGER=<n>, RS_T_HALFSTORE, RS_T_HALFLOAD   TIMING PROBES: results are wrong
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
