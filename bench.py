@@ -7,9 +7,11 @@ keyswitch) over one batch of 65,536 ciphertext pairs that are already resident i
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--gates G] [--params default128|redsec_small_v2]
 
-N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL). The gates of a batch are
-independent, so ranks shard the work with no data-path collective ("weak": each rank runs its own
-65,536 gates); the only communication is the barrier and a MAX reduction of the elapsed time.
+N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL); `python bench.py --gpus N` alone starts
+that launcher itself as a child process. The gates of a batch are independent, so ranks shard them with full key
+replicas: "weak" (default) = every rank runs its own 65,536 gates, "--scaling strong" = ONE batch of 65,536 split
+evenly. The outputs are all-gathered over RCCL inside the timed region (the north star's "final RCCL gather"),
+overlapped with the next step's kernels on RCCL's own stream; its un-overlapped cost is reported separately.
 
 Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel (blind rotation) against the HBM
 roofline as the contract asks; `roofline_valu` prices it against the FP64 vector-ALU issue rate,
@@ -70,26 +72,53 @@ def host_cpu_share():
     return n
 
 
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process (this process has
+    not touched the GPU yet: no torch.cuda call, no HIP call) and leave with its exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--gates", type=int, default=65536, help="gates per rank per step")
+    ap.add_argument("--gates", type=int, default=65536, help="gates per step: per rank (weak scaling) or in total (strong scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every rank runs --gates gates; strong = --gates gates are split across the ranks "
+                         "(sharding.shard_range). Either way the outputs are all-gathered over RCCL inside the timed region, "
+                         "overlapped with the next step's kernels (--no-gather leaves the slices where they are)")
+    ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--params", default="default128", choices=["default128", "redsec_small_v2"])
     ap.add_argument("--mode", default="fft", choices=["fft", "exact"],
-                    help="ring arithmetic of the blind rotation: fft = FP64 complex FFT (library default, exact after "
-                         "rounding, run-time certificate); exact = NTT over a 51-bit prime (exact by construction)")
+                    help="ring arithmetic of the blind rotation: fft = FP64 complex FFT rounded to the integer result, every call "
+                         "followed by its certificate-gated exact recomputation on the device (library default); exact = NTT over "
+                         "a 51-bit prime (exact by construction)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="gates timed on the CPU oracle (0 = skip)")
-    ap.add_argument("--no-exact-check", action="store_true", help="skip the full-batch cross-check against the exact-NTT mode")
+    ap.add_argument("--no-exact-check", action="store_true", help="skip the exact-NTT mode leg (its throughput and the full-batch cross-check)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xC0FFEE)
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s): a scaling run must not silently measure another size" % (args.gpus, world))
 
     import numpy as np
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # REDSEC_BENCH_REHEARSAL=1: walk the N>1 code path on a ONE-GPU box (ranks share device 0, gloo
     # instead of RCCL, which refuses two ranks on one device); never set by the driver.
@@ -112,7 +141,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import redsec_amd
-    from redsec_amd import client
+    from redsec_amd import client, sharding
 
     # ---- keys (same on every rank: seeded) and synthetic inputs, resident in HBM before timing ----
     t_setup = time.time()
@@ -120,15 +149,29 @@ def main():
     be = redsec_amd.Backend(redsec_amd.params(args.params), device=local_rank)
     be.load_keys(sk.bk, sk.ksk)
     be.set_mode(args.mode)
-    G = args.gates
-    rng = np.random.default_rng(args.seed + 17 * rank)
-    bits_a = rng.integers(0, 2, G)
-    bits_b = rng.integers(0, 2, G)
+    strong = args.scaling == "strong" and world > 1
+    if strong:
+        # ONE batch of --gates gates, every rank takes a contiguous slice; slices padded to equal length for the gather
+        total_gates = args.gates
+        lo, hi = sharding.shard_range(total_gates, rank, world)
+        width_rows = max(sharding.shard_range(total_gates, r, world)[1] - sharding.shard_range(total_gates, r, world)[0] for r in range(world))
+        rng = np.random.default_rng(args.seed)
+        bits_a_all, bits_b_all = rng.integers(0, 2, total_gates), rng.integers(0, 2, total_gates)
+        bits_a, bits_b = bits_a_all[lo:hi], bits_b_all[lo:hi]
+        G = hi - lo
+    else:
+        G = args.gates
+        total_gates = G * world
+        width_rows = G
+        rng = np.random.default_rng(args.seed + 17 * rank)
+        bits_a, bits_b = rng.integers(0, 2, G), rng.integers(0, 2, G)
     ca_h = sk.encrypt_bits(bits_a, seed=args.seed + 1000 + rank)
     cb_h = sk.encrypt_bits(bits_b, seed=args.seed + 2000 + rank)
     ca = torch.from_numpy(ca_h).to(dev)
     cb = torch.from_numpy(cb_h).to(dev)
-    out = be.empty(G, be.W)
+    gather = world > 1 and not args.no_gather
+    outs = [torch.zeros((width_rows, be.W), dtype=torch.int32, device=dev) for _ in range(2 if gather else 1)]
+    pipe = sharding.OverlappedGather(width_rows, be.W, torch.int32, dev) if gather else None
     be.reserve(G)
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
@@ -138,81 +181,139 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
-    for _ in range(args.warmup):
-        be.gate("NAND", ca, cb, out=out)
+    def step(k):
+        o = outs[k % len(outs)]
+        be.gate("NAND", ca, cb, out=o[:G])
+        return o
+
+    for k in range(args.warmup):
+        step(k)
+    if gather and args.warmup:                     # the first collective also builds the RCCL rings: keep it out of the timed region
+        h, _ = pipe.launch(outs[0])
+        pipe.wait(h)
     torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides ----
     be.set_timing(True)
     br_ms, ks_ms = [], []
+    pending = []
+    gathered = None
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        be.gate("NAND", ca, cb, out=out)
+    for k in range(args.steps):
+        if gather and len(pending) >= 2:
+            pipe.wait(pending[-2])                 # the buffer this step overwrites has left the GPU
+        o = step(k)
         # HIP events recorded on the launch stream around each kernel; reading them waits for the
-        # step (one step is one ~second-long batch, so this costs nothing measurable)
+        # step (one step is one ~third-of-a-second batch, so this costs nothing measurable)
         b_ms, k_ms = be.last_kernel_ms()
         br_ms.append(b_ms); ks_ms.append(k_ms)
+        if gather:
+            h, gathered = pipe.launch(o)           # runs on RCCL's stream while the next step computes
+            pending.append(h)
+    for h in pending[-2:]:
+        pipe.wait(h)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     be.set_timing(False)
     last_br = sum(br_ms) / len(br_ms)   # average launch duration over the timed region
     last_ks = sum(ks_ms) / len(ks_ms)
+    out = outs[(args.steps - 1) % len(outs)][:G]
 
+    gather_ms = None
     if world > 1:
         import torch.distributed as dist
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        if gather:                                  # the same collective alone, un-overlapped, for the record
+            barrier(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            h, _ = pipe.launch(outs[0]); pipe.wait(h)
+            torch.cuda.synchronize()
+            gather_ms = 1e3 * (time.perf_counter() - t1)
 
     # ---- correctness of the timed output: every gate decrypts to NAND(a, b) ----
     got = out.cpu().numpy()
     decrypt_ok = bool(np.array_equal(sk.decrypt_bits(got), 1 - (bits_a & bits_b)))
+    gather_ok = None
+    if gather:
+        # what arrived from the other ranks: this rank's own block is where it belongs, and (strong scaling, where every
+        # rank knows the whole batch's plaintext bits) the WHOLE gathered batch decrypts to the truth table
+        full = gathered.cpu().numpy().reshape(world, width_rows, be.W)
+        gather_ok = bool(np.array_equal(full[rank, :G], got))
+        if strong:
+            whole = np.concatenate([full[r, :sharding.shard_range(total_gates, r, world)[1] - sharding.shard_range(total_gates, r, world)[0]]
+                                    for r in range(world)])
+            gather_ok = gather_ok and bool(np.array_equal(sk.decrypt_bits(whole), 1 - (bits_a_all & bits_b_all)))
 
-    # FFT mode: the WHOLE batch again through the exact-by-construction NTT kernels (outside the timed
-    # region), every output word compared on the device
+    # ---- the other arithmetic mode in the same run: exact-NTT throughput next to the FFT headline, and the WHOLE
+    # batch compared word for word on the device (outside the timed region) ----
     all_equal_exact = None
+    exact_mode = None
     if args.mode == "fft" and not args.no_exact_check:
         be.set_mode("exact")
-        ref_exact = be.gate("NAND", ca, cb)
+        ref_exact = be.gate("NAND", ca, cb)                      # warm-up + the reference result
+        torch.cuda.synchronize()
         all_equal_exact = bool(torch.equal(ref_exact, out))
+        esteps = max(1, min(2, args.steps))
+        barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(esteps):
+            be.gate("NAND", ca, cb, out=ref_exact)
+        torch.cuda.synchronize()
+        e_elapsed = time.perf_counter() - t1
+        if world > 1:
+            import torch.distributed as dist
+            tm = torch.tensor([e_elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            e_elapsed = float(tm.item())
+        exact_mode = {"value": round(total_gates * esteps / e_elapsed, 1), "unit": "bootstraps/s", "ms_per_step": round(1e3 * e_elapsed / esteps, 3),
+                      "steps": esteps, "note": "RS_MODE_EXACT_NTT (exact by construction), same batch, no gather"}
         del ref_exact
         be.set_mode("fft")
 
     # FFT mode: largest distance of any inverse-transform output from an integer over the whole run
-    # (exactness needs < 0.5). None in the exact mode.
+    # (exactness needs < 0.5), and how many calls the device recomputed exactly
     certificate = round(be.rounding_certificate(), 6) if args.mode == "fft" else None
+    recomputed = be.fft_fallbacks() if args.mode == "fft" else None
 
-    total_gates = G * world
     value = total_gates * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
     if rank == 0:
         p = be.p
         info = be.info()
+        launch = be.last_launch()
         # ---- HBM roofline of the dominant kernel (blind rotation), per launch ----
-        # algorithmic bytes: key swept once per R resident ciphertexts
-        # (R = CUs x 8 waves), two input ciphertexts read, one extracted sample written.
-        R = info["num_cus"] * info["waves_per_block"]
+        # algorithmic bytes: key swept once per R resident ciphertexts (R as the launcher
+        # reports it for the kernel form that actually ran), two input ciphertexts read, one extracted sample written.
+        R = launch["resident"]
         bk_bytes = info["bk_device_bytes"]
         per_boot = bk_bytes / R + 2 * be.W * 4 + (p.N + 1) * 4
         alg_bytes = per_boot * G
         achieved = alg_bytes / (last_br * 1e-3) / 1e9
-        # fabric-side traffic of the same launch from the committed rocprofv3 --pmc passes (cannot be
-        # collected from inside the process); only filled when it was measured for this workload
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
-            traffic = pmc.get("%s_%d_%s" % (args.params, G, args.mode), {}).get("traffic_bytes")
-        except Exception:
-            pass
-        wg_form = args.mode == "fft" and G >= 8 * info["num_cus"]   # launcher's choice (rs_bootstrap.hip launch_br_xf)
-        roofline = {"bound": "hbm", "kernel": "blind_rotate_wg_kernel" if wg_form else "blind_rotate_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+        # fabric-side traffic of the same launch: rocprofv3 --pmc passes cannot be collected from inside the process, so
+        # this is READ FROM THE COMMITTED PROFILE of the same command (tools/pmc_traffic.py), and labelled as such
+        traffic, traffic_src = None, None
+        for rnd in ("r02", "r01"):
+            try:
+                path = os.path.join("profiles", rnd, "pmc_traffic.json")
+                pmc = json.load(open(os.path.join(ROOT, path)))
+                traffic = pmc.get("%s_%d_%s" % (args.params, G, args.mode), {}).get("traffic_bytes")
+                if traffic is not None:
+                    traffic_src = "from_committed_profile:" + path
+                    break
+            except Exception:
+                pass
+        kernel_name = {"workgroup": "blind_rotate_wg_kernel", "duo": "blind_rotate_duo_kernel", "per_wave": "blind_rotate_kernel",
+                       "coop2": "blind_rotate_coop_kernel", "coop4": "blind_rotate_coop_kernel"}[launch["form"]]
+        roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel_ms": round(last_br, 3), "algorithmic_bytes_per_launch": int(alg_bytes),
-                    "resident_ciphertexts_per_key_sweep": R}
+                    "resident_ciphertexts_per_key_sweep": R, "waves_per_workgroup": launch["waves_per_block"]}
         fwd_red, inv_red, fused = (2, 3, 36) if p.bk_l == 3 else (0, 1, 48)
         ops_per = fp64_ops_per_bootstrap_fft(p.n, p.bk_l) if args.mode == "fft" else \
             fp64_ops_per_bootstrap(p.n, p.bk_l, fwd_red, inv_red, fused)
@@ -265,17 +366,23 @@ def main():
         line = {
             "metric": "gate bootstraps/sec (N=1024)", "value": round(value, 1), "unit": "bootstraps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 torus; ring products in f64 (%s)" % ("complex FFT, exact after rounding" if args.mode == "fft" else "exact NTT mod a 51-bit prime"),
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "int32 torus; ring products in f64 (%s)" % ("complex FFT, exact after rounding" if args.mode == "fft" else "exact NTT mod a 51-bit prime"),
             "data": "synthetic",
-            "config": {"workload": "%d independent bootstrapped NAND gates per GPU, %s (n=%d N=%d l=%d Bgbit=%d t=%d basebit=%d)"
+            "config": {"workload": "%d independent bootstrapped NAND gates per GPU per step, %s (n=%d N=%d l=%d Bgbit=%d t=%d basebit=%d)"
                                    % (G, args.params, p.n, p.N, p.bk_l, p.bk_Bgbit, p.ks_t, p.ks_basebit),
-                       "gates_per_gpu": G, "params": args.params, "mode": args.mode, "parallelism": "gate-sharded x%d, no data-path collective" % world},
-            "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu,
+                       "gates_per_gpu": G, "total_gates": total_gates, "params": args.params, "mode": args.mode,
+                       "parallelism": "gate-sharded x%d%s" % (world, "" if world == 1 else (", outputs all-gathered over RCCL, overlapped with the next step" if gather else ", no gather"))},
+            "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu, "exact_mode": exact_mode,
+            "collective": None if not gather else {"op": "all_gather_into_tensor", "bytes_per_rank": int(width_rows * be.W * 4),
+                                                   "bytes_received_per_rank": int(world * width_rows * be.W * 4),
+                                                   "ms_alone_unoverlapped": round(gather_ms, 3), "inside_timed_region": True,
+                                                   "backend": "gloo (one-GPU rehearsal)" if rehearsal else "nccl (RCCL)"},
             "kernels_ms": {"blind_rotate": round(last_br, 3), "keyswitch": round(last_ks, 3)},
             "checks": {"all_outputs_decrypt_to_nand": decrypt_ok, "bit_exact_vs_oracle_on_sample": parity,
                        "oracle_sample_gates": {"exact_path": int(sample) if args.cpu_sample != 0 else 0},
                        "all_words_equal_exact_ntt_mode_full_batch": all_equal_exact,
-                       "fft_rounding_certificate": certificate},
+                       "fft_rounding_certificate": certificate, "calls_recomputed_exactly_on_device": recomputed,
+                       "gathered_batch_ok": gather_ok},
             "setup_s": round(setup_s, 1),
         }
         print(json.dumps(line), flush=True)

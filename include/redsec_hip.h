@@ -80,34 +80,54 @@ int rs_destroy(rs_ctx* ctx);
  * Transforms bk to the transform domain on the device (the bkFFT analogue). */
 int rs_load_keys(rs_ctx* ctx, const int32_t* bk, const int32_t* ksk);
 
-/* Arithmetic of the external product (both are resident after rs_load_keys; switching is free):
+/* Arithmetic of the external product (both keys are resident after rs_load_keys; switching is free):
  *   RS_MODE_FFT        folded 512-point complex FP64 FFT -- the arithmetic class of TFHE's own
- *                      tGswFFTExternMulToTLwe. The true product is an integer and the FFT error is two
- *                      orders of magnitude below 1/2, so rounding returns exactly the integer result
- *                      (= RS_MODE_EXACT_NTT = the CPU oracle, bit for bit) with overwhelming probability;
- *                      rs_rounding_certificate() reports the largest distance to an integer ever rounded.
- *   RS_MODE_EXACT_NTT  exact negacyclic NTT over a 51-bit prime carried in FP64: guaranteed exact, 2.3x
- *                      the FP64 operations.
- * Default RS_MODE_FFT (environment REDSEC_MODE=exact selects the NTT at context creation). */
+ *                      tGswFFTExternMulToTLwe -- rounded to the nearest integer. The true product is an
+ *                      integer and the FFT error is two orders of magnitude below 1/2, so rounding returns
+ *                      exactly the integer result. Every bootstrapped call records the largest distance to an
+ *                      integer it rounded (its "certificate") and is followed, on the same stream, by the
+ *                      exact-NTT kernels GATED on that certificate: they return at once while it is below the
+ *                      limit and otherwise overwrite the call's result with the exact one before anything
+ *                      downstream reads it. No host round trip; holds for the *_dev calls and the host calls alike.
+ *   RS_MODE_EXACT_NTT  exact negacyclic NTT over a 51-bit prime carried in FP64: exact by construction,
+ *                      2.3x the FP64 operations.
+ * Results are identical word for word in both modes (= the CPU oracle).
+ * Default RS_MODE_FFT (environment REDSEC_MODE=exact selects the NTT at context creation; the environment
+ * is read ONCE, in rs_create). rs_set_mode must not race with launches of the same context. */
 enum { RS_MODE_EXACT_NTT = 0, RS_MODE_FFT = 1 };
 int rs_set_mode(rs_ctx* ctx, int mode);
 int rs_get_mode(rs_ctx* ctx, int* mode);
-/* Largest |x - rint(x)| over every value the FFT path has rounded since the last reset (0 in NTT mode).
- * Anything far below 0.5 certifies that no rounding can have picked a neighbouring integer. */
-int rs_rounding_certificate(rs_ctx* ctx, double* max_distance, int reset);
-/* The synchronous host-pointer calls (rs_bootstrap, rs_gate, rs_mux) certify every call in FFT mode: if a
- * call's largest rounding distance reaches RS_CERTIFICATE_LIMIT the batch is recomputed with the exact NTT
- * before anything is returned. *count = how many calls took that fallback (expected: 0). The asynchronous
- * *_dev calls leave the check to the caller (rs_rounding_certificate at its next synchronisation point). */
+/* A call whose certificate reaches this limit is recomputed exactly on the device (default 0.25: an error
+ * of +-1 needs a distance > 0.5). limit = 0 forces the recomputation of every call (tests). */
 #define RS_CERTIFICATE_LIMIT 0.25
+int rs_set_certificate_limit(rs_ctx* ctx, double limit);
+/* Synchronises `stream` and reports what its calls did since the last reset: the largest rounding distance
+ * and how many calls were recomputed exactly (expected: 0). Either pointer may be NULL. */
+int rs_certify(rs_ctx* ctx, void* stream, double* max_distance, int64_t* recomputed_calls, int reset);
+/* The same over ALL streams of the context (device-wide synchronisation). */
+int rs_rounding_certificate(rs_ctx* ctx, double* max_distance, int reset);
 int rs_fft_fallbacks(rs_ctx* ctx, int64_t* count);
 
-/* Workspace is grown on demand; this pre-sizes it for batches of up to max_batch ciphertexts. */
+/* Streams. A context keeps one private slice of mutable state per stream it has seen (extracted-sample
+ * workspace, work counter, certificate slots, convolution scratch, timing events), so *_dev calls on
+ * DIFFERENT streams of one context may be issued concurrently, also from different host threads; calls on
+ * one stream are ordered by the stream. The synchronous host-pointer calls are serialised per context.
+ * Workspace is grown on demand (a device-wide wait); rs_reserve pre-sizes the default stream's,
+ * rs_reserve_stream a given stream's, for batches of up to max_batch ciphertexts. */
 int rs_reserve(rs_ctx* ctx, size_t max_batch);
+int rs_reserve_stream(rs_ctx* ctx, size_t max_batch, void* stream);
 
 /* out[b] = tfhe_bootstrap_FFT(mu, in[b]) for b < B. */
 int rs_bootstrap_dev(rs_ctx* ctx, int32_t* out, const int32_t* in, int32_t mu, size_t B, void* stream);
 int rs_bootstrap(rs_ctx* ctx, int32_t* out, const int32_t* in, int32_t mu, size_t B);
+
+/* Programmable bootstrap: tfhe_blindRotateAndExtract_FFT with the test polynomial lut[b % lut_count]
+ * (DEVICE int32[lut_count][N]) followed by lweKeySwitch. With pbar = the phase of in[b] mod-switched to
+ * [0, 2N): out[b] encrypts lut[pbar] for pbar < N and -lut[pbar - N] beyond. Serves the corrected
+ * Quantize::relu_shift (lib/IntFunc.cpp:934-973, lib/BinFunc.cpp:1120-1162): one bootstrap per neuron
+ * evaluates clamp((slope x + bias) >> slope_bits, 0, 2^shift_bits - 1), see DESIGN.md "ReLU semantics". */
+int rs_bootstrap_lut_dev(rs_ctx* ctx, int32_t* out, const int32_t* in, const int32_t* lut, size_t lut_count, size_t B,
+                         void* stream);
 
 /* out[b] = boots<OP>(a[b], b[b]) (mu = 1/8 encoding). */
 int rs_gate_dev(rs_ctx* ctx, rs_gate_op op, int32_t* out, const int32_t* a, const int32_t* b, size_t B, void* stream);
@@ -182,9 +202,14 @@ int rs_sync(rs_ctx* ctx);
 /* Time (ms) of the kernels enqueued by the last *_dev / host call, by HIP events on the stream the
  * kernels ran on; -1 if not available. Index: 0 blind-rotate, 1 keyswitch. */
 int rs_set_timing(rs_ctx* ctx, int enable);
-int rs_last_kernel_ms(rs_ctx* ctx, float* blind_rotate_ms, float* keyswitch_ms);
+int rs_last_kernel_ms(rs_ctx* ctx, float* blind_rotate_ms, float* keyswitch_ms);               /* default stream */
+int rs_last_kernel_ms_stream(rs_ctx* ctx, void* stream, float* blind_rotate_ms, float* keyswitch_ms);
 
-/* Static facts used by bench.py's roofline accounting. */
+/* Facts used by bench.py's roofline accounting. rs_last_launch: what the last blind rotation on `stream`
+ * actually ran -- form 0 per-wave, 1 lock-step workgroups, 2 duo, 3 / 4 cooperative (2 / 4 waves per
+ * ciphertext) -- its waves per workgroup, and `resident` = ciphertexts sharing one sweep of the key (R of the
+ * algorithmic-bytes formula). rs_info's waves_per_block is that of the default stream's last launch. */
+int rs_last_launch(rs_ctx* ctx, void* stream, int32_t* form, int32_t* waves_per_block, int64_t* resident);
 int rs_info(rs_ctx* ctx, int64_t* bk_device_bytes, int64_t* ksk_device_bytes, int32_t* waves_per_block,
             int32_t* num_cus);
 

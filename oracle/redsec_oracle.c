@@ -593,13 +593,15 @@ static size_t scratch_i32_words(const ro_params* p) { return (size_t)(p->k + 1) 
 static size_t scratch_u64_words(const ro_params* p) { return (size_t)(p->k + 2) * p->N; }
 
 /* tfhe_bootstrap_woKS_FFT -> tfhe_blindRotateAndExtract_FFT -> tfhe_blindRotate_FFT. */
-static void blind_rotate(const ro_ctx* c, int32_t* acc, int32_t mu, const int32_t* in, int32_t steps) {
+static void blind_rotate_tv(const ro_ctx* c, int32_t* acc, int32_t mu, const int32_t* tv, const int32_t* in, int32_t steps) {
   const int32_t N = c->p.N, k = c->p.k, n = c->p.n, Nx2 = 2 * N;
   int32_t* si = (int32_t*)malloc(sizeof(int32_t) * scratch_i32_words(&c->p));
   uint64_t* su = (uint64_t*)malloc(sizeof(uint64_t) * scratch_u64_words(&c->p));
   int32_t* testvect = (int32_t*)malloc(sizeof(int32_t) * (size_t)N);
   int32_t barb = ro_modswitch_from_torus32(in[n], Nx2);
-  for (int32_t j = 0; j < N; ++j) testvect[j] = mu;
+  /* tfhe_bootstrap_woKS_FFT fills the test vector with mu; tfhe_blindRotateAndExtract_FFT itself takes
+   * an arbitrary test polynomial v (the programmable form: out = v[phase] on [0, 1/2), -v[phase - N] beyond) */
+  for (int32_t j = 0; j < N; ++j) testvect[j] = tv ? tv[j] : mu;
   memset(acc, 0, sizeof(int32_t) * (size_t)(k + 1) * N);
   if (barb != 0) mul_by_xai(acc + (size_t)k * N, Nx2 - barb, testvect, N);
   else memcpy(acc + (size_t)k * N, testvect, sizeof(int32_t) * (size_t)N);
@@ -610,6 +612,10 @@ static void blind_rotate(const ro_ctx* c, int32_t* acc, int32_t mu, const int32_
     cmux_step(c, acc, i, barai, si, su);
   }
   free(si); free(su); free(testvect);
+}
+
+static void blind_rotate(const ro_ctx* c, int32_t* acc, int32_t mu, const int32_t* in, int32_t steps) {
+  blind_rotate_tv(c, acc, mu, NULL, in, steps);
 }
 
 void ro_blind_rotate_acc(const ro_ctx* c, int32_t* acc_out, int32_t mu, const int32_t* in, int32_t steps) {
@@ -632,6 +638,18 @@ void ro_bootstrap_wo_ks(const ro_ctx* c, int32_t* out_extracted, int32_t mu, con
   blind_rotate(c, acc, mu, in, -1);
   sample_extract0(c, out_extracted, acc);
   free(acc);
+}
+
+/* Programmable bootstrap: tfhe_blindRotateAndExtract_FFT with test polynomial `testvect` (N words), then
+ * lweKeySwitch. REDsec: the corrected Quantize::relu_shift (IntFunc.cpp:934-973) evaluates
+ * clamp((slope x + bias) >> slope_bits, 0, 2^shift_bits - 1) as ONE such bootstrap per neuron. */
+void ro_bootstrap_lut(const ro_ctx* c, int32_t* out, const int32_t* testvect, const int32_t* in) {
+  int32_t* acc = (int32_t*)malloc(sizeof(int32_t) * (size_t)(c->p.k + 1) * c->p.N);
+  int32_t* u = (int32_t*)malloc(sizeof(int32_t) * (size_t)(c->p.k * c->p.N + 1));
+  blind_rotate_tv(c, acc, 0, testvect, in, -1);
+  sample_extract0(c, u, acc);
+  ro_keyswitch(c, out, u);
+  free(acc); free(u);
 }
 
 /* TFHE lwe-keyswitch-functions.cpp lweKeySwitch + lweKeySwitchTranslate_fromArray. */
@@ -718,6 +736,12 @@ void ro_mux(const ro_ctx* c, int32_t* out, const int32_t* a, const int32_t* b, c
  * Batches: the REDsec layer loops (BinFunc.cpp:1056-1071, IntFunc.cpp:871-887, BinFunc.cpp:896-921)
  * are OpenMP loops over independent ciphertexts; so is this.
  * ---------------------------------------------------------------------------------------------- */
+void ro_bootstrap_lut_batch(const ro_ctx* c, int32_t* out, const int32_t* luts, size_t lut_count, const int32_t* in, size_t B) {
+  const size_t W = (size_t)c->p.n + 1, N = (size_t)c->p.N;
+#pragma omp parallel for schedule(dynamic)
+  for (long b = 0; b < (long)B; ++b) ro_bootstrap_lut(c, out + (size_t)b * W, luts + ((size_t)b % lut_count) * N, in + (size_t)b * W);
+}
+
 int ro_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -110,6 +110,12 @@ void ro_keyswitch(const ro_ctx* c, int32_t* out, const int32_t* in_extracted);
 /* tfhe_bootstrap_FFT = woKS + keyswitch (REDsec call site: BinOps_enc.cpp:182-192). */
 void ro_bootstrap(const ro_ctx* c, int32_t* out, int32_t mu, const int32_t* in);
 
+/* Programmable bootstrap (tfhe_blindRotateAndExtract_FFT with an arbitrary test polynomial + lweKeySwitch):
+ * out decrypts to testvect[pbar] for the mod-switched phase pbar in [0, N), -testvect[pbar - N] in [N, 2N).
+ * Batch: ciphertext b uses luts[b % lut_count] (N words each). */
+void ro_bootstrap_lut(const ro_ctx* c, int32_t* out, const int32_t* testvect, const int32_t* in);
+void ro_bootstrap_lut_batch(const ro_ctx* c, int32_t* out, const int32_t* luts, size_t lut_count, const int32_t* in, size_t B);
+
 /* Debug tap: run the blind rotate for the first `steps` key indices only and return the TRLWE
  * accumulator (k+1 polynomials of N words). steps<0 means all n. */
 void ro_blind_rotate_acc(const ro_ctx* c, int32_t* acc_out, int32_t mu, const int32_t* in, int32_t steps);

@@ -21,6 +21,7 @@ ABI_SYMBOLS = [
     "rs_gate_mu_dev", "rs_gather_rows_dev", "rs_bootstrap_wo_ks_dev", "rs_keyswitch_dev", "rs_debug_polymul", "rs_linear_fc_dev", "rs_conv_ternary_dev",
     "rs_sumpool_dev", "rs_lincomb_dev", "rs_dev_alloc", "rs_dev_free", "rs_copy_to_dev", "rs_copy_to_host", "rs_sync",
     "rs_set_timing", "rs_last_kernel_ms", "rs_info", "rs_set_mode", "rs_get_mode", "rs_rounding_certificate", "rs_fft_fallbacks",
+    "rs_bootstrap_lut_dev", "rs_set_certificate_limit", "rs_certify", "rs_reserve_stream", "rs_last_kernel_ms_stream", "rs_last_launch",
 ]
 
 GATES = {"NAND": 0, "OR": 1, "AND": 2, "NOR": 3, "XOR": 4, "XNOR": 5, "ANDNY": 6, "ANDYN": 7, "ORNY": 8, "ORYN": 9}
@@ -98,6 +99,12 @@ def load_library(path=None):
     L.rs_get_mode.argtypes = [vp, C.POINTER(C.c_int)]
     L.rs_rounding_certificate.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
     L.rs_fft_fallbacks.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.rs_bootstrap_lut_dev.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_size_t, vp]
+    L.rs_set_certificate_limit.argtypes = [vp, C.c_double]
+    L.rs_certify.argtypes = [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
+    L.rs_reserve_stream.argtypes = [vp, C.c_size_t, vp]
+    L.rs_last_kernel_ms_stream.argtypes = [vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.rs_last_launch.argtypes = [vp, vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     if path is None:
         _lib = L
     return L
@@ -162,7 +169,8 @@ class Backend:
         _check(self.L, self.L.rs_load_keys(self.h, pbk, pksk))
 
     def reserve(self, max_batch):
-        _check(self.L, self.L.rs_reserve(self.h, int(max_batch)))
+        """Pre-size the workspace of torch's current stream."""
+        _check(self.L, self.L.rs_reserve_stream(self.h, int(max_batch), self._stream()))
 
     # ---- torch plumbing ----
     @staticmethod
@@ -187,6 +195,14 @@ class Backend:
         B = x.shape[0]
         out = self.empty(B, self.W) if out is None else out
         _check(self.L, self.L.rs_bootstrap_dev(self.h, self._ck_dev(out, self.W), self._ck_dev(x, self.W), int(mu), B, self._stream()))
+        return out
+
+    def bootstrap_lut(self, x, lut, out=None):
+        """Programmable bootstrap: ciphertext b uses the test polynomial lut[b % len(lut)] (int32 CUDA [L][N])."""
+        B = x.shape[0]
+        out = self.empty(B, self.W) if out is None else out
+        _check(self.L, self.L.rs_bootstrap_lut_dev(self.h, self._ck_dev(out, self.W), self._ck_dev(x, self.W),
+                                                    self._ck_dev(lut, self.p.N), lut.shape[0], B, self._stream()))
         return out
 
     def gate(self, op, a, b, out=None):
@@ -322,10 +338,26 @@ class Backend:
         return d.value
 
     def fft_fallbacks(self):
-        """Host-pointer calls that were recomputed in exact mode because their rounding distance reached 0.25."""
+        """Calls (all streams) whose FFT result was recomputed exactly on the device: certificate >= the limit."""
         n = C.c_int64()
         _check(self.L, self.L.rs_fft_fallbacks(self.h, C.byref(n)))
         return n.value
+
+    def set_certificate_limit(self, limit):
+        """Rounding distance at which a call is recomputed exactly (default 0.25; 0 forces every call)."""
+        _check(self.L, self.L.rs_set_certificate_limit(self.h, float(limit)))
+
+    def certify(self, reset=True):
+        """Synchronise torch's current stream -> (largest rounding distance, calls recomputed exactly) on it."""
+        d, n = C.c_double(), C.c_int64()
+        _check(self.L, self.L.rs_certify(self.h, self._stream(), C.byref(d), C.byref(n), 1 if reset else 0))
+        return d.value, n.value
+
+    def last_launch(self):
+        """(form, waves per workgroup, ciphertexts per key sweep) of the last blind rotation on the current stream."""
+        f, w, r = C.c_int32(), C.c_int32(), C.c_int64()
+        _check(self.L, self.L.rs_last_launch(self.h, self._stream(), C.byref(f), C.byref(w), C.byref(r)))
+        return {"form": ["per_wave", "workgroup", "duo", "coop2", "coop4"][f.value], "waves_per_block": w.value, "resident": r.value}
 
     # ---- timing / facts ----
     def set_timing(self, on=True):
@@ -333,7 +365,7 @@ class Backend:
 
     def last_kernel_ms(self):
         a, b = C.c_float(), C.c_float()
-        _check(self.L, self.L.rs_last_kernel_ms(self.h, C.byref(a), C.byref(b)))
+        _check(self.L, self.L.rs_last_kernel_ms_stream(self.h, self._stream(), C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def info(self):

@@ -99,7 +99,7 @@ REFNETS_DIR = os.path.join(ROOT, "build", "refnets")
 
 
 def build_reference_drivers(verbose=False):
-    """Compile the reference's OWN, UNMODIFIED sources -- nets/mnist/sign1024x{1,2,3}/{net,main}.cpp, nets/cifar/binarynet{,_small}/{net,main}.cpp and
+    """Compile the reference's OWN, UNMODIFIED sources -- nets/mnist/{sign,relu}1024x{1,2,3}/{net,main}.cpp, nets/cifar/binarynet{,_small}/{net,main}.cpp and
     client/{gen_secure_keyset,encrypt_image,decrypt_image}.cpp -- with -DENCRYPTED against the shim
     headers and link them to libredsec_layers.so. Only possible where /root/reference exists; the
     binaries land in build/refnets/ (git-ignored, shipped to the GPU box with the snapshot)."""
@@ -112,6 +112,7 @@ def build_reference_drivers(verbose=False):
               "-Wl,-rpath," + HERE]
     built = []
     for family, net in (("mnist", "sign1024x1"), ("mnist", "sign1024x2"), ("mnist", "sign1024x3"),
+                        ("mnist", "relu1024x1"), ("mnist", "relu1024x2"), ("mnist", "relu1024x3"),
                         ("cifar", "binarynet"), ("cifar", "binarynet_small")):
         d = os.path.join(REF, "nets", family, net)
         out = os.path.join(REFNETS_DIR, "%s_%s_enc.out" % (family, net))

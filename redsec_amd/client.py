@@ -125,9 +125,12 @@ class SecretKeySet:
         e8 = 1 << 29
         return self.encrypt_torus(np.where(np.asarray(bits) != 0, e8, -e8), SECALPHA, seed)
 
-    def encrypt_image(self, pixels, seed=1):
-        """client/encrypt_image.cpp:76-77: ptxt = 2*pixel - 255, message ptxt/4096."""
-        v = 2 * np.asarray(pixels, dtype=np.int64).ravel() - 255
+    def encrypt_image(self, pixels, seed=1, preprocess="sign"):
+        """client/encrypt_image.cpp:76-77: ptxt = 2*pixel - 255, message ptxt/4096. preprocess="relu": the
+        ReLU nets' own input map pixel/100 - 1 (nets/mnist/relu1024x1/main.cpp:203), which the reference's
+        client tool does not know about."""
+        px = np.asarray(pixels, dtype=np.int64).ravel()
+        v = (px // 100 - 1) if preprocess == "relu" else 2 * px - 255
         return self.encrypt_torus(v * (1 << 20), SECALPHA, seed)
 
     def phase(self, ct):
@@ -149,3 +152,88 @@ class SecretKeySet:
     def classify(self, logits_ct):
         """client/decrypt_image.cpp:61-62 argmax."""
         return int(np.argmax(self.decrypt_ints(logits_ct)))
+
+
+# ---- TFHE v1.1 file formats (the reference's client/*.cpp and nets/*/*/main.cpp exchange these files) -------------
+# Same layout as redsec_amd/host/tfhe_shim.cpp writes and reads (see the comment there; [TFHE-recalled]).
+TFHE_UID = dict(lwe_sample=42, lwe_key=43, tlwe_key=45, tgsw_sample=47, ks_key=200, bk_key=201)
+
+
+def _section(title, props):
+    body = "".join("%s: %s\n" % (k, v) for k, v in sorted(props.items()))
+    return ("-----BEGIN %s-----\n%s-----END %s-----\n" % (title, body, title)).encode()
+
+
+def _read_section(f, want):
+    head = f.readline().decode().rstrip("\n")
+    assert head == "-----BEGIN %s-----" % want, (head, want)
+    props = {}
+    while True:
+        line = f.readline().decode().rstrip("\n")
+        if line.startswith("-----END "):
+            return props
+        k, v = line.split(": ", 1)
+        props[k] = v
+
+
+def write_tfhe_keyset(f, sk, secret, ks_stdev, bk_stdev, max_stdev=0.012467):
+    """export_tfheGateBootstrapping{Secret,Cloud}KeySet_toFile for a SecretKeySet (binary file object)."""
+    i32 = lambda v: np.int32(v).tobytes()
+    f.write(_section("GATEBOOTSPARAMS", dict(ks_t=sk.t, ks_basebit=sk.basebit)))
+    f.write(_section("LWEPARAMS", dict(n=sk.n, alpha_min=repr(float(ks_stdev)), alpha_max=repr(float(max_stdev)))))
+    f.write(_section("TLWEPARAMS", dict(N=sk.N, k=sk.k, alpha_min=repr(float(bk_stdev)), alpha_max=repr(float(max_stdev)))))
+    f.write(_section("TGSWPARAMS", dict(l=sk.l, Bgbit=sk.Bgbit)))
+    f.write(i32(TFHE_UID["bk_key"]))
+    f.write(_section("LWEKSPARAMS", dict(n=sk.k * sk.N, t=sk.t, basebit=sk.basebit)))
+    f.write(i32(TFHE_UID["ks_key"]) + np.float64(ks_stdev ** 2).tobytes())
+    f.write(np.ascontiguousarray(sk.ksk, np.int32).tobytes())
+    for i in range(sk.n):
+        f.write(i32(TFHE_UID["tgsw_sample"]) + np.float64(bk_stdev ** 2).tobytes())
+        f.write(np.ascontiguousarray(sk.bk[i], np.int32).tobytes())
+    if secret:
+        f.write(i32(TFHE_UID["lwe_key"]) + np.ascontiguousarray(sk.lwe_key, np.int32).tobytes())
+        f.write(i32(TFHE_UID["tlwe_key"]) + np.ascontiguousarray(sk.tlwe_key, np.int32).tobytes())
+
+
+def read_tfhe_keyset(f, secret):
+    """-> dict(params..., bk [n][2l][2][N], ksk [N][t][base][n+1], and for secret files lwe_key, tlwe_key, uids seen)."""
+    g = _read_section(f, "GATEBOOTSPARAMS"); lw = _read_section(f, "LWEPARAMS")
+    tl = _read_section(f, "TLWEPARAMS"); tg = _read_section(f, "TGSWPARAMS")
+    n, N, k, l, Bgbit = int(lw["n"]), int(tl["N"]), int(tl["k"]), int(tg["l"]), int(tg["Bgbit"])
+    t, basebit = int(g["ks_t"]), int(g["ks_basebit"])
+    rd = lambda count: np.frombuffer(f.read(4 * count), np.int32)
+    uids = [int(rd(1)[0])]
+    ks = _read_section(f, "LWEKSPARAMS")
+    assert (int(ks["n"]), int(ks["t"]), int(ks["basebit"])) == (k * N, t, basebit)
+    uids.append(int(rd(1)[0])); f.read(8)
+    ksk = rd(k * N * t * (1 << basebit) * (n + 1)).reshape(k * N, t, 1 << basebit, n + 1)
+    bk = np.empty((n, (k + 1) * l, k + 1, N), np.int32)
+    for i in range(n):
+        uids.append(int(rd(1)[0])); f.read(8)
+        bk[i] = rd((k + 1) * l * (k + 1) * N).reshape((k + 1) * l, k + 1, N)
+    out = dict(n=n, N=N, k=k, l=l, Bgbit=Bgbit, t=t, basebit=basebit, ks_stdev=float(lw["alpha_min"]), bk_stdev=float(tl["alpha_min"]),
+               bk=bk, ksk=ksk)
+    if secret:
+        uids.append(int(rd(1)[0])); out["lwe_key"] = rd(n).copy()
+        uids.append(int(rd(1)[0])); out["tlwe_key"] = rd(k * N).copy()
+    assert f.read(1) == b"", "trailing bytes in key file"
+    out["uids"] = uids
+    return out
+
+
+def write_ciphertexts(f, ct):
+    """export_gate_bootstrapping_ciphertext_toFile per row of ct [B][n+1]: uid 42, a[n], b, double variance."""
+    ct = np.ascontiguousarray(ct, np.int32)
+    for row in ct:
+        f.write(np.int32(TFHE_UID["lwe_sample"]).tobytes() + row.tobytes() + np.float64(0.0).tobytes())
+
+
+def read_ciphertexts(f, n, count):
+    rec = 4 + 4 * (n + 1) + 8
+    raw = f.read(rec * count)
+    assert len(raw) == rec * count
+    out = np.empty((count, n + 1), np.int32)
+    for i in range(count):
+        assert np.frombuffer(raw[i * rec:i * rec + 4], np.int32)[0] == TFHE_UID["lwe_sample"]
+        out[i] = np.frombuffer(raw[i * rec + 4:i * rec + 4 + 4 * (n + 1)], np.int32)
+    return out

@@ -11,6 +11,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -40,33 +43,48 @@ int fail(int code, const char* fmt, ...) {
 
 }  // namespace
 
-struct rs_ctx {
-  uint32_t* d_conv_scratch = nullptr;   // expanded weights of the tiled convolution (grown on demand)
+// Everything a launch writes besides its outputs lives in a LANE = the per-stream slice of a context:
+// the extracted-sample workspace between blind rotation and keyswitch, the persistent-wave work counter,
+// the certificate slots, the convolution scratch and the timing events. Calls on DIFFERENT streams of one
+// context therefore never share mutable state (calls on one stream are ordered by the stream itself).
+constexpr unsigned kCertSlots = 1024;   // ring of per-call certificate slots; slot kCertSlots = running max, +1 = recomputed calls
+struct Lane {
+  hipStream_t stream = nullptr;
+  int32_t* d_u0 = nullptr;
+  int32_t* d_u1 = nullptr;
+  size_t ws_batch = 0;
+  unsigned int* d_counter = nullptr;      // work counter of the persistent blind-rotate launches
+  unsigned long long* d_cert = nullptr;   // [kCertSlots + 2]
+  unsigned slot_next = 0;
+  uint32_t* d_conv_scratch = nullptr;     // expanded weights of the tiled convolution (grown on demand)
   size_t conv_scratch_words = 0;
-  int64_t fft_fallbacks = 0;   // host calls recomputed in exact mode after a rounding distance >= RS_CERTIFICATE_LIMIT
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  bool ev_valid = false;
+  rs::LaunchInfo last;
+};
+
+struct rs_ctx {
   rs_params p{};
   int device = 0;
   int cfg = 0;  // 0 default128-shaped gadget, 1 redsec_v2-shaped gadget
   rs::Tables tables;
   int mode = 1;  // RS_MODE_FFT by default; RS_MODE_EXACT_NTT = 0
+  double cert_limit = RS_CERTIFICATE_LIMIT;
+  rs::LaunchOpts opts;
   double* d_tw = nullptr;          // exact-NTT tables (kTwTotal doubles)
   double* d_tw_fft = nullptr;      // FFT tables (kFftTwDoubles doubles)
   double* d_bk_ntt = nullptr;      // key in the NTT domain
   double* d_bk_fft = nullptr;      // key in the FFT domain
-  unsigned long long* d_dev_flag = nullptr;  // FFT rounding certificate (max distance to an integer)
   int32_t* d_ksk = nullptr;
   size_t bk_bytes = 0, ksk_bytes = 0;
   bool keys = false;
-  int32_t* d_u0 = nullptr;
-  int32_t* d_u1 = nullptr;
-  unsigned int* d_counter = nullptr;  // work counters of the persistent blind-rotate launches
-  size_t ws_batch = 0;
-  int32_t* d_io[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t io_batch = 0;
   int num_cus = 256;
   bool timing = false;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool ev_valid = false;
+  std::mutex lanes_mu;                              // guards the map (a lane itself belongs to its stream's caller)
+  std::map<hipStream_t, std::unique_ptr<Lane>> lanes;
+  std::mutex host_mu;                               // serialises the synchronous host-pointer calls (shared staging buffers)
+  int32_t* d_io[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t io_batch = 0;
 };
 
 namespace {
@@ -97,15 +115,41 @@ int use_device(rs_ctx* c) {
   return RS_OK;
 }
 
-int ensure_ws(rs_ctx* c, size_t B) {
-  if (B <= c->ws_batch) return RS_OK;
-  if (c->d_u0) { (void)hipFree(c->d_u0); c->d_u0 = nullptr; }
-  if (c->d_u1) { (void)hipFree(c->d_u1); c->d_u1 = nullptr; }
-  c->ws_batch = 0;
+void free_lane(Lane* ln) {
+  (void)hipFree(ln->d_u0); (void)hipFree(ln->d_u1); (void)hipFree(ln->d_counter); (void)hipFree(ln->d_cert);
+  (void)hipFree(ln->d_conv_scratch);
+  for (auto& e : ln->ev) if (e) (void)hipEventDestroy(e);
+}
+
+// the calling stream's lane, created on first use
+int lane_of(rs_ctx* c, hipStream_t st, Lane** out) {
+  std::lock_guard<std::mutex> g(c->lanes_mu);
+  auto it = c->lanes.find(st);
+  if (it != c->lanes.end()) { *out = it->second.get(); return RS_OK; }
+  std::unique_ptr<Lane> ln(new Lane);
+  ln->stream = st;
+  const size_t cert_bytes = sizeof(unsigned long long) * (kCertSlots + 2);
+  if (hipMalloc(&ln->d_cert, cert_bytes) != hipSuccess || hipMemset(ln->d_cert, 0, cert_bytes) != hipSuccess ||
+      (!c->opts.no_persist && hipMalloc(&ln->d_counter, 256) != hipSuccess)) {
+    free_lane(ln.get());
+    return fail(RS_ERR_HIP, "per-stream state allocation failed");
+  }
+  for (auto& e : ln->ev) (void)hipEventCreate(&e);
+  *out = ln.get();
+  c->lanes[st] = std::move(ln);
+  return RS_OK;
+}
+
+int ensure_ws(Lane* ln, size_t B) {
+  if (B <= ln->ws_batch) return RS_OK;
+  // hipFree waits for the device: no launch can still be using the old workspace
+  if (ln->d_u0) { (void)hipFree(ln->d_u0); ln->d_u0 = nullptr; }
+  if (ln->d_u1) { (void)hipFree(ln->d_u1); ln->d_u1 = nullptr; }
+  ln->ws_batch = 0;
   const size_t bytes = B * (size_t)(rs::kN + 1) * sizeof(int32_t);
-  RS_HIP(hipMalloc(&c->d_u0, bytes));
-  RS_HIP(hipMalloc(&c->d_u1, bytes));
-  c->ws_batch = B;
+  RS_HIP(hipMalloc(&ln->d_u0, bytes));
+  RS_HIP(hipMalloc(&ln->d_u1, bytes));
+  ln->ws_batch = B;
   return RS_OK;
 }
 
@@ -134,46 +178,89 @@ int ready(rs_ctx* c) {
   return RS_OK;
 }
 
-rs::BlindRotateArgs br_args(rs_ctx* c, const int32_t* in0, const int32_t* in1, int32_t c0, int32_t c1, int32_t bconst, int32_t mu,
-                            size_t B, int32_t* u) {
+struct Combo { const int32_t* in0; const int32_t* in1; int32_t c0, c1, bconst; int32_t* u; };
+
+rs::BlindRotateArgs br_args(rs_ctx* c, Lane* ln, int mode, const Combo& x, int32_t mu, const int32_t* lut, size_t lut_count, size_t B) {
   rs::BlindRotateArgs a;
-  a.in0 = in0; a.in1 = in1; a.c0 = c0; a.c1 = c1; a.bconst = bconst; a.mu = mu;
-  a.bk_x = c->mode == 1 ? c->d_bk_fft : c->d_bk_ntt;
-  a.tw = c->mode == 1 ? c->d_tw_fft : c->d_tw;
+  a.in0 = x.in0; a.in1 = x.in1; a.c0 = x.c0; a.c1 = x.c1; a.bconst = x.bconst; a.mu = mu;
+  a.bk_x = mode == 1 ? c->d_bk_fft : c->d_bk_ntt;
+  a.tw = mode == 1 ? c->d_tw_fft : c->d_tw;
   a.f = c->tables.f;
-  a.n = c->p.n; a.W = c->p.n + 1; a.B = (long)B; a.u_out = u;
-  a.counter = c->d_counter;
-  a.dev_flag = c->mode == 1 ? c->d_dev_flag : nullptr;
+  a.n = c->p.n; a.W = c->p.n + 1; a.B = (long)B; a.u_out = x.u;
+  a.counter = ln->d_counter;
+  a.dev_flag = nullptr;
+  a.lut = lut; a.lut_count = (int32_t)lut_count;
   return a;
 }
 
-rs::KeyswitchArgs ks_args(rs_ctx* c, const int32_t* u0, const int32_t* u1, int32_t bconst, size_t B, int32_t* out) {
-  rs::KeyswitchArgs a;
-  a.u0 = u0; a.u1 = u1; a.bconst = bconst; a.ksk = c->d_ksk;
-  a.W = c->p.n + 1; a.t = c->p.ks_t; a.basebit = c->p.ks_basebit; a.B = (long)B; a.out = out;
-  return a;
-}
-
-// blind rotate(s) then keyswitch, with optional event timing on the launch stream
-int run_bootstrap(rs_ctx* c, int32_t* out, const int32_t* in0, const int32_t* in1, int32_t c0, int32_t c1, int32_t bconst,
-                  int32_t mu, size_t B, hipStream_t st) {
-  int rc = ensure_ws(c, B);
+// The one path every bootstrapped entry point takes: `count` blind rotations (1, or 2 for bootsMUX) then the
+// keyswitch of their (summed) extracted samples.
+//   exact mode: the NTT kernels.
+//   FFT mode:   the FFT kernels write the call's largest rounding distance into a fresh certificate slot, then
+//               the SAME rotations are enqueued as exact-NTT launches gated on that slot: they return at once
+//               unless the distance reached the limit, in which case they overwrite the extracted samples with
+//               the guaranteed-exact result before the keyswitch reads them. No host round trip, stream-ordered,
+//               so every *_dev result is exact (= RS_MODE_EXACT_NTT = the CPU oracle) by construction.
+int run_bootstrap(rs_ctx* c, hipStream_t st, int32_t* out, const Combo* combos, int count, int32_t ks_bconst, int32_t mu,
+                  const int32_t* lut, size_t lut_count, size_t B) {
+  Lane* ln = nullptr;
+  int rc = lane_of(c, st, &ln);
+  if (rc) return rc;
+  rc = ensure_ws(ln, B);
   if (rc) return rc;
   const int wpb = pick_wpb(c, B);
-  if (c->timing) RS_HIP(hipEventRecord(c->ev[0], st));
-  RS_HIP(rs::launch_blind_rotate(c->cfg, c->mode, br_args(c, in0, in1, c0, c1, bconst, mu, B, c->d_u0), wpb, c->num_cus, st));
-  if (c->timing) RS_HIP(hipEventRecord(c->ev[1], st));
-  RS_HIP(rs::launch_keyswitch(ks_args(c, c->d_u0, nullptr, 0, B, out), st));
-  if (c->timing) { RS_HIP(hipEventRecord(c->ev[2], st)); c->ev_valid = true; }
+  const int mode = c->mode;
+  Combo cs[2];
+  for (int k = 0; k < count; ++k) { cs[k] = combos[k]; cs[k].u = k == 0 ? ln->d_u0 : ln->d_u1; }
+  if (c->timing) RS_HIP(hipEventRecord(ln->ev[0], st));
+  if (mode == RS_MODE_FFT) {
+    unsigned long long* slot = ln->d_cert + (ln->slot_next++ % kCertSlots);
+    RS_HIP(hipMemsetAsync(slot, 0, sizeof *slot, st));
+    for (int k = 0; k < count; ++k) {
+      rs::BlindRotateArgs a = br_args(c, ln, 1, cs[k], mu, lut, lut_count, B);
+      a.dev_flag = slot;
+      RS_HIP(rs::launch_blind_rotate(c->cfg, 1, a, wpb, c->num_cus, c->opts, st, &ln->last));
+    }
+    unsigned long long limit_bits;
+    const double lim = c->cert_limit;
+    memcpy(&limit_bits, &lim, sizeof limit_bits);
+    for (int k = 0; k < count; ++k) {
+      rs::BlindRotateArgs a = br_args(c, ln, 0, cs[k], mu, lut, lut_count, B);
+      a.gate_flag = slot; a.gate_limit_bits = limit_bits;
+      a.running_flag = k == 0 ? ln->d_cert + kCertSlots : nullptr;
+      a.fallback_count = k == 0 ? ln->d_cert + kCertSlots + 1 : nullptr;
+      RS_HIP(rs::launch_blind_rotate(c->cfg, 0, a, wpb, c->num_cus, c->opts, st, nullptr));
+    }
+  } else {
+    for (int k = 0; k < count; ++k)
+      RS_HIP(rs::launch_blind_rotate(c->cfg, 0, br_args(c, ln, 0, cs[k], mu, lut, lut_count, B), wpb, c->num_cus, c->opts, st, &ln->last));
+  }
+  if (c->timing) RS_HIP(hipEventRecord(ln->ev[1], st));
+  if (out) {
+    rs::KeyswitchArgs k;
+    k.u0 = ln->d_u0; k.u1 = count == 2 ? ln->d_u1 : nullptr; k.bconst = ks_bconst; k.ksk = c->d_ksk;
+    k.W = c->p.n + 1; k.t = c->p.ks_t; k.basebit = c->p.ks_basebit; k.B = (long)B; k.out = out;
+    RS_HIP(rs::launch_keyswitch(k, st));
+  }
+  if (c->timing) { RS_HIP(hipEventRecord(ln->ev[2], st)); ln->ev_valid = true; }
   return RS_OK;
 }
+
+void destroy_ctx(rs_ctx* c) {
+  (void)hipFree(c->d_tw); (void)hipFree(c->d_tw_fft); (void)hipFree(c->d_bk_ntt); (void)hipFree(c->d_bk_fft); (void)hipFree(c->d_ksk);
+  for (auto& kv : c->lanes) free_lane(kv.second.get());
+  for (auto& p : c->d_io) (void)hipFree(p);
+  delete c;
+}
+
+bool env_on(const char* name) { const char* v = getenv(name); return v && *v && strcmp(v, "0") != 0; }
 
 }  // namespace
 
 extern "C" {
 
 const char* rs_last_error(void) { return g_err.c_str(); }
-const char* rs_version(void) { return "redsec_hip 0.2 (gfx950; fp64 fft + exact fp64-carried ntt)"; }
+const char* rs_version(void) { return "redsec_hip 0.3 (gfx950; fp64 fft with on-device exact recomputation + exact fp64-carried ntt)"; }
 
 int rs_params_default128(rs_params* p) {
   if (!p) return fail(RS_ERR_INVALID, "null params");
@@ -209,13 +296,13 @@ int rs_create(rs_ctx** out, const rs_params* p, int device) {
   const bool mid = c->cfg == 0 ? rs::CfgDefault128::MID_REDUCE : rs::CfgRedsecV2::MID_REDUCE;
   c->tables = rs::make_tables(ps, fuse);
   const std::string why = rs::validate_schedule(c->tables.f.p, p->bk_l, p->bk_Bgbit, fwd_mask, inv_mask, fuse, mid);
-  if (!why.empty()) { delete c; return fail(RS_ERR_INVALID, "transform schedule not exact: %s", why.c_str()); }
-  if (hipSetDevice(device) != hipSuccess) { delete c; return fail(RS_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device); }
+  if (!why.empty()) { destroy_ctx(c); return fail(RS_ERR_INVALID, "transform schedule not exact: %s", why.c_str()); }
+  if (hipSetDevice(device) != hipSuccess) { destroy_ctx(c); return fail(RS_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device); }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
     c->num_cus = prop.multiProcessorCount;
     if (!strstr(prop.gcnArchName, "gfx950")) {
-      delete c;
+      destroy_ctx(c);
       return fail(RS_ERR_NO_DEVICE, "device %d is %s; this library ships gfx950 code only", device, prop.gcnArchName);
     }
   }
@@ -223,15 +310,16 @@ int rs_create(rs_ctx** out, const rs_params* p, int device) {
   if (hipMalloc(&c->d_tw, sizeof(double) * rs::kTwTotal) != hipSuccess ||
       hipMemcpy(c->d_tw, c->tables.tw.data(), sizeof(double) * rs::kTwTotal, hipMemcpyHostToDevice) != hipSuccess ||
       hipMalloc(&c->d_tw_fft, sizeof(double) * rs::kFftTwDoubles) != hipSuccess ||
-      hipMemcpy(c->d_tw_fft, fft_tw.data(), sizeof(double) * rs::kFftTwDoubles, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMalloc(&c->d_dev_flag, 64) != hipSuccess || hipMemset(c->d_dev_flag, 0, 64) != hipSuccess) {
-    delete c;
+      hipMemcpy(c->d_tw_fft, fft_tw.data(), sizeof(double) * rs::kFftTwDoubles, hipMemcpyHostToDevice) != hipSuccess) {
+    destroy_ctx(c);   // releases whatever was allocated
     return fail(RS_ERR_HIP, "twiddle table upload failed");
   }
+  // the environment is read here, once: launches never call getenv
   if (const char* m = getenv("REDSEC_MODE")) c->mode = (strcmp(m, "exact") == 0 || strcmp(m, "ntt") == 0) ? 0 : 1;
-  for (auto& e : c->ev) (void)hipEventCreate(&e);
-  if (hipMalloc(&c->d_counter, 256) != hipSuccess) { delete c; return fail(RS_ERR_HIP, "counter allocation failed"); }
-  if (getenv("RS_NO_PERSIST")) { (void)hipFree(c->d_counter); c->d_counter = nullptr; }
+  c->opts.no_coop = env_on("RS_NO_COOP"); c->opts.no_wg = env_on("RS_NO_WG"); c->opts.no_duo = env_on("RS_NO_DUO");
+  c->opts.no_persist = env_on("RS_NO_PERSIST"); c->opts.no_conv_tiled = env_on("RS_NO_CONV_TILED");
+  Lane* ln = nullptr;
+  if (lane_of(c, nullptr, &ln) != RS_OK) { destroy_ctx(c); return RS_ERR_HIP; }   // the default stream's lane
   *out = c;
   return RS_OK;
 }
@@ -240,12 +328,7 @@ int rs_destroy(rs_ctx* c) {
   if (!c) return RS_OK;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  (void)hipFree(c->d_tw); (void)hipFree(c->d_tw_fft); (void)hipFree(c->d_bk_ntt); (void)hipFree(c->d_bk_fft); (void)hipFree(c->d_ksk);
-  (void)hipFree(c->d_dev_flag); (void)hipFree(c->d_conv_scratch);
-  (void)hipFree(c->d_u0); (void)hipFree(c->d_u1); (void)hipFree(c->d_counter);
-  for (auto& p : c->d_io) (void)hipFree(p);
-  for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
-  delete c;
+  destroy_ctx(c);
   return RS_OK;
 }
 
@@ -264,8 +347,8 @@ int rs_load_keys(rs_ctx* c, const int32_t* bk, const int32_t* ksk) {
   int32_t* d_bk = nullptr;
   RS_HIP(hipMalloc(&d_bk, bk_words * sizeof(int32_t)));
   RS_HIP(hipMemcpy(d_bk, bk, bk_words * sizeof(int32_t), hipMemcpyHostToDevice));
-  // both transform domains are kept resident (62 + 62 MB default-128, 115 + 115 MB REDsec) so that the
-  // mode can be switched per call
+  // both transform domains are kept resident (62 + 62 MB default-128, 115 + 115 MB REDsec): the FFT mode's
+  // gated exact recomputation needs the NTT-domain key, and the mode can be switched per call
   RS_HIP(hipMalloc(&c->d_bk_ntt, bk_words * sizeof(double)));
   RS_HIP(hipMalloc(&c->d_bk_fft, bk_words * sizeof(double)));
   RS_HIP(rs::launch_bk_transform(c->cfg, 0, d_bk, c->d_bk_ntt, c->d_tw, c->tables.f, c->tables.ninv, (long)n_polys, nullptr));
@@ -280,10 +363,15 @@ int rs_load_keys(rs_ctx* c, const int32_t* bk, const int32_t* ksk) {
   return RS_OK;
 }
 
-int rs_reserve(rs_ctx* c, size_t max_batch) {
+int rs_reserve(rs_ctx* c, size_t max_batch) { return rs_reserve_stream(c, max_batch, nullptr); }
+
+int rs_reserve_stream(rs_ctx* c, size_t max_batch, void* stream) {
   int rc = use_device(c);
   if (rc) return rc;
-  return ensure_ws(c, max_batch);
+  Lane* ln = nullptr;
+  rc = lane_of(c, (hipStream_t)stream, &ln);
+  if (rc) return rc;
+  return ensure_ws(ln, max_batch);
 }
 
 int rs_bootstrap_dev(rs_ctx* c, int32_t* out, const int32_t* in, int32_t mu, size_t B, void* stream) {
@@ -291,17 +379,18 @@ int rs_bootstrap_dev(rs_ctx* c, int32_t* out, const int32_t* in, int32_t mu, siz
   if (rc) return rc;
   if (B == 0) return RS_OK;
   if (!out || !in) return fail(RS_ERR_INVALID, "null ciphertext pointer");
-  return run_bootstrap(c, out, in, nullptr, 1, 0, 0, mu, B, (hipStream_t)stream);
+  const Combo x{in, nullptr, 1, 0, 0, nullptr};
+  return run_bootstrap(c, (hipStream_t)stream, out, &x, 1, 0, mu, nullptr, 0, B);
 }
 
-int rs_gate_dev(rs_ctx* c, rs_gate_op op, int32_t* out, const int32_t* a, const int32_t* b, size_t B, void* stream) {
+int rs_bootstrap_lut_dev(rs_ctx* c, int32_t* out, const int32_t* in, const int32_t* lut, size_t lut_count, size_t B, void* stream) {
   int rc = ready(c);
   if (rc) return rc;
-  GateCoef g;
-  if (!gate_coef(op, &g)) return fail(RS_ERR_INVALID, "unknown gate %d", (int)op);
   if (B == 0) return RS_OK;
-  if (!out || !a || !b) return fail(RS_ERR_INVALID, "null ciphertext pointer");
-  return run_bootstrap(c, out, a, b, g.sa, g.sb, g.bconst, 1 << 29, B, (hipStream_t)stream);
+  if (!out || !in || !lut) return fail(RS_ERR_INVALID, "null pointer");
+  if (lut_count < 1 || lut_count > 0x7fffffffu) return fail(RS_ERR_INVALID, "lut_count must be >= 1");
+  const Combo x{in, nullptr, 1, 0, 0, nullptr};
+  return run_bootstrap(c, (hipStream_t)stream, out, &x, 1, 0, 0, lut, lut_count, B);
 }
 
 int rs_gate_mu_dev(rs_ctx* c, rs_gate_op op, int32_t* out, const int32_t* a, const int32_t* b, int32_t mu, size_t B, void* stream) {
@@ -311,7 +400,12 @@ int rs_gate_mu_dev(rs_ctx* c, rs_gate_op op, int32_t* out, const int32_t* a, con
   if (!gate_coef(op, &g)) return fail(RS_ERR_INVALID, "unknown gate %d", (int)op);
   if (B == 0) return RS_OK;
   if (!out || !a || !b) return fail(RS_ERR_INVALID, "null ciphertext pointer");
-  return run_bootstrap(c, out, a, b, g.sa, g.sb, g.bconst, mu, B, (hipStream_t)stream);
+  const Combo x{a, b, g.sa, g.sb, g.bconst, nullptr};
+  return run_bootstrap(c, (hipStream_t)stream, out, &x, 1, 0, mu, nullptr, 0, B);
+}
+
+int rs_gate_dev(rs_ctx* c, rs_gate_op op, int32_t* out, const int32_t* a, const int32_t* b, size_t B, void* stream) {
+  return rs_gate_mu_dev(c, op, out, a, b, 1 << 29, B, stream);
 }
 
 int rs_gather_rows_dev(rs_ctx* c, int32_t* out, const int32_t* in, const int32_t* row_index, size_t B, void* stream) {
@@ -328,19 +422,10 @@ int rs_mux_dev(rs_ctx* c, int32_t* out, const int32_t* a, const int32_t* b, cons
   if (rc) return rc;
   if (B == 0) return RS_OK;
   if (!out || !a || !b || !cc) return fail(RS_ERR_INVALID, "null ciphertext pointer");
-  rc = ensure_ws(c, B);
-  if (rc) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  const int wpb = pick_wpb(c, B);
   const int32_t e8 = 1 << 29;
-  if (c->timing) RS_HIP(hipEventRecord(c->ev[0], st));
   // u1 = woKS(AND(a,b)), u2 = woKS(ANDNY(a,c)); out = KS((0,1/8) + u1 + u2)
-  RS_HIP(rs::launch_blind_rotate(c->cfg, c->mode, br_args(c, a, b, 1, 1, -e8, e8, B, c->d_u0), wpb, c->num_cus, st));
-  RS_HIP(rs::launch_blind_rotate(c->cfg, c->mode, br_args(c, a, cc, -1, 1, -e8, e8, B, c->d_u1), wpb, c->num_cus, st));
-  if (c->timing) RS_HIP(hipEventRecord(c->ev[1], st));
-  RS_HIP(rs::launch_keyswitch(ks_args(c, c->d_u0, c->d_u1, e8, B, out), st));
-  if (c->timing) { RS_HIP(hipEventRecord(c->ev[2], st)); c->ev_valid = true; }
-  return RS_OK;
+  const Combo xs[2] = {{a, b, 1, 1, -e8, nullptr}, {a, cc, -1, 1, -e8, nullptr}};
+  return run_bootstrap(c, (hipStream_t)stream, out, xs, 2, e8, e8, nullptr, 0, B);
 }
 
 int rs_bootstrap_wo_ks_dev(rs_ctx* c, int32_t* u, const int32_t* in, int32_t mu, size_t B, void* stream) {
@@ -348,7 +433,15 @@ int rs_bootstrap_wo_ks_dev(rs_ctx* c, int32_t* u, const int32_t* in, int32_t mu,
   if (rc) return rc;
   if (B == 0) return RS_OK;
   if (!u || !in) return fail(RS_ERR_INVALID, "null ciphertext pointer");
-  RS_HIP(rs::launch_blind_rotate(c->cfg, c->mode, br_args(c, in, nullptr, 1, 0, 0, mu, B, u), pick_wpb(c, B), c->num_cus, (hipStream_t)stream));
+  // rotate into the lane workspace (so that the gated exact recomputation applies), then hand the samples over
+  const Combo x{in, nullptr, 1, 0, 0, nullptr};
+  hipStream_t st = (hipStream_t)stream;
+  rc = run_bootstrap(c, st, nullptr, &x, 1, 0, mu, nullptr, 0, B);
+  if (rc) return rc;
+  Lane* ln = nullptr;
+  rc = lane_of(c, st, &ln);
+  if (rc) return rc;
+  RS_HIP(hipMemcpyAsync(u, ln->d_u0, B * (size_t)(rs::kN + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   return RS_OK;
 }
 
@@ -357,16 +450,21 @@ int rs_keyswitch_dev(rs_ctx* c, int32_t* out, const int32_t* u, size_t B, void* 
   if (rc) return rc;
   if (B == 0) return RS_OK;
   if (!out || !u) return fail(RS_ERR_INVALID, "null ciphertext pointer");
-  RS_HIP(rs::launch_keyswitch(ks_args(c, u, nullptr, 0, B, out), (hipStream_t)stream));
+  rs::KeyswitchArgs k;
+  k.u0 = u; k.u1 = nullptr; k.bconst = 0; k.ksk = c->d_ksk;
+  k.W = c->p.n + 1; k.t = c->p.ks_t; k.basebit = c->p.ks_basebit; k.B = (long)B; k.out = out;
+  RS_HIP(rs::launch_keyswitch(k, (hipStream_t)stream));
   return RS_OK;
 }
 
-// ---- host-pointer conveniences ----
+// ---- host-pointer conveniences: H2D, the *_dev call on the default stream, D2H. Serialised per context
+// (the per-ciphertext TFHE-style wrappers above this ABI are called from OpenMP regions). ----
 static int host_roundtrip(rs_ctx* c, int32_t* out, const int32_t* const* ins, int n_in, size_t B,
                           int (*run)(rs_ctx*, int32_t*, int32_t* const*, size_t, void*), void* extra) {
   int rc = ready(c);
   if (rc) return rc;
   if (B == 0) return RS_OK;
+  std::lock_guard<std::mutex> g(c->host_mu);
   rc = ensure_io(c, B);
   if (rc) return rc;
   const size_t bytes = B * (size_t)(c->p.n + 1) * sizeof(int32_t);
@@ -374,31 +472,9 @@ static int host_roundtrip(rs_ctx* c, int32_t* out, const int32_t* const* ins, in
     if (!ins[i]) return fail(RS_ERR_INVALID, "null ciphertext pointer");
     RS_HIP(hipMemcpy(c->d_io[i], ins[i], bytes, hipMemcpyHostToDevice));
   }
-  // FFT mode: certify THIS call (the device flag is a running maximum: set it aside, restore the maximum after)
-  const bool certify = c->mode == RS_MODE_FFT && c->d_dev_flag;
-  unsigned long long before = 0, call = 0;
-  if (certify) {
-    RS_HIP(hipMemcpy(&before, c->d_dev_flag, sizeof before, hipMemcpyDeviceToHost));
-    RS_HIP(hipMemset(c->d_dev_flag, 0, sizeof before));
-  }
   rc = run(c, c->d_io[3], c->d_io, B, extra);
   if (rc) return rc;
-  RS_HIP(hipDeviceSynchronize());
-  if (certify) {
-    RS_HIP(hipMemcpy(&call, c->d_dev_flag, sizeof call, hipMemcpyDeviceToHost));
-    const unsigned long long keep = call > before ? call : before;   // positive doubles order like their bit patterns
-    RS_HIP(hipMemcpy(c->d_dev_flag, &keep, sizeof keep, hipMemcpyHostToDevice));
-    double dist;
-    memcpy(&dist, &call, sizeof dist);
-    if (!(dist < RS_CERTIFICATE_LIMIT)) {   // never observed; recompute exactly rather than return an uncertified result
-      ++c->fft_fallbacks;
-      c->mode = RS_MODE_EXACT_NTT;
-      rc = run(c, c->d_io[3], c->d_io, B, extra);
-      c->mode = RS_MODE_FFT;
-      if (rc) return rc;
-      RS_HIP(hipDeviceSynchronize());
-    }
-  }
+  RS_HIP(hipStreamSynchronize(nullptr));
   RS_HIP(hipMemcpy(out, c->d_io[3], bytes, hipMemcpyDeviceToHost));
   return RS_OK;
 }
@@ -435,6 +511,9 @@ int rs_debug_polymul(rs_ctx* c, int32_t* out, const int32_t* a_small, const int3
   if (rc) return rc;
   if (count == 0) return RS_OK;
   if (!out || !a_small || !b_torus) return fail(RS_ERR_INVALID, "null pointer");
+  Lane* ln = nullptr;
+  rc = lane_of(c, nullptr, &ln);
+  if (rc) return rc;
   const size_t bytes = count * rs::kN * sizeof(int32_t);
   int32_t *da = nullptr, *db = nullptr, *dout = nullptr;
   double* scratch = nullptr;
@@ -443,7 +522,7 @@ int rs_debug_polymul(rs_ctx* c, int32_t* out, const int32_t* a_small, const int3
   RS_HIP(hipMemcpy(da, a_small, bytes, hipMemcpyHostToDevice));
   RS_HIP(hipMemcpy(db, b_torus, bytes, hipMemcpyHostToDevice));
   RS_HIP(rs::launch_polymul(c->cfg, c->mode, da, db, dout, scratch, c->mode == 1 ? c->d_tw_fft : c->d_tw, c->tables.f, c->tables.ninv,
-                            (long)count, c->mode == 1 ? c->d_dev_flag : nullptr, nullptr));
+                            (long)count, c->mode == 1 ? ln->d_cert + kCertSlots : nullptr, nullptr));
   RS_HIP(hipDeviceSynchronize());
   RS_HIP(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
   (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout); (void)hipFree(scratch);
@@ -463,21 +542,72 @@ int rs_get_mode(rs_ctx* c, int* mode) {
   return RS_OK;
 }
 
+int rs_set_certificate_limit(rs_ctx* c, double limit) {
+  if (!c) return fail(RS_ERR_INVALID, "null context");
+  if (!(limit >= 0.0 && limit <= 0.5)) return fail(RS_ERR_INVALID, "certificate limit must lie in [0, 0.5]");
+  c->cert_limit = limit;
+  return RS_OK;
+}
+
+// running maximum / recomputed-call count of one lane (device must be idle on that lane)
+static int read_lane(Lane* ln, double* dist, int64_t* fallbacks, bool reset) {
+  unsigned long long v[2] = {0, 0};
+  RS_HIP(hipMemcpy(v, ln->d_cert + kCertSlots, sizeof v, hipMemcpyDeviceToHost));
+  memcpy(dist, &v[0], sizeof *dist);
+  *fallbacks = (int64_t)v[1];
+  if (reset) RS_HIP(hipMemset(ln->d_cert + kCertSlots, 0, sizeof(unsigned long long)));
+  return RS_OK;
+}
+
+int rs_certify(rs_ctx* c, void* stream, double* max_distance, int64_t* recomputed_calls, int reset) {
+  int rc = use_device(c);
+  if (rc) return rc;
+  Lane* ln = nullptr;
+  rc = lane_of(c, (hipStream_t)stream, &ln);
+  if (rc) return rc;
+  RS_HIP(hipStreamSynchronize((hipStream_t)stream));
+  double d = 0.0;
+  int64_t n = 0;
+  rc = read_lane(ln, &d, &n, reset != 0);
+  if (rc) return rc;
+  if (max_distance) *max_distance = d;
+  if (recomputed_calls) *recomputed_calls = n;
+  return RS_OK;
+}
+
 int rs_rounding_certificate(rs_ctx* c, double* max_distance, int reset) {
   int rc = use_device(c);
   if (rc) return rc;
   if (!max_distance) return fail(RS_ERR_INVALID, "null pointer");
   RS_HIP(hipDeviceSynchronize());
-  unsigned long long bits = 0;
-  RS_HIP(hipMemcpy(&bits, c->d_dev_flag, sizeof bits, hipMemcpyDeviceToHost));
-  memcpy(max_distance, &bits, sizeof bits);
-  if (reset) RS_HIP(hipMemset(c->d_dev_flag, 0, sizeof bits));
+  std::lock_guard<std::mutex> g(c->lanes_mu);
+  double best = 0.0;
+  for (auto& kv : c->lanes) {
+    double d = 0.0;
+    int64_t n = 0;
+    rc = read_lane(kv.second.get(), &d, &n, reset != 0);
+    if (rc) return rc;
+    if (d > best) best = d;
+  }
+  *max_distance = best;
   return RS_OK;
 }
 
 int rs_fft_fallbacks(rs_ctx* c, int64_t* count) {
-  if (!c || !count) return fail(RS_ERR_INVALID, "null argument");
-  *count = c->fft_fallbacks;
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (!count) return fail(RS_ERR_INVALID, "null argument");
+  RS_HIP(hipDeviceSynchronize());
+  std::lock_guard<std::mutex> g(c->lanes_mu);
+  int64_t total = 0;
+  for (auto& kv : c->lanes) {
+    double d = 0.0;
+    int64_t n = 0;
+    rc = read_lane(kv.second.get(), &d, &n, false);
+    if (rc) return rc;
+    total += n;
+  }
+  *count = total;
   return RS_OK;
 }
 
@@ -513,18 +643,21 @@ int rs_conv_ternary_dev(rs_ctx* c, int32_t* out, const int32_t* in, const uint8_
     return fail(RS_ERR_INVALID, "bad convolution shape");
   if (bias_b && bias_depth < 1) return fail(RS_ERR_INVALID, "bias_depth must be >= 1");
   rs::ConvShape cs{s->H, s->Wd, s->Cin, s->Cout, s->fh, s->fw, s->stride_h, s->stride_w, s->off_h, s->off_w, s->Ho, s->Wo};
-  if (zero_tap_b == 0 && pad_tap_b == 0 && !getenv("RS_NO_CONV_TILED")) {
+  if (zero_tap_b == 0 && pad_tap_b == 0 && !c->opts.no_conv_tiled) {
     // BinFunc-style convolution (ternary-zero and padding taps contribute nothing): register-tiled kernel.
-    // The expanded weights live in a context-owned scratch buffer, rebuilt on every call (microseconds).
+    // The expanded weights live in the stream's own scratch buffer, rebuilt on every call (microseconds).
+    Lane* ln = nullptr;
+    rc = lane_of(c, (hipStream_t)stream, &ln);
+    if (rc) return rc;
     const size_t words = rs::conv_tiled_scratch_words(cs);
-    if (words > c->conv_scratch_words) {
+    if (words > ln->conv_scratch_words) {
       RS_HIP(hipStreamSynchronize((hipStream_t)stream));   // a previous call may still be reading the old buffer
-      if (c->d_conv_scratch) RS_HIP(hipFree(c->d_conv_scratch));
-      c->d_conv_scratch = nullptr; c->conv_scratch_words = 0;
-      RS_HIP(hipMalloc(&c->d_conv_scratch, words * sizeof(uint32_t)));
-      c->conv_scratch_words = words;
+      if (ln->d_conv_scratch) RS_HIP(hipFree(ln->d_conv_scratch));
+      ln->d_conv_scratch = nullptr; ln->conv_scratch_words = 0;
+      RS_HIP(hipMalloc(&ln->d_conv_scratch, words * sizeof(uint32_t)));
+      ln->conv_scratch_words = words;
     }
-    RS_HIP(rs::launch_conv_ternary_tiled(out, in, sign, zero, cs, c->p.n + 1, bias_b, bias_depth, c->d_conv_scratch, (hipStream_t)stream));
+    RS_HIP(rs::launch_conv_ternary_tiled(out, in, sign, zero, cs, c->p.n + 1, bias_b, bias_depth, ln->d_conv_scratch, (hipStream_t)stream));
     return RS_OK;
   }
   RS_HIP(rs::launch_conv_ternary(out, in, sign, zero, cs, c->p.n + 1, zero_tap_b, pad_tap_b, bias_b, bias_depth, (hipStream_t)stream));
@@ -580,20 +713,37 @@ int rs_sync(rs_ctx* c) {
 int rs_set_timing(rs_ctx* c, int enable) {
   if (!c) return fail(RS_ERR_INVALID, "null context");
   c->timing = enable != 0;
-  c->ev_valid = false;
+  std::lock_guard<std::mutex> g(c->lanes_mu);
+  for (auto& kv : c->lanes) kv.second->ev_valid = false;
   return RS_OK;
 }
 
-int rs_last_kernel_ms(rs_ctx* c, float* br_ms, float* ks_ms) {
+int rs_last_kernel_ms_stream(rs_ctx* c, void* stream, float* br_ms, float* ks_ms) {
   int rc = use_device(c);
   if (rc) return rc;
-  if (!c->ev_valid) return fail(RS_ERR_STATE, "no timed launch recorded");
-  RS_HIP(hipEventSynchronize(c->ev[2]));
+  Lane* ln = nullptr;
+  rc = lane_of(c, (hipStream_t)stream, &ln);
+  if (rc) return rc;
+  if (!ln->ev_valid) return fail(RS_ERR_STATE, "no timed launch recorded on this stream");
+  RS_HIP(hipEventSynchronize(ln->ev[2]));
   float a = -1.f, b = -1.f;
-  RS_HIP(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
-  RS_HIP(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
+  RS_HIP(hipEventElapsedTime(&a, ln->ev[0], ln->ev[1]));
+  RS_HIP(hipEventElapsedTime(&b, ln->ev[1], ln->ev[2]));
   if (br_ms) *br_ms = a;
   if (ks_ms) *ks_ms = b;
+  return RS_OK;
+}
+int rs_last_kernel_ms(rs_ctx* c, float* br_ms, float* ks_ms) { return rs_last_kernel_ms_stream(c, nullptr, br_ms, ks_ms); }
+
+int rs_last_launch(rs_ctx* c, void* stream, int32_t* form, int32_t* waves_per_block, int64_t* resident) {
+  if (!c) return fail(RS_ERR_INVALID, "null context");
+  Lane* ln = nullptr;
+  int rc = lane_of(c, (hipStream_t)stream, &ln);
+  if (rc) return rc;
+  if (ln->last.form < 0) return fail(RS_ERR_STATE, "no blind rotation launched on this stream yet");
+  if (form) *form = ln->last.form;
+  if (waves_per_block) *waves_per_block = ln->last.waves_per_block;
+  if (resident) *resident = ln->last.resident;
   return RS_OK;
 }
 
@@ -601,7 +751,10 @@ int rs_info(rs_ctx* c, int64_t* bk_bytes, int64_t* ksk_bytes, int32_t* wpb, int3
   if (!c) return fail(RS_ERR_INVALID, "null context");
   if (bk_bytes) *bk_bytes = (int64_t)c->bk_bytes;
   if (ksk_bytes) *ksk_bytes = (int64_t)c->ksk_bytes;
-  if (wpb) *wpb = 8;
+  if (wpb) {   // of the last blind rotation on the default stream (8 = what a full-chip batch would use, before any launch)
+    Lane* ln = nullptr;
+    *wpb = (lane_of(c, nullptr, &ln) == RS_OK && ln->last.form >= 0) ? ln->last.waves_per_block : 8;
+  }
   if (cus) *cus = c->num_cus;
   return RS_OK;
 }

@@ -235,6 +235,29 @@ __device__ __forceinline__ void publish_certificate(double dev, unsigned long lo
   if (lane == 0) atomicMax(flag, (unsigned long long)__double_as_longlong(dev));
 }
 
+// Initial accumulator body: (test polynomial * X^rot)_j. Constant test vector (tfhe_bootstrap_woKS_FFT) or, in
+// the programmable form, the ciphertext's own polynomial lut[ct % lut_count] (tfhe_blindRotateAndExtract_FFT).
+__device__ __forceinline__ int32_t test_vector(const BlindRotateArgs& a, long ct, int j, int rot) {
+  if (!a.lut) return rotated_const(a.mu, j, rot);
+  const int32_t* v = a.lut + (size_t)(ct % a.lut_count) * kN;
+  const int aa = rot & (kN - 1), nb = (rot >> 10) & 1;
+  const uint32_t x = (uint32_t)v[(j - aa) & (kN - 1)];
+  return (int32_t)((((j < aa) ? 1 : 0) ^ nb) ? 0u - x : x);
+}
+
+// Exact recomputation gate (see BlindRotateArgs::gate_flag). Uniform over the grid: every thread reads the
+// same word, so whole workgroups leave before their first barrier. Returns true when the launch has nothing to do.
+__device__ __forceinline__ bool recompute_not_needed(const BlindRotateArgs& a) {
+  if (!a.gate_flag) return false;
+  const unsigned long long bits = *(const volatile unsigned long long*)a.gate_flag;   // positive doubles order like their bit patterns
+  const bool needed = bits >= a.gate_limit_bits;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (a.running_flag) atomicMax(a.running_flag, bits);
+    if (needed && a.fallback_count) atomicAdd(a.fallback_count, 1ull);
+  }
+  return !needed;
+}
+
 // -------------------------------------------------------------------------------------------------
 // Key transform: one wavefront per key polynomial. Output layout per polynomial: [v 0..7][lane][2]
 // doubles in the exact register order of the consuming wavefront, so the blind rotation reads each
@@ -266,6 +289,7 @@ __global__ __launch_bounds__(64 * WPB) void bk_transform_kernel(const int32_t* _
 template <class Xf, int WPB>
 __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs a) {
   using C = typename Xf::Cfg;
+  if (recompute_not_needed(a)) return;
   __shared__ double s_tw[Xf::kTableDoubles + 1];
   __shared__ double s_buf[WPB][kBufDoubles];
   __shared__ int32_t s_acc[WPB][2][kN];
@@ -308,7 +332,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_kernel(BlindRotateArgs 
       for (int r = 0; r < kRegs; ++r) {
         const int j = lane + 64 * r;
         acc0[j] = 0;
-        acc1[j] = rotated_const(a.mu, j, rot);
+        acc1[j] = test_vector(a, ct, j, rot);
       }
     }
     wave_lds_sync();
@@ -537,7 +561,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
       for (int r = 0; r < kRegs; ++r) {
         const int j = lane + 64 * r;
         acc0[j] = 0;
-        acc1[j] = rotated_const(a.mu, j, rot);
+        acc1[j] = test_vector(a, ct, j, rot);
       }
     }
     // all global reads of this prologue are complete and every wave has left the previous group's
@@ -742,7 +766,7 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
 #pragma unroll
       for (int r = 0; r < kRegs; ++r) {
         const int j = lane + 64 * r;
-        acc[j] = h ? rotated_const(a.mu, j, rot) : 0;
+        acc[j] = h ? test_vector(a, ct, j, rot) : 0;
       }
     }
     __syncthreads();   // bara complete; previous group's last reads of the quad buffer are over
@@ -836,6 +860,7 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
 template <class Xf, int G>
 __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateArgs a) {
   using C = typename Xf::Cfg;
+  if (recompute_not_needed(a)) return;
   constexpr int KPL = 2 * C::L;
   constexpr int R = KPL / G;
   static_assert(KPL % G == 0 && G % 2 == 0, "waves must split the digit rows evenly within a component");
@@ -868,7 +893,7 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateAr
 #pragma unroll
     for (int r = 0; r < kRegs; ++r) {
       const int j = lane + 64 * r;
-      s_acc[wave][j] = wave == 0 ? 0 : rotated_const(a.mu, j, rot);
+      s_acc[wave][j] = wave == 0 ? 0 : test_vector(a, ct, j, rot);
     }
   }
   __syncthreads();
@@ -1012,54 +1037,68 @@ static hipError_t launch_br(const BlindRotateArgs& a, long max_blocks, hipStream
 }
 
 template <class Xf>
-static hipError_t launch_br_xf(const BlindRotateArgs& a, int wpb, long num_cus, bool coop4, hipStream_t st) {
+static hipError_t launch_br_xf(const BlindRotateArgs& a, int wpb, long num_cus, bool coop4, const LaunchOpts& o, hipStream_t st, LaunchInfo* info) {
+  LaunchInfo li;
+  auto done = [&](int form, int w, long resident) {
+    li.form = form; li.waves_per_block = w; li.resident = resident;
+    if (info) *info = li;
+    return hipGetLastError();
+  };
   // latency form: several waves per ciphertext while the batch cannot fill the chip by itself
-  if (!getenv("RS_NO_COOP")) {
+  if (!o.no_coop) {
     if (coop4 && a.B <= num_cus) {
       if constexpr ((2 * Xf::Cfg::L) % 4 == 0) {
         hipLaunchKernelGGL((blind_rotate_coop_kernel<Xf, 4>), dim3((unsigned)a.B), dim3(256), 0, st, a);
-        return hipGetLastError();
+        return done(kFormCoop4, 4, 1);
       }
     }
     if (a.B <= 2L * num_cus) {
       hipLaunchKernelGGL((blind_rotate_coop_kernel<Xf, 2>), dim3((unsigned)a.B), dim3(128), 0, st, a);
-      return hipGetLastError();
+      return done(kFormCoop2, 2, 1);
     }
   }
   if constexpr (Xf::kWorkgroupForm) {
     // throughput form once every CU gets a whole 8-ciphertext group: lock-step workgroups, key rows
     // shared in LDS. (Groups of 2 or 4 waves were measured for 512 < B < 2048 and do not beat the
     // per-wave kernel there: with one wave per SIMD the single-wave CMUX latency dominates.)
-    if (!getenv("RS_NO_WG") && a.B >= 8L * num_cus) {
+    if (!o.no_wg && a.B >= 8L * num_cus) {
       const long groups = (a.B + 7) / 8;
-      hipLaunchKernelGGL((blind_rotate_wg_kernel<Xf, 8>), dim3((unsigned)(groups < num_cus ? groups : num_cus)), dim3(512), 0, st, a);
-      return hipGetLastError();
+      const long grid = groups < num_cus ? groups : num_cus;
+      hipLaunchKernelGGL((blind_rotate_wg_kernel<Xf, 8>), dim3((unsigned)grid), dim3(512), 0, st, a);
+      return done(kFormWorkgroup, 8, 8 * grid);   // the workgroups sweep the key together: 8 x grid ciphertexts per sweep
     }
   }
   if constexpr (Xf::kWorkgroupForm && Xf::Cfg::L % 2 == 0) {
-    // mid-size batches: 4 ciphertexts x 2 waves per workgroup (RS_NO_DUO falls back to one wave per ciphertext)
-    if (!getenv("RS_NO_WG") && !getenv("RS_NO_DUO") && a.B > 2L * num_cus) {
+    // mid-size batches: 4 ciphertexts x 2 waves per workgroup (no_duo falls back to one wave per ciphertext)
+    if (!o.no_wg && !o.no_duo && a.B > 2L * num_cus) {
       const long groups = (a.B + 3) / 4;
-      hipLaunchKernelGGL((blind_rotate_duo_kernel<Xf>), dim3((unsigned)(groups < num_cus ? groups : num_cus)), dim3(512), 0, st, a);
-      return hipGetLastError();
+      const long grid = groups < num_cus ? groups : num_cus;
+      hipLaunchKernelGGL((blind_rotate_duo_kernel<Xf>), dim3((unsigned)grid), dim3(512), 0, st, a);
+      return done(kFormDuo, 8, 4 * grid);
     }
   }
+  hipError_t e;
   switch (wpb) {
-    case 1: return launch_br<Xf, 1>(a, 1L << 40, st);
-    case 2: return launch_br<Xf, 2>(a, 1L << 40, st);
-    case 4: return launch_br<Xf, 4>(a, 1L << 40, st);
-    default: return launch_br<Xf, 8>(a, num_cus, st);   // ~150 KB LDS: exactly one workgroup per CU
+    case 1: e = launch_br<Xf, 1>(a, 1L << 40, st); break;
+    case 2: e = launch_br<Xf, 2>(a, 1L << 40, st); break;
+    case 4: e = launch_br<Xf, 4>(a, 1L << 40, st); break;
+    default: wpb = 8; e = launch_br<Xf, 8>(a, num_cus, st); break;   // ~150 KB LDS: exactly one workgroup per CU
   }
+  const long waves = a.B < (long)wpb * num_cus ? a.B : (long)wpb * num_cus;
+  li.form = kFormPerWave; li.waves_per_block = wpb; li.resident = waves;   // waves drift apart: an upper bound on key sharing
+  if (info) *info = li;
+  return e;
 }
 
-hipError_t launch_blind_rotate(int cfg, int mode, const BlindRotateArgs& a, int wpb, int num_cus, hipStream_t st) {
+hipError_t launch_blind_rotate(int cfg, int mode, const BlindRotateArgs& a, int wpb, int num_cus, const LaunchOpts& opts, hipStream_t st,
+                               LaunchInfo* info) {
   if (a.B <= 0) return hipSuccess;
   if (mode == 0) {
-    return cfg == 0 ? launch_br_xf<XfNtt<CfgDefault128>>(a, wpb, num_cus, false, st)
-                    : launch_br_xf<XfNtt<CfgRedsecV2>>(a, wpb, num_cus, true, st);
+    return cfg == 0 ? launch_br_xf<XfNtt<CfgDefault128>>(a, wpb, num_cus, false, opts, st, info)
+                    : launch_br_xf<XfNtt<CfgRedsecV2>>(a, wpb, num_cus, true, opts, st, info);
   }
-  return cfg == 0 ? launch_br_xf<XfFft<CfgDefault128>>(a, wpb, num_cus, false, st)
-                  : launch_br_xf<XfFft<CfgRedsecV2>>(a, wpb, num_cus, true, st);
+  return cfg == 0 ? launch_br_xf<XfFft<CfgDefault128>>(a, wpb, num_cus, false, opts, st, info)
+                  : launch_br_xf<XfFft<CfgRedsecV2>>(a, wpb, num_cus, true, opts, st, info);
 }
 
 hipError_t launch_bk_transform(int cfg, int mode, const int32_t* bk, double* bk_x, const double* tw, Field f, double scale,

@@ -24,8 +24,28 @@ struct BlindRotateArgs {
   long B;
   int32_t* u_out;       // [B][N+1] extracted samples
   unsigned int* counter;  // persistent-wave work counter (device), or nullptr
-  unsigned long long* dev_flag;  // FFT mode: running max of the rounding distance (double bits), or nullptr
+  unsigned long long* dev_flag;  // FFT mode: this CALL's certificate slot (max rounding distance, double bits), or nullptr
+  // Programmable form (tfhe_blindRotateAndExtract_FFT's test polynomial): ciphertext b starts from
+  // lut[(b % lut_count)][N] instead of the constant mu. nullptr = constant test vector.
+  const int32_t* lut = nullptr;
+  int32_t lut_count = 0;
+  // Conditional exact recomputation (exact-NTT kernels launched behind an FFT call): the grid reads the
+  // FFT call's certificate slot and returns at once unless it reached `gate_limit_bits`; either way it folds
+  // the slot into the stream's running maximum and counts the recomputed calls.
+  const unsigned long long* gate_flag = nullptr;
+  unsigned long long gate_limit_bits = 0;
+  unsigned long long* running_flag = nullptr;
+  unsigned long long* fallback_count = nullptr;
 };
+
+// Launch policy switches, read from the environment ONCE at rs_create (A/B experiments only).
+struct LaunchOpts {
+  bool no_coop = false, no_wg = false, no_duo = false, no_persist = false, no_conv_tiled = false;
+};
+// What a blind-rotate launch actually ran: kernel form and how many ciphertexts share one sweep of the key
+// from L2/HBM (R of SURVEY.md section 8d).
+enum { kFormPerWave = 0, kFormWorkgroup = 1, kFormDuo = 2, kFormCoop2 = 3, kFormCoop4 = 4 };
+struct LaunchInfo { int form = -1; int waves_per_block = 0; long resident = 0; };
 
 struct KeyswitchArgs {
   const int32_t* u0;    // [B][N+1]
@@ -41,7 +61,8 @@ struct ConvShape { int32_t H, Wd, Cin, Cout, fh, fw, stride_h, stride_w, off_h, 
 struct PoolShape { int32_t H, Wd, C, win_h, win_w, stride_h, stride_w, off_h, off_w, Ho, Wo; };
 
 // cfg: 0 = CfgDefault128 (l=3, Bgbit=7), 1 = CfgRedsecV2 (l=10, Bgbit=3); mode: 0 = exact NTT, 1 = FFT
-hipError_t launch_blind_rotate(int cfg, int mode, const BlindRotateArgs& a, int waves_per_block, int num_cus, hipStream_t st);
+hipError_t launch_blind_rotate(int cfg, int mode, const BlindRotateArgs& a, int waves_per_block, int num_cus, const LaunchOpts& opts,
+                               hipStream_t st, LaunchInfo* info = nullptr);
 hipError_t launch_bk_transform(int cfg, int mode, const int32_t* bk, double* bk_x, const double* tw, Field f, double scale,
                                long n_polys, hipStream_t st);
 hipError_t launch_keyswitch(const KeyswitchArgs& a, hipStream_t st);

@@ -249,15 +249,49 @@ struct DevSlab {
   int32_t* ptr = nullptr;
   size_t rows = 0;
   rs_ctx* ctx = nullptr;
+  uint64_t tag = 0;   // fingerprint of the host copy handed out with it
+  uint64_t seq = 0;   // publication order
 };
 
-// Device copies of the ciphertext arrays handed back to the caller, keyed by host pointer.
+// Device copies of the ciphertext arrays handed back to the caller, keyed by host pointer. A slab is
+// reused only if the host array still carries the ciphertexts it was published with (fingerprint over
+// sampled rows): an address recycled for other data, or samples edited between layers, are uploaded afresh.
+// Arrays the caller never feeds to another layer (the logits) would stay here for good, so the table keeps
+// the kMaxResident most recent slabs and releases the rest.
 std::mutex g_lock;
 std::map<const void*, DevSlab> g_resident;
+uint64_t g_seq = 0;
+constexpr size_t kMaxResident = 16;
 
-void remember(const void* host, const DevSlab& s) {
-  std::lock_guard<std::mutex> g(g_lock);
-  g_resident[host] = s;
+// FNV-1a over up to 64 evenly spaced rows (first and last included) of a packed [rows][W] host copy
+uint64_t fingerprint(const int32_t* words, size_t rows, int W) {
+  uint64_t h = 1469598103934665603ull ^ (uint64_t)rows;
+  if (rows == 0) return h;
+  const size_t picks = rows < 64 ? rows : 64;
+  for (size_t k = 0; k < picks; ++k) {
+    const size_t r = picks == 1 ? 0 : k * (rows - 1) / (picks - 1);
+    const int32_t* row = words + r * (size_t)W;
+    for (int w = 0; w < W; ++w) { h ^= (uint32_t)row[w]; h *= 1099511628211ull; }
+  }
+  return h;
+}
+
+void remember(const void* host, DevSlab s) {
+  std::vector<DevSlab> evicted;
+  {
+    std::lock_guard<std::mutex> g(g_lock);
+    s.seq = ++g_seq;
+    auto old = g_resident.find(host);
+    if (old != g_resident.end()) { evicted.push_back(old->second); g_resident.erase(old); }
+    g_resident[host] = s;
+    while (g_resident.size() > kMaxResident) {
+      auto oldest = g_resident.begin();
+      for (auto it = g_resident.begin(); it != g_resident.end(); ++it) if (it->second.seq < oldest->second.seq) oldest = it;
+      evicted.push_back(oldest->second);
+      g_resident.erase(oldest);
+    }
+  }
+  for (const DevSlab& e : evicted) (void)rs_dev_free(e.ctx, e.ptr);
 }
 bool is_resident(const void* host) {
   std::lock_guard<std::mutex> g(g_lock);
@@ -273,6 +307,20 @@ bool take(const void* host, DevSlab* s) {
 }
 
 struct Geometry { int H, Wd, C, Ho, Wo, win_h, win_w, st_h, st_w, off_h, off_w; };
+
+constexpr int32_t kUnit4096 = 1 << 20;   // modSwitchToTorus32(1, 4096)
+constexpr int32_t kUnitRelu = 1 << 18;   // ReLU outputs: 1/16384, so that 1,024 of them sum inside a quarter turn
+constexpr int32_t kQuarter = 1 << 30;
+constexpr int32_t kLutStep = 1 << 21;    // one mod-switched phase step, 2^32 / 2N
+constexpr int kSlopeBitsInt = 8;         // lib/IntFunc.cpp:45
+constexpr int kRingN = 1024;
+
+// The unit in which a network's values travel is not part of tDimensions, so it rides beside it: keyed by
+// the tDimensions object the driver threads through every prep() (nets/*/*/net.cpp: p_dim = layerK->prep(f, p_dim)),
+// together with a copy of what that object held when the previous layer returned it -- a driver that starts
+// a new network with the same object is recognised by the contents having changed.
+struct UnitNote { tDimensions seen; int32_t unit; };
+std::map<const tDimensions*, UnitNote> g_units;
 
 struct LayerImpl {
   bool is_int;
@@ -298,6 +346,17 @@ struct LayerImpl {
   bool pool_fused = false;
   int32_t pool_mu = 0;
   int32_t* d_pool_bias = nullptr;
+  // Encoding: torus32 value of ONE integer step of this layer's input / output (1/4096 = 2^20 for client
+  // pixels and sign bits, 1/16384 = 2^18 for ReLU outputs; DESIGN.md "ReLU semantics")
+  int32_t unit_in = kUnit4096, unit_out = kUnit4096;
+  // IntFunc::Convolution's plaintext branch negates by one's complement (-x - 1): per output channel the
+  // number of negative taps, folded into the bias of integer layers (see int_conv_plain)
+  std::vector<int32_t> neg_taps;
+  bool int_conv_plain = true;
+  // ReLU (Quantize::relu_shift): slope per channel, shift amount, and the test polynomials [depth][N]
+  std::vector<int32_t> slope, raw_bias;
+  int shift_bits = 0, relu_shift = 0;
+  int32_t* d_lut = nullptr;
 
   rs_ctx* ctx() const { return redsec_ctx_of(bk); }
   int W() const { return bk->params->in_out_params->n + 1; }
@@ -317,10 +376,20 @@ LayerImpl* make_impl(bool is_int, eConvType ec, uint32_t dep, ePoolType ep, eQua
   if (L->np.pool.stride.w == 0) L->np.pool.stride.w = L->np.pool.window.w;
   if (ep == E_MAXPOOL) assert(eq == E_ACTIVATION_SIGN);
   if (eq == E_ACTIVATION_RELU) {
-    fprintf(stderr, "redsec layers: the ReLU activation path (relu_shift) is not on this backend yet (SURVEY.md 8f rank 3)\n");
-    abort();
+    L->shift_bits = L->np.quant.shift_bits;
+    if (L->shift_bits < 2 || L->shift_bits > 8) { fprintf(stderr, "redsec layers: ReLU shift_bits %d outside [2, 8]\n", L->shift_bits); abort(); }
   }
+  const char* ic = getenv("REDSEC_INTCONV");   // "enc": the ENCRYPTED branch's constants (-1/4096 per zero/padding tap)
+  L->int_conv_plain = !(ic && strcmp(ic, "enc") == 0);
   return L;
+}
+
+// -1 per negative tap of an integer layer's convolution on the plaintext branch's constants (a sum-pool
+// behind the convolution adds one such term per window tap; windows inside the image, as in every shipped net)
+int32_t neg_fold(const LayerImpl* L, size_t channel) {
+  if (!(L->is_int && L->int_conv_plain) || L->neg_taps.empty()) return 0;
+  const int mul = (L->e_pool == E_SUMPOOL && L->e_conv != E_NO_CONV) ? L->pool.win_h * L->pool.win_w : 1;
+  return L->neg_taps[channel % L->neg_taps.size()] * mul;
 }
 
 uint8_t bits_for(uint32_t up_bound, uint8_t from) {
@@ -335,6 +404,11 @@ tDimensions* prep_impl(LayerImpl* L, FILE* fd, tDimensions* dim, tDimensions* in
   assert(!L->prepared && dim != NULL);
   *in_dim = *dim;
   L->in_count = dim->hw.h * dim->hw.w * (int)dim->in_dep;
+  {
+    std::lock_guard<std::mutex> g(g_lock);
+    auto it = g_units.find(dim);
+    L->unit_in = (it != g_units.end() && memcmp(&it->second.seen, dim, sizeof *dim) == 0) ? it->second.unit : kUnit4096;
+  }
   if (L->e_conv != E_NO_CONV) {
     if (L->e_conv == E_FC || L->e_conv == E_FC_FINAL) { dim->in_dep *= dim->hw.h * dim->hw.w; dim->hw.h = 1; dim->hw.w = 1; }   // flatten
     const tConvParams& c = L->np.conv;
@@ -353,6 +427,9 @@ tDimensions* prep_impl(LayerImpl* L, FILE* fd, tDimensions* dim, tDimensions* in
     const size_t flen = (size_t)g.win_h * g.win_w * g.C * L->depth;
     L->sign.resize(flen); L->zero.resize(flen);
     BinOps::get_ternfilters(fd, L->sign.data(), L->zero.data(), (uint32_t)flen, c.tern_thresh, L->bk);
+    L->neg_taps.assign(L->depth, 0);
+    for (size_t i = 0; i < flen; ++i)
+      if (!L->zero[i] && !L->sign[i]) ++L->neg_taps[i % L->depth];   // filter index ((fh*fw_+fw)*Cin+di)*Cout+od
     dim->up_bound *= (uint32_t)dim->filter_bits * g.win_w * g.win_h * g.C;
     dim->in_bits = bits_for(dim->up_bound, dim->in_bits);
     dim->hw.h = (int16_t)g.Ho; dim->hw.w = (int16_t)g.Wo; dim->in_dep = L->depth; dim->out_bits = SINGLE_BIT;
@@ -385,10 +462,40 @@ tDimensions* prep_impl(LayerImpl* L, FILE* fd, tDimensions* dim, tDimensions* in
     assert(tag == 3 || tag == 4);
     std::vector<int32_t> v((size_t)L->quant_depth);
     got = fread(v.data(), sizeof(int32_t), v.size(), fd);
+    L->raw_bias = v;
     L->bias.resize(v.size());
-    for (size_t i = 0; i < v.size(); ++i) L->bias[i] = modSwitchToTorus32(v[i], 4096);
+    // trivial samples of bias * unit (get_intfilters: modSwitchToTorus32(b, 4096), i.e. unit 2^20, for 1/4096 inputs);
+    // integer layers running on the plaintext branch's constants also fold its -1 per negative tap
+    for (size_t i = 0; i < v.size(); ++i) L->bias[i] = (int32_t)((uint32_t)(v[i] - neg_fold(L, i)) * (uint32_t)L->unit_in);
+    // slope: read when the layer is IntLayer(RELU, E_BNORM) (IntLayer::prep allocates p_slope only then,
+    // IntLayer.cpp:96-100) or BinLayer(RELU) (BinFunc::Quantize::prep reads it whenever p_slope != NULL)
+    if (L->e_act == E_ACTIVATION_RELU && (!L->is_int || L->np.e_bias == E_BNORM)) {
+      got = fread(&tag, 1, 1, fd);
+      assert(tag == 3 || tag == 4);
+      L->slope.resize((size_t)L->quant_depth);
+      got = fread(L->slope.data(), sizeof(int32_t), L->slope.size(), fd);
+    }
   }
-  if (L->e_act == E_ACTIVATION_SIGN) { dim->in_bits = 1; dim->up_bound = 1; dim->scale = L->is_int ? 1.0f : 0.5f; }
+  L->unit_out = L->unit_in;
+  if (L->e_act == E_ACTIVATION_SIGN) { dim->in_bits = 1; dim->up_bound = 1; dim->scale = L->is_int ? 1.0f : 0.5f; L->unit_out = kUnit4096; }
+  if (L->e_act == E_ACTIVATION_RELU) {
+    if (L->slope.empty()) { fprintf(stderr, "redsec layers: ReLU layer without a slope record (needs E_BNORM)\n"); abort(); }
+    if (L->is_int) {
+      int sc_b = 0;                                       // IntFunc::Quantize::prep, lib/IntFunc.cpp:812-815
+      while ((float)(1 << sc_b) < dim->scale) ++sc_b;
+      L->relu_shift = kSlopeBitsInt + sc_b - L->shift_bits;
+      dim->in_bits = (uint8_t)L->shift_bits;             // :835-844
+      dim->scale = (float)((1 << L->shift_bits) - 1);
+      dim->up_bound = 1u << (L->shift_bits - 1);
+    } else {
+      L->relu_shift = L->shift_bits + 1;                  // BinFunc::Quantize::relu_shift shifts by shift_bits + 1 (lib/BinFunc.cpp:1154)
+      dim->in_bits = (uint8_t)(L->shift_bits + 1);        // lib/BinFunc.cpp:1019-1030
+      dim->up_bound = 1u << L->shift_bits;
+      dim->scale = (float)dim->up_bound;
+    }
+    if (L->relu_shift < 0 || L->relu_shift > 40) { fprintf(stderr, "redsec layers: ReLU shift %d out of range\n", L->relu_shift); abort(); }
+    L->unit_out = kUnitRelu;
+  }
   dim->out_bits = SINGLE_BIT;
   L->out_count = L->quant_count;
   if (L->e_pool == E_MAXPOOL && L->e_act == E_ACTIVATION_SIGN && !(L->is_int && L->e_conv == E_FC_FINAL)) {
@@ -415,8 +522,29 @@ tDimensions* prep_impl(LayerImpl* L, FILE* fd, tDimensions* dim, tDimensions* in
     dim->hw.h = (int16_t)g.Ho; dim->hw.w = (int16_t)g.Wo;
   }
   *out_dim = *dim;
+  {
+    std::lock_guard<std::mutex> g(g_lock);
+    g_units[dim] = UnitNote{*dim, L->unit_out};
+  }
   L->prepared = true;
   return dim;
+}
+
+// Test polynomials of a ReLU layer (same table as redsec_amd/nets.py::relu_luts): index t stands for
+// pre = (t - N/2) * (kLutStep / unit_in), the centre of the phase bucket the mod-switch rounds to after the
+// quarter-turn shift; entry = clamp((slope * pre + bias) >> relu_shift, 0, 2^shift_bits - 1) * unit_out
+// (IntOps::shift + IntOps::relu, lib/IntOps.cpp).
+std::vector<int32_t> relu_luts(const LayerImpl* L) {
+  const int64_t upi = kLutStep / L->unit_in, top = (1 << L->shift_bits) - 1;
+  std::vector<int32_t> lut((size_t)L->quant_depth * kRingN);
+  for (int m = 0; m < L->quant_depth; ++m)
+    for (int t = 0; t < kRingN; ++t) {
+      const int64_t pre = (int64_t)(t - kRingN / 2) * upi;
+      const int64_t x = (int64_t)L->slope[m] * pre + (int64_t)L->raw_bias[m];
+      const int64_t y = x < 0 ? 0 : ((x >> L->relu_shift) > top ? top : (x >> L->relu_shift));
+      lut[(size_t)m * kRingN + t] = (int32_t)((uint32_t)y * (uint32_t)L->unit_out);
+    }
+  return lut;
 }
 
 void upload_weights(LayerImpl* L) {
@@ -427,6 +555,14 @@ void upload_weights(LayerImpl* L) {
     RS_CHECK(rs_dev_alloc(c, (void**)&L->d_zero, L->zero.size()));
     RS_CHECK(rs_copy_to_dev(c, L->d_sign, L->sign.data(), L->sign.size()));
     RS_CHECK(rs_copy_to_dev(c, L->d_zero, L->zero.data(), L->zero.size()));
+  }
+  if (L->e_act == E_ACTIVATION_RELU) {
+    // the bias lives inside the test polynomial; what joins the linear stage is the quarter turn that moves
+    // pre in [-N/2, N/2) steps onto [0, 1/2), and the -1 per negative tap of the plaintext branch
+    for (size_t i = 0; i < L->bias.size(); ++i) L->bias[i] = (int32_t)((uint32_t)kQuarter - (uint32_t)neg_fold(L, i) * (uint32_t)L->unit_in);
+    const std::vector<int32_t> lut = relu_luts(L);
+    RS_CHECK(rs_dev_alloc(c, (void**)&L->d_lut, lut.size() * 4));
+    RS_CHECK(rs_copy_to_dev(c, L->d_lut, lut.data(), lut.size() * 4));
   }
   RS_CHECK(rs_dev_alloc(c, (void**)&L->d_bias, L->bias.size() * 4));
   RS_CHECK(rs_copy_to_dev(c, L->d_bias, L->bias.data(), L->bias.size() * 4));
@@ -460,7 +596,9 @@ DevSlab run_layer(LayerImpl* L, DevSlab x) {
   upload_weights(L);
   const bool pool_sum = L->e_pool == E_SUMPOOL;
   // IntFunc constants: ternary-zero and padding taps contribute the trivial -1/4096 (IntFunc.cpp:268,277)
-  const int32_t tap_const = L->is_int ? -mu4096 : 0;
+  // (REDSEC_INTCONV=enc; the default follows the plaintext branch, whose constant is folded into the bias:
+  // the two disagree and only the plaintext one matches the trained biases, DESIGN.md "ReLU semantics")
+  const int32_t tap_const = (L->is_int && !L->int_conv_plain) ? -mu4096 : 0;
   if (L->e_conv != E_NO_CONV) {
     const Geometry& g = L->conv;
     const int rows = g.Ho * g.Wo * (int)L->depth;
@@ -489,6 +627,15 @@ DevSlab run_layer(LayerImpl* L, DevSlab x) {
     x.ptr = y; x.rows = (size_t)rows;
   }
   assert((int)x.rows == L->quant_count);
+  if (L->e_act == E_ACTIVATION_RELU) {
+    // Quantize::relu_shift, corrected: ONE programmable bootstrap per neuron evaluates the plaintext
+    // branch's staircase (lib/IntFunc.cpp:964-967) on the mod-switched phase of the pre-activation
+    int32_t* y = dev_rows(c, x.rows, W);
+    RS_CHECK(rs_bootstrap_lut_dev(c, y, x.ptr, L->d_lut, (size_t)L->quant_depth, x.rows, nullptr));
+    RS_CHECK(rs_sync(c));
+    RS_CHECK(rs_dev_free(c, x.ptr));
+    x.ptr = y;
+  }
   if (L->e_act == E_ACTIVATION_SIGN) {
     const bool maxpool = !L->pool_index.empty();
     // Quantize::execute: one sign bootstrap per neuron (BinOps_enc.cpp:182-186). Ahead of a max-pool
@@ -542,9 +689,24 @@ DevSlab run_layer(LayerImpl* L, DevSlab x) {
 // host array of LweSample -> device slab (or the resident copy a previous layer left)
 DevSlab stage_input(LayerImpl* L, const void* key, const std::vector<const LweSample*>& samples) {
   DevSlab s;
-  if (take(key, &s) && s.rows == samples.size()) return s;
   rs_ctx* c = L->ctx();
   const int W = L->W(), n = W - 1;
+  const bool had = take(key, &s);
+  if (had && s.rows == samples.size() && s.ctx == c) {
+    // same fingerprint as at publication: sampled rows only (packing 131,072 x 351 words per layer just to
+    // compare them would cost more than the check is worth)
+    const size_t rows = samples.size(), picks = rows < 64 ? rows : 64;
+    std::vector<int32_t> probe(picks * (size_t)W);
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)rows;
+    for (size_t k = 0; k < picks; ++k) {
+      const size_t r = picks == 1 ? 0 : k * (rows - 1) / (picks - 1);
+      redsec_pack(&probe[k * W], samples[r], n);
+      for (int w = 0; w < W; ++w) { h ^= (uint32_t)probe[k * W + w]; h *= 1099511628211ull; }
+    }
+    if (h == s.tag) return s;
+  }
+  if (had) RS_CHECK(rs_dev_free(s.ctx, s.ptr));   // stale or foreign: release it and upload what the host holds
+  s = DevSlab{};
   std::vector<int32_t> host(samples.size() * (size_t)W);
   for (size_t i = 0; i < samples.size(); ++i) redsec_pack(&host[i * W], samples[i], n);
   s.ptr = dev_rows(c, samples.size(), W);
@@ -555,22 +717,17 @@ DevSlab stage_input(LayerImpl* L, const void* key, const std::vector<const LweSa
 
 std::vector<int32_t> download(const DevSlab& s, int W) {
   std::vector<int32_t> host(s.rows * (size_t)W);
+  // nothing to certify here: in FFT mode every bootstrapped call is followed on the device by its gated exact
+  // recomputation (include/redsec_hip.h), so what comes down is exact by construction
   RS_CHECK(rs_copy_to_host(s.ctx, host.data(), s.ptr, host.size() * 4));
-  // Layer chains stay on the device and run asynchronously; results become visible to the caller here,
-  // so this is where the FFT mode's running rounding certificate is checked (include/redsec_hip.h).
-  double dist = 0.0;
-  RS_CHECK(rs_rounding_certificate(s.ctx, &dist, 0));
-  if (!(dist < RS_CERTIFICATE_LIMIT)) {
-    fprintf(stderr, "redsec layers: FFT rounding certificate %.3f >= %.2f -- rerun with REDSEC_MODE=exact\n", dist, RS_CERTIFICATE_LIMIT);
-    abort();
-  }
   return host;
 }
 
 // Output as the reference returns it: tBit* for sign layers, tMultiBit* (ctxt[0] used) otherwise.
-void* publish(LayerImpl* L, const DevSlab& out) {
+void* publish(LayerImpl* L, DevSlab out) {
   const int W = L->W(), n = W - 1;
   std::vector<int32_t> host = download(out, W);
+  out.tag = fingerprint(host.data(), out.rows, W);
   void* ret = nullptr;
   if (L->e_act == E_ACTIVATION_SIGN) {
     tBit* bits = bit_calloc((uint32_t)out.rows, L->bk);

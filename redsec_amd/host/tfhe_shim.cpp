@@ -10,7 +10,12 @@
 // nothing here computes a bootstrap on the CPU, and without a GPU those calls abort loudly.
 #include "tfhe/tfhe.h"
 
+#include <initializer_list>
+#include <map>
+#include <mutex>
 #include <random>
+#include <string>
+#include <utility>
 #include <vector>
 
 #include "redsec_hip.h"
@@ -104,8 +109,12 @@ LweBootstrappingKeyFFT* new_bkfft(const TFheGateBootstrappingParameterSet* p, co
   return f;
 }
 
+// Created on the first bootstrap; the per-ciphertext wrappers are called from OpenMP regions of the caller
+// (lib/BinFunc.cpp:217,896,1056), so creation is serialised.
 rs_ctx* ctx_of_fft(const LweBootstrappingKeyFFT* cf) {
   LweBootstrappingKeyFFT* f = const_cast<LweBootstrappingKeyFFT*>(cf);
+  static std::mutex mu;
+  std::lock_guard<std::mutex> g(mu);
   if (f->ctx) return f->ctx;
   const TFheGateBootstrappingParameterSet* p = f->params;
   const TLweParams* tp = p->tgsw_params->tlwe_params;
@@ -304,7 +313,150 @@ void delete_gate_bootstrapping_cloud_keyset(TFheGateBootstrappingCloudKeySet* ks
 void delete_gate_bootstrapping_parameters(TFheGateBootstrappingParameterSet*) {}
 
 // ---- files ----
+// KEY FILES. Two formats are read, told apart by the first bytes; REDSEC_KEY_FORMAT=rs selects the private one
+// for writing, the default is TFHE's.
+//
+// (1) TFHE v1.1's own (tfhe_io.cpp write_tfheGateBootstrappingCloudKeySet / ...SecretKeySet) [TFHE-recalled:
+//     the library is not in this image, so this is restated from its published source and could not be run
+//     against it -- tools/tfhe_crosscheck.md is the recipe for whoever has libtfhe]:
+//       text sections "-----BEGIN <TITLE>-----\n" / "name: value\n"... / "-----END <TITLE>-----\n", names sorted:
+//         GATEBOOTSPARAMS {ks_basebit, ks_t}; LWEPARAMS {alpha_max, alpha_min, n};
+//         TLWEPARAMS {N, alpha_max, alpha_min, k}; TGSWPARAMS {Bgbit, l}
+//       then the bootstrapping key: int32 uid; text section LWEKSPARAMS {basebit, n (= k N), t};
+//         keyswitch key: int32 uid, double max variance, N t base x (int32 a[n], int32 b);
+//         n x TGSW sample: int32 uid, double max variance, (k+1) l x (k+1) x int32[N]
+//       secret key files continue with: int32 uid, int32 lwe_key[n]; int32 uid, k x int32 tlwe_key[N].
+//     The reader takes the sizes from the text sections and does not insist on the uid VALUES (a mismatch is
+//     reported on stderr unless REDSEC_TFHE_QUIET is set), since those constants are the least certain part of
+//     the restatement; REDSEC_TFHE_STRICT=1 turns a mismatch into an error.
+// (2) this backend's first format: 16-byte-aligned header with magic "RSK1"/"RSS1" + raw arrays.
+namespace {
+
+enum TfheUid : int32_t {   // [TFHE-recalled]
+  kUidLweSample = 42, kUidLweKey = 43, kUidTlweKey = 45, kUidTgswSample = 47, kUidLweKeySwitchKey = 200, kUidLweBootstrappingKey = 201,
+};
+
+bool key_format_is_rs() { const char* f = getenv("REDSEC_KEY_FORMAT"); return f && strcmp(f, "rs") == 0; }
+
+void put_section(FILE* f, const char* title, std::initializer_list<std::pair<const char*, std::string>> props) {
+  fprintf(f, "-----BEGIN %s-----\n", title);
+  for (const auto& kv : props) fprintf(f, "%s: %s\n", kv.first, kv.second.c_str());
+  fprintf(f, "-----END %s-----\n", title);
+}
+std::string num(long v) { return std::to_string(v); }
+std::string num(double v) { char b[64]; snprintf(b, sizeof b, "%.17g", v); return b; }
+
+bool get_line(FILE* f, std::string* line) {
+  line->clear();
+  int ch;
+  while ((ch = fgetc(f)) != EOF) { if (ch == '\n') return true; line->push_back((char)ch); }
+  return !line->empty();
+}
+struct Section { std::string title; std::map<std::string, std::string> kv; };
+Section get_section(FILE* f, const char* want) {
+  Section s;
+  std::string line;
+  if (!get_line(f, &line) || line.rfind("-----BEGIN ", 0) != 0 || line.size() < 16) { fprintf(stderr, "redsec tfhe shim: key file: expected section %s\n", want); abort(); }
+  s.title = line.substr(11, line.size() - 16);
+  if (s.title != want) { fprintf(stderr, "redsec tfhe shim: key file: section %s where %s was expected\n", s.title.c_str(), want); abort(); }
+  while (get_line(f, &line)) {
+    if (line.rfind("-----END ", 0) == 0) return s;
+    const size_t pos = line.find(": ");
+    if (pos == std::string::npos) continue;
+    s.kv[line.substr(0, pos)] = line.substr(pos + 2);
+  }
+  fprintf(stderr, "redsec tfhe shim: key file: section %s is not terminated\n", want);
+  abort();
+}
+long prop_long(const Section& s, const char* k) {
+  auto it = s.kv.find(k);
+  if (it == s.kv.end()) { fprintf(stderr, "redsec tfhe shim: key file: %s lacks %s\n", s.title.c_str(), k); abort(); }
+  return strtol(it->second.c_str(), nullptr, 10);
+}
+double prop_double(const Section& s, const char* k) {
+  auto it = s.kv.find(k);
+  if (it == s.kv.end()) { fprintf(stderr, "redsec tfhe shim: key file: %s lacks %s\n", s.title.c_str(), k); abort(); }
+  return strtod(it->second.c_str(), nullptr);
+}
+void put_uid(FILE* f, int32_t uid) { write_exact(f, &uid, sizeof uid, "type uid"); }
+void get_uid(FILE* f, int32_t want, const char* what) {
+  int32_t uid = 0;
+  read_exact(f, &uid, sizeof uid, what);
+  if (uid == want) return;
+  if (getenv("REDSEC_TFHE_STRICT")) { fprintf(stderr, "redsec tfhe shim: %s: type uid %d, expected %d\n", what, uid, want); abort(); }
+  if (!getenv("REDSEC_TFHE_QUIET")) fprintf(stderr, "redsec tfhe shim: note: %s carries type uid %d (this reader expected %d; sizes come from the parameter sections)\n", what, uid, want);
+}
+
+void tfhe_write_params(FILE* f, const TFheGateBootstrappingParameterSet* p) {
+  const TLweParams* tp = p->tgsw_params->tlwe_params;
+  put_section(f, "GATEBOOTSPARAMS", {{"ks_basebit", num((long)p->ks_basebit)}, {"ks_t", num((long)p->ks_t)}});
+  put_section(f, "LWEPARAMS", {{"alpha_max", num(p->in_out_params->alpha_max)}, {"alpha_min", num(p->in_out_params->alpha_min)}, {"n", num((long)p->in_out_params->n)}});
+  put_section(f, "TLWEPARAMS", {{"N", num((long)tp->N)}, {"alpha_max", num(tp->alpha_max)}, {"alpha_min", num(tp->alpha_min)}, {"k", num((long)tp->k)}});
+  put_section(f, "TGSWPARAMS", {{"Bgbit", num((long)p->tgsw_params->Bgbit)}, {"l", num((long)p->tgsw_params->l)}});
+}
+TFheGateBootstrappingParameterSet* tfhe_read_params(FILE* f) {
+  const Section g = get_section(f, "GATEBOOTSPARAMS"), lw = get_section(f, "LWEPARAMS"), tl = get_section(f, "TLWEPARAMS"),
+                tg = get_section(f, "TGSWPARAMS");
+  ParamHeader h{};
+  h.n = (int32_t)prop_long(lw, "n"); h.N = (int32_t)prop_long(tl, "N"); h.k = (int32_t)prop_long(tl, "k");
+  h.l = (int32_t)prop_long(tg, "l"); h.Bgbit = (int32_t)prop_long(tg, "Bgbit");
+  h.ks_t = (int32_t)prop_long(g, "ks_t"); h.ks_basebit = (int32_t)prop_long(g, "ks_basebit");
+  h.lwe_alpha_min = prop_double(lw, "alpha_min"); h.lwe_alpha_max = prop_double(lw, "alpha_max");
+  h.tlwe_alpha_min = prop_double(tl, "alpha_min"); h.tlwe_alpha_max = prop_double(tl, "alpha_max");
+  check_header(h, "TFHE key file");
+  return params_from_header(h);
+}
+void tfhe_write_bk(FILE* f, const TFheGateBootstrappingParameterSet* p, const LweBootstrappingKey* bk) {
+  const TLweParams* tp = p->tgsw_params->tlwe_params;
+  const int32_t n = p->in_out_params->n, N = tp->N, k = tp->k, kpl = p->tgsw_params->kpl;
+  put_uid(f, kUidLweBootstrappingKey);
+  put_section(f, "LWEKSPARAMS", {{"basebit", num((long)p->ks_basebit)}, {"n", num((long)(k * N))}, {"t", num((long)p->ks_t)}});
+  put_uid(f, kUidLweKeySwitchKey);
+  const double ks_var = p->in_out_params->alpha_min * p->in_out_params->alpha_min;
+  write_exact(f, &ks_var, sizeof ks_var, "keyswitch variance");
+  write_exact(f, bk->ksk_words, sizeof(int32_t) * ksk_words(p), "keyswitch key");      // [kN][t][base] x (a[n], b): TFHE's ks0_raw order
+  const double bk_var = tp->alpha_min * tp->alpha_min;
+  const size_t sample_words = (size_t)kpl * (k + 1) * N;
+  for (int32_t i = 0; i < n; ++i) {
+    put_uid(f, kUidTgswSample);
+    write_exact(f, &bk_var, sizeof bk_var, "TGSW variance");
+    write_exact(f, bk->bk_words + (size_t)i * sample_words, sizeof(int32_t) * sample_words, "TGSW sample");
+  }
+}
+LweBootstrappingKey* tfhe_read_bk(FILE* f, const TFheGateBootstrappingParameterSet* p) {
+  const TLweParams* tp = p->tgsw_params->tlwe_params;
+  const int32_t n = p->in_out_params->n, N = tp->N, k = tp->k, kpl = p->tgsw_params->kpl;
+  get_uid(f, kUidLweBootstrappingKey, "bootstrapping key");
+  const Section ks = get_section(f, "LWEKSPARAMS");
+  if (prop_long(ks, "n") != (long)k * N || prop_long(ks, "t") != p->ks_t || prop_long(ks, "basebit") != p->ks_basebit) {
+    fprintf(stderr, "redsec tfhe shim: key file: LWEKSPARAMS disagree with the parameter sections\n");
+    abort();
+  }
+  LweBootstrappingKey* bk = new_bk(p);
+  double var = 0;
+  get_uid(f, kUidLweKeySwitchKey, "keyswitch key");
+  read_exact(f, &var, sizeof var, "keyswitch variance");
+  read_exact(f, bk->ksk_words, sizeof(int32_t) * ksk_words(p), "keyswitch key");
+  const size_t sample_words = (size_t)kpl * (k + 1) * N;
+  for (int32_t i = 0; i < n; ++i) {
+    get_uid(f, kUidTgswSample, "TGSW sample");
+    read_exact(f, &var, sizeof var, "TGSW variance");
+    read_exact(f, bk->bk_words + (size_t)i * sample_words, sizeof(int32_t) * sample_words, "TGSW sample");
+  }
+  return bk;
+}
+// first bytes decide the format: '-' opens a TFHE text section
+bool file_is_tfhe(FILE* f) {
+  const int ch = fgetc(f);
+  if (ch == EOF) { fprintf(stderr, "redsec tfhe shim: empty key file\n"); abort(); }
+  ungetc(ch, f);
+  return ch == '-';
+}
+
+}  // namespace
+
 void export_tfheGateBootstrappingCloudKeySet_toFile(FILE* f, const TFheGateBootstrappingCloudKeySet* key) {
+  if (!key_format_is_rs()) { tfhe_write_params(f, key->params); tfhe_write_bk(f, key->params, key->bk); return; }
   const ParamHeader h = header_from_params(kMagicCloud, key->params);
   write_exact(f, &h, sizeof h, "cloud key header");
   write_exact(f, key->bk->bk_words, sizeof(int32_t) * bk_words(key->params), "bootstrapping key");
@@ -312,6 +464,15 @@ void export_tfheGateBootstrappingCloudKeySet_toFile(FILE* f, const TFheGateBoots
 }
 void export_tfheGateBootstrappingSecretKeySet_toFile(FILE* f, const TFheGateBootstrappingSecretKeySet* key) {
   const ParamHeader h = header_from_params(kMagicSecret, key->params);
+  if (!key_format_is_rs()) {   // write_tfheGateBootstrappingSecretKeySet: cloud part, lwe key, tgsw (= tlwe) key
+    tfhe_write_params(f, key->params);
+    tfhe_write_bk(f, key->params, key->cloud.bk);
+    put_uid(f, kUidLweKey);
+    write_exact(f, key->lwe_key->key, sizeof(int32_t) * (size_t)h.n, "lwe key");
+    put_uid(f, kUidTlweKey);
+    write_exact(f, key->tgsw_key->key, sizeof(int32_t) * (size_t)h.k * h.N, "tlwe key");
+    return;
+  }
   write_exact(f, &h, sizeof h, "secret key header");
   write_exact(f, key->lwe_key->key, sizeof(int32_t) * (size_t)h.n, "lwe key");
   write_exact(f, key->tgsw_key->key, sizeof(int32_t) * (size_t)h.k * h.N, "tlwe key");
@@ -319,6 +480,11 @@ void export_tfheGateBootstrappingSecretKeySet_toFile(FILE* f, const TFheGateBoot
   write_exact(f, key->cloud.bk->ksk_words, sizeof(int32_t) * ksk_words(key->params), "keyswitch key");
 }
 TFheGateBootstrappingCloudKeySet* new_tfheGateBootstrappingCloudKeySet_fromFile(FILE* f) {
+  if (file_is_tfhe(f)) {
+    TFheGateBootstrappingParameterSet* p = tfhe_read_params(f);
+    LweBootstrappingKey* bk = tfhe_read_bk(f, p);
+    return new TFheGateBootstrappingCloudKeySet(p, bk, new_bkfft(p, bk));
+  }
   ParamHeader h;
   read_exact(f, &h, sizeof h, "cloud key header");
   if (h.magic != kMagicCloud) { fprintf(stderr, "redsec tfhe shim: not a cloud key file\n"); abort(); }
@@ -330,6 +496,18 @@ TFheGateBootstrappingCloudKeySet* new_tfheGateBootstrappingCloudKeySet_fromFile(
   return new TFheGateBootstrappingCloudKeySet(p, bk, new_bkfft(p, bk));
 }
 TFheGateBootstrappingSecretKeySet* new_tfheGateBootstrappingSecretKeySet_fromFile(FILE* f) {
+  if (file_is_tfhe(f)) {
+    TFheGateBootstrappingParameterSet* p = tfhe_read_params(f);
+    LweBootstrappingKey* bk = tfhe_read_bk(f, p);
+    const int32_t n = p->in_out_params->n, kN = p->tgsw_params->tlwe_params->k * p->tgsw_params->tlwe_params->N;
+    LweKey* lk = new LweKey{p->in_out_params, alloc_words((size_t)n, "lwe key")};
+    TGswKey* gk = new TGswKey{p->tgsw_params, alloc_words((size_t)kN, "tlwe key")};
+    get_uid(f, kUidLweKey, "lwe key");
+    read_exact(f, lk->key, sizeof(int32_t) * (size_t)n, "lwe key");
+    get_uid(f, kUidTlweKey, "tlwe key");
+    read_exact(f, gk->key, sizeof(int32_t) * (size_t)kN, "tlwe key");
+    return new TFheGateBootstrappingSecretKeySet(p, bk, new_bkfft(p, bk), lk, gk);
+  }
   ParamHeader h;
   read_exact(f, &h, sizeof h, "secret key header");
   if (h.magic != kMagicSecret) { fprintf(stderr, "redsec tfhe shim: not a secret key file\n"); abort(); }
@@ -347,7 +525,7 @@ TFheGateBootstrappingSecretKeySet* new_tfheGateBootstrappingSecretKeySet_fromFil
 // TFHE v1.1's LweSample record (tfhe_io.cpp write_lweSample): int32 type uid 42, int32 a[n], int32 b,
 // double current_variance = 4n + 16 bytes -- image.ctxt / network_output.ctxt
 // written here are byte-compatible with a TFHE client's.
-static const int32_t kLweSampleTypeUid = 42;
+static const int32_t kLweSampleTypeUid = kUidLweSample;
 void export_gate_bootstrapping_ciphertext_toFile(FILE* f, const LweSample* s, const TFheGateBootstrappingParameterSet* p) {
   write_exact(f, &kLweSampleTypeUid, sizeof(int32_t), "sample type uid");
   write_exact(f, s->a, sizeof(Torus32) * (size_t)p->in_out_params->n, "sample mask");

@@ -124,6 +124,124 @@ class EncryptedMnist:
         return be.linear_fc(bits, sign, zero, zero_tap_b=0, bias_b=bias)      # Quantize::add_bias, no bootstrap
 
 
+# ---- ReLU networks (nets/mnist/relu1024x{1,2,3}) -------------------------------------------------------
+# Quantize::relu_shift (lib/IntFunc.cpp:934-973), corrected semantics -- DESIGN.md "ReLU semantics".
+# The reference's ENCRYPTED branch is not a function of the layer input (shared scratch across OpenMP
+# threads, accumulation into an uncleared ciphertext, +-1/4096 operands fed to a +-1/8 MUX, and
+# slope*x + bias wrapping around the torus); its plaintext branch is: x = slope*pre + bias;
+# y = x >> slope_bits; out = 0 if x < 0 else min(y, 2^shift_bits - 1). That staircase is evaluated here as
+# ONE programmable bootstrap per neuron (rs_bootstrap_lut_dev) whose test polynomial tabulates it over
+# the mod-switched phase of pre, with two encoding choices the reference leaves open:
+#   * the phase is shifted by 1/4 so that pre in [-N/2, N/2) LUT steps lands on [0, 1/2), where a
+#     negacyclic test polynomial is unconstrained;
+#   * ReLU outputs are emitted in units of RELU_UNIT = 2^-14 (not 2^-12): the next layer sums up to 1,024 of
+#     them (|pre| up to 2,690 over the 100 bundled images, 15,360 worst case) and must stay inside a
+#     quarter turn. Each layer therefore carries its input unit; biases are added in that unit.
+SLOPE_BITS_INT = 8            # lib/IntFunc.cpp:45
+UNIT_4096 = 1 << 20           # one integer step of a client-encrypted / sign-layer value: 1/4096
+RELU_UNIT = 1 << 18           # one integer step of a ReLU output: 1/16384
+QUARTER = 1 << 30
+LUT_STEP = 1 << 21            # torus32 width of one mod-switched phase step (2^32 / 2N, N = 1024)
+
+
+def relu_luts(slope, bias, slope_bits, shift_bits, unit_in, unit_out, N=1024):
+    """Test polynomials of a ReLU layer: int32 [len(slope)][N]. Index t <-> pre = (t - N/2) * (LUT_STEP / unit_in)
+    (the centre of the phase bucket the mod-switch rounds to, after the quarter-turn shift)."""
+    upi = LUT_STEP // unit_in
+    assert upi * unit_in == LUT_STEP and upi >= 1
+    pre = (np.arange(N, dtype=np.int64) - N // 2) * upi
+    x = slope.astype(np.int64)[:, None] * pre[None, :] + bias.astype(np.int64)[:, None]
+    y = np.where(x < 0, 0, np.minimum(x >> slope_bits, (1 << shift_bits) - 1))       # IntOps::shift + IntOps::relu
+    return np.ascontiguousarray((y * unit_out).astype(np.uint64).astype(np.uint32).view(np.int32))
+
+
+def relu_slope_bits(scale, shift_bits):
+    """IntFunc::Quantize::prep, lib/IntFunc.cpp:812-815: SLOPE_BITS + ceil(log2(scale)) - shift_bits."""
+    sc_b = 0
+    while (1 << sc_b) < scale:
+        sc_b += 1
+    return SLOPE_BITS_INT + sc_b - shift_bits
+
+
+class MnistReluNet:
+    """Weights of nets/mnist/relu1024x<K>: IntLayer(NO_CONV, SUMPOOL, NONE); K x IntLayer(FC 1024, RELU
+    shift_bits 4); IntLayer(FC 10, NONE) (net.cpp:125-167). Records: bias0[1]; per hidden layer ternary
+    [K][1024], bias[1024], slope[1024]; final ternary [1024][10], bias[10]."""
+
+    SHIFT_BITS = 4
+
+    def __init__(self, blob, hidden_layers, hidden=1024, classes=10):
+        r = WeightReader(blob)
+        self.bias0 = r.ints(1)
+        self.fc = []
+        k = 14 * 14
+        for _ in range(hidden_layers):
+            sign, zero = r.ternary(k * hidden)
+            bias = r.ints(hidden)
+            slope = r.ints(hidden)
+            self.fc.append((sign.reshape(k, hidden), zero.reshape(k, hidden), bias, slope))
+            k = hidden
+        sign, zero = r.ternary(k * classes)
+        self.final = (sign.reshape(k, classes), zero.reshape(k, classes), r.ints(classes))
+        assert r.done(), "trailing bytes in weight file"
+
+    @staticmethod
+    def neg_taps(sign, zero):
+        """IntFunc::Convolution's plaintext branch multiplies by -1 as the one's complement ~x = -x - 1
+        (IntOps::invert, lib/IntOps.cpp): every NEGATIVE tap also contributes -1. The trained biases fold
+        that constant, so the encrypted chain adds it too (the ENCRYPTED branch's own constant, -1/4096 per
+        ZERO tap at lib/IntFunc.cpp:268,277, classifies 5 % of relu1024x2's bundled images; this one 100 %)."""
+        return ((zero == 0) & (sign == 0)).sum(axis=0).astype(np.int64)
+
+    def stages(self):
+        """Per hidden layer: (slope_bits, unit_in, unit_out); the scale chain of IntFunc::*::prep."""
+        out = []
+        scale, unit = 4.0, UNIT_4096          # input scale 1 x 2x2 sum-pool (lib/IntFunc.cpp:629)
+        for _ in self.fc:
+            out.append((relu_slope_bits(scale, self.SHIFT_BITS), unit, RELU_UNIT))
+            scale, unit = float((1 << self.SHIFT_BITS) - 1), RELU_UNIT
+        return out, unit
+
+
+def relu_preprocess(pixels):
+    """nets/mnist/relu1024x1/main.cpp:203: v / 100 - 1 (0..99 -> -1, 100..199 -> 0, 200..255 -> 1)."""
+    return np.asarray(pixels, dtype=np.int64) // 100 - 1
+
+
+class EncryptedMnistRelu:
+    """relu1024x<K> on a redsec_amd.Backend, device-resident. image_ct: [784][W] encryptions of
+    relu_preprocess(pixels) / 4096. Returns the 10 logit ciphertexts in units of `self.logit_unit`."""
+
+    def __init__(self, backend, net):
+        import torch
+        self.be = backend
+        dev = "cuda:%d" % backend.device
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        w32 = lambda a: np.asarray(a, np.int64).astype(np.uint64).astype(np.uint32).view(np.int32)
+        self.bias0 = t(w32(net.bias0.astype(np.int64) * UNIT_4096))
+        self.pool = dict(H=28, Wd=28, C=1, win_h=2, win_w=2, stride_h=2, stride_w=2, off_h=0, off_w=0, Ho=14, Wo=14)
+        stages, self.logit_unit = net.stages()
+        self.fc = []
+        for (sign, zero, bias, slope), (sb, u_in, u_out) in zip(net.fc, stages):
+            lin_bias = w32(QUARTER - net.neg_taps(sign, zero) * u_in)          # quarter-turn shift + the -1 per negative tap
+            self.fc.append((t(sign), t(zero), t(lin_bias), t(relu_luts(slope, bias, sb, net.SHIFT_BITS, u_in, u_out))))
+        sign, zero, bias = net.final
+        self.final = (t(sign), t(zero), t(w32((bias.astype(np.int64) - net.neg_taps(sign, zero)) * self.logit_unit)))
+
+    def run(self, image_ct, taps=None):
+        be = self.be
+        v = be.sumpool(image_ct.view(28, 28, 1, be.W), self.pool, bias_b=self.bias0).view(196, be.W)   # Quantize::add_bias
+        if taps is not None:
+            taps["in0"] = v
+        for li, (sign, zero, lin_bias, luts) in enumerate(self.fc):
+            pre = be.linear_fc(v, sign, zero, zero_tap_b=0, bias_b=lin_bias)
+            v = be.bootstrap_lut(pre, luts)
+            if taps is not None:
+                taps["pre%d" % (li + 1)], taps["act%d" % (li + 1)] = pre, v
+        sign, zero, bias = self.final
+        return be.linear_fc(v, sign, zero, zero_tap_b=0, bias_b=bias)
+
+
 class EncryptedCifar:
     """nets/cifar/binarynet{,_small}/net.cpp:96-209 on a redsec_amd.Backend, device-resident:
     IntLayer(NO_CONV, SIGN); 6 x BinLayer(CONV 3x3 same, SIGN), a 2x2 max-pool after every second one;

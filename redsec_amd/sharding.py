@@ -44,3 +44,41 @@ def sharded_stage(fn, batch, group=None):
     lo, hi = shard_range(batch.shape[0], rank, world)
     out = fn(batch[lo:hi].contiguous())
     return all_gather_rows(out, batch.shape[0], group) if world > 1 else out
+
+
+class OverlappedGather:
+    """All-gather of equally sized per-rank row blocks that overlaps with the NEXT step's kernels.
+
+    The gate batch of a layer stage shards across the GPUs of a node with no exchange until its outputs are needed
+    whole ("final RCCL gather over xGMI" of the north star). With backend "nccl" (= RCCL) the collective runs on the
+    process group's own stream: launch() makes that stream wait for the kernels already enqueued on the current
+    stream and returns at once; wait() makes the current stream wait for the collective. Two result buffers
+    alternate, so step k+1 computes while the outputs of step k travel. With "gloo" (CPU tests, one-GPU
+    rehearsals) the same calls run synchronously through host memory.
+    """
+
+    def __init__(self, rows_per_rank, width, dtype, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rows = int(rows_per_rank)
+        self.via_host = torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo"
+        buf_dev = "cpu" if self.via_host else device
+        self.full = [torch.empty((self.world * self.rows, width), dtype=dtype, device=buf_dev) for _ in range(2)]
+        self.device = device
+        self.k = 0
+
+    def launch(self, local):
+        """Start gathering `local` ([rows_per_rank][width]); returns (handle, full) where `full` is valid after wait(handle)."""
+        assert local.shape[0] == self.rows
+        full = self.full[self.k % 2]
+        self.k += 1
+        if self.via_host:
+            dist.all_gather_into_tensor(full, local.cpu(), group=self.group)
+            return None, full
+        work = dist.all_gather_into_tensor(full, local, group=self.group, async_op=True)
+        return work, full
+
+    @staticmethod
+    def wait(handle):
+        if handle is not None:
+            handle.wait()

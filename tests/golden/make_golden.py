@@ -51,6 +51,24 @@ def main():
         print(net, "accuracy", acc, "image0", logits[0] if logits else progress[:3])
 
 
+def relu():
+    """ReLU nets: the reference's main.cpp runs ONE image and prints only label/prediction
+    (nets/mnist/relu1024x1/main.cpp:25,160), so the logits of the first 100 rows come from oracle/ref_logits_driver.cpp
+    (our main() around the reference's unmodified HeBNN, plaintext flavour). ONE OpenMP thread: the reference's
+    relu_shift loop shares a scratch value between threads (lib/IntFunc.cpp:953) and is not deterministic otherwise."""
+    for net in ("relu1024x1", "relu1024x2", "relu1024x3"):
+        exe = os.path.join(ROOT, "oracle/_ref/mnist_%s_logits.out" % net)
+        out = subprocess.run([exe, "../mnist_data.csv", "100", "relu"], cwd=os.path.join(REF, "nets/mnist", net), capture_output=True,
+                             text=True, check=True, env=dict(os.environ, OMP_NUM_THREADS="1")).stdout
+        rows = [[int(t) for t in l.split("logits")[1].split()] for l in out.splitlines() if l.startswith("row")]
+        assert len(rows) == 100 and all(len(r) == 10 for r in rows)
+        json.dump({"source": "reference plaintext flavour of nets/mnist/%s through oracle/ref_logits_driver.cpp, 100 rows of "
+                             "nets/mnist/mnist_data.csv, input v/100 - 1, OMP_NUM_THREADS=1" % net, "logits": rows},
+                  open(os.path.join(HERE, "mnist_%s.json" % net), "w"), separators=(",", ":"))
+        shutil.copyfile(os.path.join(REF, "nets/mnist", net, "var_prep.dat"), os.path.join(HERE, "mnist_%s_var_prep.dat" % net))
+        print(net, "image0", rows[0])
+
+
 def cifar():
     """CIFAR nets: the reference's main.cpp runs NUM_SAMPLES = 1 image (main.cpp:25) and prints only
     label/prediction, so the fixture holds that one prediction plus the first 20 rows of
@@ -79,3 +97,4 @@ if __name__ == "__main__":
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
     cifar()
     main()
+    relu()

@@ -79,6 +79,8 @@ def lib():
     L.ro_bootstrap_batch.argtypes = [C.c_void_p, _i32p, C.c_int32, _i32p, C.c_size_t]
     L.ro_gate_batch.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p, _i32p, C.c_size_t]
     L.ro_mux_batch.argtypes = [C.c_void_p, _i32p, _i32p, _i32p, _i32p, C.c_size_t]
+    L.ro_bootstrap_lut.argtypes = [C.c_void_p, _i32p, _i32p, _i32p]
+    L.ro_bootstrap_lut_batch.argtypes = [C.c_void_p, _i32p, _i32p, C.c_size_t, _i32p, C.c_size_t]
     L.ro_max_threads.restype = C.c_int
     L.ro_set_threads.argtypes = [C.c_int]
     L.ro_linear_fc.argtypes = [_i32p, _i32p, _u8p, _u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
@@ -197,6 +199,14 @@ class Ctx:
         x = np.ascontiguousarray(x, np.int32)
         out = np.zeros_like(x)
         lib().ro_bootstrap_batch(self.h, _p(out), int(mu), _p(x), x.shape[0])
+        return out
+
+    def bootstrap_lut_batch(self, x, luts):
+        """Programmable bootstrap: ciphertext b uses the test polynomial luts[b % len(luts)] ([L][N] int32)."""
+        x = np.ascontiguousarray(x, np.int32)
+        luts = np.ascontiguousarray(luts, np.int32).reshape(-1, self.p.N)
+        out = np.zeros_like(x)
+        lib().ro_bootstrap_lut_batch(self.h, _p(out), _p(luts), luts.shape[0], _p(x), x.shape[0])
         return out
 
     def bootstrap_wo_ks(self, x, mu):

@@ -43,6 +43,35 @@ def forward(net, pixels, taps=None):
     return bits @ w + bias.astype(np.int64)
 
 
+# ---- nets/mnist/relu1024x<K>: the reference's PLAINTEXT flavour, restated -----------------------------------
+def load_relu_net(name):
+    from redsec_amd.nets import MnistReluNet
+    blob = open(os.path.join(GOLD, "mnist_%s_var_prep.dat" % name), "rb").read()
+    return MnistReluNet(blob, hidden_layers=int(name[-1]))
+
+
+def relu_forward(net, pixels, taps=None):
+    """pixels [784] -> integer logits [10], bit for bit what the reference's plaintext build computes when run
+    on ONE thread (tests/golden/mnist_relu1024x*.json; its relu_shift loop shares a scratch value between
+    OpenMP threads, lib/IntFunc.cpp:953): IntFunc::Convolution multiplies by -1 as ~x (IntOps::invert), so a
+    negative tap contributes -x - 1; relu_shift is x = slope * pre + bias, y = x >> slope_bits,
+    out = 0 if x < 0 else min(y, 15) (lib/IntFunc.cpp:964-967, lib/IntOps.cpp relu/shift)."""
+    from redsec_amd import nets
+    x = nets.relu_preprocess(pixels).reshape(28, 28)
+    v = x.reshape(14, 2, 14, 2).sum(axis=(1, 3)).reshape(196) + int(net.bias0[0])
+    stages, _ = net.stages()
+    for li, ((sign, zero, bias, slope), (sb, _, _)) in enumerate(zip(net.fc, stages)):
+        w = np.where(zero == 1, 0, np.where(sign == 1, 1, -1)).astype(np.int64)
+        pre = v @ w - net.neg_taps(sign, zero)
+        xb = slope.astype(np.int64) * pre + bias.astype(np.int64)
+        v = np.where(xb < 0, 0, np.minimum(xb >> sb, (1 << net.SHIFT_BITS) - 1))
+        if taps is not None:
+            taps["pre%d" % (li + 1)], taps["act%d" % (li + 1)] = pre.copy(), v.copy()
+    sign, zero, bias = net.final
+    w = np.where(zero == 1, 0, np.where(sign == 1, 1, -1)).astype(np.int64)
+    return v @ w - net.neg_taps(sign, zero) + bias.astype(np.int64)
+
+
 # ---- CIFAR binarynet / binarynet_small (nets/cifar/*/net.cpp:96-209) ---------------------------------
 CIFAR_WIDTHS = {"binarynet": ([128, 128, 256, 256, 512, 512], [1024, 1024]),
                 "binarynet_small": ([64, 64, 128, 128, 256, 256], [512, 512])}

@@ -41,7 +41,14 @@ def write_image_csv(path, label, pixels):
 
 
 def read_secret_key(path):
+    """secret.key as the shim writes it: TFHE v1.1's layout (default) or the private RSS1 header + arrays
+    (REDSEC_KEY_FORMAT=rs). The TFHE layout is parsed by redsec_amd/client.py's own reader, an independent
+    restatement of the format in the other language."""
     with open(path, "rb") as f:
+        if f.peek(1)[:1] == b"-":
+            from redsec_amd import client
+            k = client.read_tfhe_keyset(f, secret=True)
+            return dict(n=k["n"], N=k["N"], k=k["k"], l=k["l"], Bgbit=k["Bgbit"], t=k["t"], basebit=k["basebit"]), k["lwe_key"]
         magic, n, N, k, l, bg, t, bb, *_ = HEADER.unpack(f.read(HEADER.size))
         assert magic == 0x31535352
         lwe = np.frombuffer(f.read(4 * n), np.int32)

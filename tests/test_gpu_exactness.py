@@ -1,0 +1,126 @@
+"""Exactness is a property of the product (VERDICT r1 item 1 / ADVICE): in FFT mode every bootstrapped call -- the
+asynchronous *_dev ones included -- is followed on its stream by the exact-NTT kernels gated on the call's rounding
+certificate. Forcing the limit to 0 makes every call take that recomputation, which must still equal the oracle word
+for word; and one context serves several streams at once (per-stream workspace, counter, certificate slots)."""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+ALPHA = 2.0 ** -15
+
+
+def _dev(x):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(x, np.int32)).cuda()
+
+
+def _bits(ks, B, seed):
+    rng = np.random.default_rng(seed)
+    e8 = ol.to_torus(1, 8)
+    bits = rng.integers(0, 2, B)
+    return bits, ks.encrypt(np.where(bits == 1, e8, -e8), ALPHA, seed)
+
+
+def _backend(ks, name):
+    import redsec_amd
+    be = redsec_amd.Backend(redsec_amd.params(name, n=ks.p.n), device=0)
+    be.load_keys(ks.bk, ks.ksk)
+    return be
+
+
+@pytest.mark.parametrize("fix,name", [("toy_default", "default128"), ("toy_redsec", "redsec_small_v2")])
+def test_forced_exact_recomputation_on_the_async_path(fix, name, request):
+    import torch
+    ks, ctx = request.getfixturevalue(fix)
+    be = _backend(ks, name)
+    assert be.mode() == "fft"
+    cus = be.info()["num_cus"]
+    mu = ol.to_torus(1, 8)
+    for B in (5, 3 * cus + 1, 8 * cus + 3):          # cooperative, duo / per-wave, lock-step workgroup forms
+        _, ca = _bits(ks, B, 10 + B)
+        _, cb = _bits(ks, B, 11 + B)
+        da, db = _dev(ca), _dev(cb)
+        n0 = be.certify()[1]                         # the recomputed-call count is cumulative
+        normal = be.gate("NAND", da, db)
+        dist, n = be.certify()
+        assert 0 < dist < 0.2 and n == n0            # certified, nothing recomputed
+        be.set_certificate_limit(0.0)                # every call's certificate now "fails"
+        forced = be.gate("NAND", da, db)             # *_dev call: no host round trip in between
+        lut = torch.full((1, ks.p.N), int(mu), dtype=torch.int32, device="cuda")
+        forced_lut = be.bootstrap_lut(da, lut)
+        forced_mux = be.mux(da, db, da)
+        dist, n = be.certify()
+        assert n == n0 + 3 and be.fft_fallbacks() == n   # three calls were recomputed by the exact-NTT kernels
+        be.set_certificate_limit(0.25)
+        assert torch.equal(normal, forced)
+        sample = np.r_[0:min(B, 6), max(0, B - 5):B]
+        assert np.array_equal(forced.cpu().numpy()[sample], ctx.gate_batch("NAND", ca[sample], cb[sample]))
+        assert np.array_equal(forced_lut.cpu().numpy()[sample], ctx.bootstrap_batch(ca[sample], mu))
+        assert np.array_equal(forced_mux.cpu().numpy()[sample], ctx.mux_batch(ca[sample], cb[sample], ca[sample]))
+        # host-pointer calls go through the same path
+        be.set_certificate_limit(0.0)
+        assert np.array_equal(be.gate_host("XOR", ca[:4], cb[:4]), ctx.gate_batch("XOR", ca[:4], cb[:4]))
+        be.set_certificate_limit(0.25)
+        be.certify()
+    be.close()
+
+
+def test_two_streams_and_two_threads_on_one_context(toy_default):
+    """Calls on different streams of ONE context run concurrently, issued from two host threads: each stream has its
+    own extracted-sample workspace, work counter and certificate slots (include/redsec_hip.h "Streams")."""
+    import torch
+    ks, ctx = toy_default
+    be = _backend(ks, "default128")
+    cus = be.info()["num_cus"]
+    Bs = (8 * cus + 5, 2 * cus + 7)                   # persistent/lock-step form on one stream, per-wave form on the other
+    inputs = [(_bits(ks, B, 50 + i)[1], _bits(ks, B, 60 + i)[1]) for i, B in enumerate(Bs)]
+    dev = [(_dev(a), _dev(b)) for a, b in inputs]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    outs = [None, None]
+    errs = []
+
+    def work(i):
+        try:
+            with torch.cuda.stream(streams[i]):
+                for _ in range(3):                    # several calls back to back on each stream
+                    outs[i] = be.gate("NAND" if i == 0 else "XOR", dev[i][0], dev[i][1])
+                d, n = be.certify()
+                assert 0 < d < 0.2 and n == 0
+        except Exception as e:                        # surfaced below: an assert in a thread is silent otherwise
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    torch.cuda.synchronize()
+    for i, op in enumerate(("NAND", "XOR")):
+        a, b = inputs[i]
+        sample = np.r_[0:6, Bs[i] - 6:Bs[i]]
+        assert np.array_equal(outs[i].cpu().numpy()[sample], ctx.gate_batch(op, a[sample], b[sample])), op
+        with torch.cuda.stream(streams[i]):           # and the same call alone gives the same words everywhere
+            again = be.gate(op, dev[i][0], dev[i][1])
+        streams[i].synchronize()
+        assert torch.equal(again, outs[i])
+    be.close()
+
+
+def test_kernel_form_is_reported_per_launch(toy_redsec):
+    ks, _ = toy_redsec
+    be = _backend(ks, "redsec_small_v2")
+    cus = be.info()["num_cus"]
+    mu = ol.to_torus(1, 4096)
+    seen = {}
+    for B in (3, cus + 9, 3 * cus, 8 * cus):
+        _, ct = _bits(ks, B, B)
+        be.bootstrap(_dev(ct), mu)
+        seen[B] = be.last_launch()
+    assert seen[3]["form"] == "coop4" and seen[cus + 9]["form"] == "coop2"
+    assert seen[3 * cus]["form"] == "duo" and seen[3 * cus]["resident"] == 3 * cus
+    assert seen[8 * cus]["form"] == "workgroup" and seen[8 * cus]["resident"] == 8 * cus and seen[8 * cus]["waves_per_block"] == 8
+    assert be.info()["waves_per_block"] == 8
+    be.close()

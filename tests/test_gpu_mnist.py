@@ -145,13 +145,15 @@ def test_linear_kernels_against_numpy():
     bias2 = torch.from_numpy(rng.integers(-2**31, 2**31, Cout2).astype(np.int32)).cuda()
     shape2 = dict(H=H2, Wd=Wd2, Cin=Cin2, Cout=Cout2, fh=3, fw=3, stride_h=1, stride_w=1, off_h=1, off_w=1, Ho=H2, Wo=Wd2)
     tiled = be2.conv_ternary(x2, sign2, zero2, shape2, bias_b=bias2)
-    os.environ["RS_NO_CONV_TILED"] = "1"
+    os.environ["RS_NO_CONV_TILED"] = "1"          # launch switches are read once, at context creation
     try:
-        plain = be2.conv_ternary(x2, sign2, zero2, shape2, bias_b=bias2)
+        be3 = redsec_amd.Backend(redsec_amd.params("redsec_small_v2"), 0)
     finally:
         del os.environ["RS_NO_CONV_TILED"]
+    plain = be3.conv_ternary(x2, sign2, zero2, shape2, bias_b=bias2)
     assert torch.equal(tiled, plain)
     be2.close()
+    be3.close()
     # sum pooling 2x2 stride 2 (valid) and 3x3 stride 1 same-pad
     for win, stride, off, Ho, Wo in ((2, 2, 0, 3, 3), (3, 1, 1, 7, 6)):
         shape = dict(H=H, Wd=Wd, C=Cin, win_h=win, win_w=win, stride_h=stride, stride_w=stride, off_h=off, off_w=off, Ho=Ho, Wo=Wo)

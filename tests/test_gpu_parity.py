@@ -257,17 +257,25 @@ def test_workgroup_kernel_ragged_groups_and_identity_steps(which, fix, size, req
     mu = ol.to_torus(1, 8)
     d = _dev(ct)
     got = be.bootstrap(d, mu)
+    if be.mode() == "fft":
+        assert be.last_launch()["form"] == ("workgroup" if size == "wg8" else ("duo" if ks.p.bk_l % 2 == 0 else "per_wave"))
+    # the launch switches are read once, at context creation: a second context under RS_NO_WG runs the per-wave kernel
     monkeypatch.setenv("RS_NO_WG", "1")
-    ref = be.bootstrap(d, mu)
+    be2 = _backend(ks, "default128" if ks.p.bk_l == 3 else "redsec_small_v2")
     monkeypatch.delenv("RS_NO_WG")
+    be2.set_mode(be.mode())
+    ref = be2.bootstrap(d, mu)
+    assert be2.last_launch()["form"] == "per_wave"
     assert torch.equal(got, ref)
+    _BACKENDS.remove(be2)
+    be2.close()
     sample = np.r_[0:8, B - 11:B]
     assert np.array_equal(got.cpu().numpy()[sample], ctx.bootstrap_batch(ct[sample], mu))
 
 
 def test_host_calls_are_certified_without_fallbacks(be_toy_default, toy_default, arith_mode):
-    """rs_gate / rs_bootstrap with host pointers certify each FFT-mode call (include/redsec_hip.h
-    RS_CERTIFICATE_LIMIT) and keep the context's running maximum intact; no call needs the exact fallback."""
+    """Every FFT-mode call records its rounding certificate and folds it into the stream's running maximum
+    (include/redsec_hip.h RS_CERTIFICATE_LIMIT); no call needs the exact recomputation."""
     be = be_toy_default
     ks, ctx = toy_default
     _, ca = _bits(ks, 9, 1)
@@ -277,7 +285,7 @@ def test_host_calls_are_certified_without_fallbacks(be_toy_default, toy_default,
     assert np.array_equal(got, ctx.gate_batch("XOR", ca, cb))
     first = be.rounding_certificate(reset=False)
     be.gate_host("AND", ca, cb)
-    assert be.rounding_certificate(reset=False) >= first          # running maximum survives the per-call reset
+    assert be.rounding_certificate(reset=False) >= first          # a running maximum
     assert (first > 0) == (arith_mode == "fft") and first < 0.25
     assert be.fft_fallbacks() == 0
 
@@ -396,3 +404,60 @@ def test_output_noise_matches_cggi_theory(be_full_default, full_default):
     measured = np.sqrt(np.mean(err ** 2))
     assert 0.5 * theory < measured < 2.0 * theory, (measured, theory)
     assert abs(err.mean()) < 2.0 * theory
+
+
+def test_bench_batch_65536_default128_nands(be_full_default, full_default, arith_mode):
+    """BASELINE configs[1] at its full size inside the test suite: 65,536 independent default-128 NANDs. Every output
+    decrypts to NAND(a, b); the whole batch is identical in the other arithmetic mode, compared on the device; and
+    256 gates drawn from the first, middle and last workgroups of the launch equal the oracle word for word."""
+    import torch
+    be = be_full_default
+    ks, ctx = full_default
+    B = 65536
+    rng = np.random.default_rng(0xC0FFEE)
+    e8 = ol.to_torus(1, 8)
+    ba, bb = rng.integers(0, 2, B), rng.integers(0, 2, B)
+    # fresh encryptions, vectorised (oracle_lib.KeySet.encrypt is a per-sample loop): a uniform, b = a.s + mu + e
+    def enc(bits, seed):
+        r = np.random.default_rng(seed)
+        a = r.integers(-2**31, 2**31, (B, ks.p.n)).astype(np.int32)
+        e = np.round(r.normal(0.0, ALPHA, B) * 2.0**32).astype(np.int64)
+        dot = (a.astype(np.int64) * ks.lwe_key.astype(np.int64)).sum(axis=1)
+        b = (dot + np.where(bits == 1, e8, -e8) + e) & 0xFFFFFFFF
+        return np.concatenate([a, b.astype(np.uint32).view(np.int32)[:, None]], axis=1)
+    ca, cb = enc(ba, 1), enc(bb, 2)
+    da, db = _dev(ca), _dev(cb)
+    out = be.gate("NAND", da, db)
+    if arith_mode == "fft":
+        assert be.last_launch() == {"form": "workgroup", "waves_per_block": 8, "resident": 8 * be.info()["num_cus"]}
+    other = "exact" if arith_mode == "fft" else "fft"
+    be.set_mode(other)
+    assert torch.equal(be.gate("NAND", da, db), out)
+    be.set_mode(arith_mode)
+    got = out.cpu().numpy()
+    phase = (got[:, -1].astype(np.int64) - (got[:, :-1].astype(np.int64) * ks.lwe_key.astype(np.int64)).sum(axis=1)) & 0xFFFFFFFF
+    assert np.array_equal((phase < (1 << 31)).astype(int), 1 - (ba & bb))
+    sample = np.r_[0:86, B // 2 - 42:B // 2 + 43, B - 85:B]
+    assert len(sample) == 256
+    assert np.array_equal(got[sample], ctx.gate_batch("NAND", ca[sample], cb[sample]))
+    assert be.fft_fallbacks() == 0
+
+
+@pytest.mark.parametrize("which,fix,form", [("be_full_default", "full_default", "workgroup"), ("be_full_redsec", "full_redsec", "workgroup"),
+                                            ("be_full_redsec", "full_redsec", "duo")])
+def test_workgroup_and_duo_kernels_on_full_keys_against_oracle(which, fix, form, request, arith_mode):
+    """The throughput forms against the ORACLE on the real parameter sets (n = 630 / n = 350), not only on toy keys:
+    a batch large enough to select the form, 32 sampled ciphertexts (first, middle and last groups, incl. the ragged one)."""
+    be = request.getfixturevalue(which)
+    ks, ctx = request.getfixturevalue(fix)
+    cus = be.info()["num_cus"]
+    B = 8 * cus + 5 if form == "workgroup" else 4 * cus + 2
+    rng = np.random.default_rng(31)
+    mu = ol.to_torus(1, 4096)
+    sample = np.r_[0:11, B // 2:B // 2 + 10, B - 11:B]
+    ct = rng.integers(-2**31, 2**31, (B, ks.p.n + 1)).astype(np.int32)       # arbitrary words: the kernel is a function of them
+    ct[sample] = ks.encrypt(rng.integers(-2**31, 2**31, len(sample)), ALPHA, 3)
+    got = be.bootstrap(_dev(ct), mu)
+    if arith_mode == "fft":
+        assert be.last_launch()["form"] == form
+    assert np.array_equal(got.cpu().numpy()[sample], ctx.bootstrap_batch(ct[sample], mu))

@@ -62,3 +62,92 @@ def test_sharded_stage_equals_unsharded_gloo(total):
         p.join(120)
         assert p.exitcode == 0
     assert ret.get(timeout=5) == 1
+
+
+def _pipe_worker(rank, world, port, rows, W, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pipe = sharding.OverlappedGather(rows, W, torch.int32, "cpu")
+        ok = True
+        pending = []
+        for k in range(4):                                   # bench.py's loop: two buffers alternate
+            if len(pending) >= 2:
+                pipe.wait(pending[-2][0])
+            local = torch.full((rows, W), 100 * k + rank, dtype=torch.int32)
+            pending.append(pipe.launch(local))
+        for k, (h, full) in enumerate(pending[-2:], start=2):
+            pipe.wait(h)
+            want = torch.cat([torch.full((rows, W), 100 * k + r, dtype=torch.int32) for r in range(world)])
+            ok = ok and torch.equal(full, want)
+        flag = torch.tensor([1 if ok else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            ret.put(int(flag.item()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_gather_pipeline_gloo():
+    """The collective of bench.py --gpus N (sharding.OverlappedGather) on two gloo ranks."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, 2, port, 5, 7, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) == 1
+
+
+def _gpu_stage_worker(rank, world, port, ret):
+    """Two ranks sharing device 0 (gloo: RCCL refuses two ranks on one device) shard a REAL bootstrap stage."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+        import redsec_amd
+        from redsec_amd import client
+        sk = client.SecretKeySet("redsec_small_v2", seed=3, n=24)            # same key on both ranks (seeded)
+        be = redsec_amd.Backend(redsec_amd.params("redsec_small_v2", n=24), 0)
+        be.load_keys(sk.bk, sk.ksk)
+        B = 37                                                              # ragged split: 19 + 18
+        ct = torch.from_numpy(sk.encrypt_torus(np.arange(B) * (1 << 24) - (1 << 28), seed=5)).cuda()
+        mu = 1 << 20
+        whole = be.bootstrap(ct, mu)
+        got = sharding.sharded_stage(lambda rows: be.bootstrap(rows, mu), ct)
+        ok = torch.equal(got, whole)
+        lo, hi = sharding.shard_range(B, rank, world)
+        pipe = sharding.OverlappedGather(19, be.W, torch.int32, "cuda:0")    # equal blocks: pad the shorter slice
+        block = torch.zeros((19, be.W), dtype=torch.int32, device="cuda")
+        block[: hi - lo] = be.bootstrap(ct[lo:hi].contiguous(), mu)
+        h, full = pipe.launch(block)
+        pipe.wait(h)
+        full = full.reshape(world, 19, be.W)
+        ok = ok and torch.equal(torch.cat([full[0, :19], full[1, :18]]).cuda(), whole)
+        flag = torch.tensor([1 if ok else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            ret.put(int(flag.item()))
+        be.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_bootstrap_stage_two_ranks_one_device():
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_stage_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) == 1
