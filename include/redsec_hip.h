@@ -121,13 +121,14 @@ int rs_reserve_stream(rs_ctx* ctx, size_t max_batch, void* stream);
 int rs_bootstrap_dev(rs_ctx* ctx, int32_t* out, const int32_t* in, int32_t mu, size_t B, void* stream);
 int rs_bootstrap(rs_ctx* ctx, int32_t* out, const int32_t* in, int32_t mu, size_t B);
 
-/* Programmable bootstrap: tfhe_blindRotateAndExtract_FFT with the test polynomial lut[b % lut_count]
- * (DEVICE int32[lut_count][N]) followed by lweKeySwitch. With pbar = the phase of in[b] mod-switched to
+/* Programmable bootstrap: tfhe_blindRotateAndExtract_FFT with the test polynomial lut[(lut_first + b) % lut_count]
+ * (DEVICE int32[lut_count][N]; lut_first lets a caller that shards a batch keep the batch-wide assignment)
+ * followed by lweKeySwitch. With pbar = the phase of in[b] mod-switched to
  * [0, 2N): out[b] encrypts lut[pbar] for pbar < N and -lut[pbar - N] beyond. Serves the corrected
  * Quantize::relu_shift (lib/IntFunc.cpp:934-973, lib/BinFunc.cpp:1120-1162): one bootstrap per neuron
  * evaluates clamp((slope x + bias) >> slope_bits, 0, 2^shift_bits - 1), see DESIGN.md "ReLU semantics". */
-int rs_bootstrap_lut_dev(rs_ctx* ctx, int32_t* out, const int32_t* in, const int32_t* lut, size_t lut_count, size_t B,
-                         void* stream);
+int rs_bootstrap_lut_dev(rs_ctx* ctx, int32_t* out, const int32_t* in, const int32_t* lut, size_t lut_count, size_t lut_first,
+                         size_t B, void* stream);
 
 /* out[b] = boots<OP>(a[b], b[b]) (mu = 1/8 encoding). */
 int rs_gate_dev(rs_ctx* ctx, rs_gate_op op, int32_t* out, const int32_t* a, const int32_t* b, size_t B, void* stream);
@@ -197,6 +198,9 @@ int rs_dev_alloc(rs_ctx* ctx, void** ptr, size_t bytes);
 int rs_dev_free(rs_ctx* ctx, void* ptr);
 int rs_copy_to_dev(rs_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int rs_copy_to_host(rs_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* Device-to-device copy between the devices of two contexts (the same device is fine): the slice exchange of a
+ * stage sharded over several GPUs of one process. Synchronous. */
+int rs_copy_dev_to_dev(rs_ctx* dst_ctx, void* dst_dev, rs_ctx* src_ctx, const void* src_dev, size_t bytes);
 int rs_sync(rs_ctx* ctx);
 
 /* Time (ms) of the kernels enqueued by the last *_dev / host call, by HIP events on the stream the

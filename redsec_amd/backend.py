@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "rs_gate_mu_dev", "rs_gather_rows_dev", "rs_bootstrap_wo_ks_dev", "rs_keyswitch_dev", "rs_debug_polymul", "rs_linear_fc_dev", "rs_conv_ternary_dev",
     "rs_sumpool_dev", "rs_lincomb_dev", "rs_dev_alloc", "rs_dev_free", "rs_copy_to_dev", "rs_copy_to_host", "rs_sync",
     "rs_set_timing", "rs_last_kernel_ms", "rs_info", "rs_set_mode", "rs_get_mode", "rs_rounding_certificate", "rs_fft_fallbacks",
-    "rs_bootstrap_lut_dev", "rs_set_certificate_limit", "rs_certify", "rs_reserve_stream", "rs_last_kernel_ms_stream", "rs_last_launch",
+    "rs_bootstrap_lut_dev", "rs_set_certificate_limit", "rs_certify", "rs_reserve_stream", "rs_last_kernel_ms_stream", "rs_last_launch", "rs_copy_dev_to_dev",
 ]
 
 GATES = {"NAND": 0, "OR": 1, "AND": 2, "NOR": 3, "XOR": 4, "XNOR": 5, "ANDNY": 6, "ANDYN": 7, "ORNY": 8, "ORYN": 9}
@@ -99,7 +99,8 @@ def load_library(path=None):
     L.rs_get_mode.argtypes = [vp, C.POINTER(C.c_int)]
     L.rs_rounding_certificate.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
     L.rs_fft_fallbacks.argtypes = [vp, C.POINTER(C.c_int64)]
-    L.rs_bootstrap_lut_dev.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_size_t, vp]
+    L.rs_bootstrap_lut_dev.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp]
+    L.rs_copy_dev_to_dev.argtypes = [vp, vp, vp, vp, C.c_size_t]
     L.rs_set_certificate_limit.argtypes = [vp, C.c_double]
     L.rs_certify.argtypes = [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
     L.rs_reserve_stream.argtypes = [vp, C.c_size_t, vp]
@@ -197,12 +198,12 @@ class Backend:
         _check(self.L, self.L.rs_bootstrap_dev(self.h, self._ck_dev(out, self.W), self._ck_dev(x, self.W), int(mu), B, self._stream()))
         return out
 
-    def bootstrap_lut(self, x, lut, out=None):
-        """Programmable bootstrap: ciphertext b uses the test polynomial lut[b % len(lut)] (int32 CUDA [L][N])."""
+    def bootstrap_lut(self, x, lut, out=None, first=0):
+        """Programmable bootstrap: ciphertext b uses the test polynomial lut[(first + b) % len(lut)] (int32 CUDA [L][N])."""
         B = x.shape[0]
         out = self.empty(B, self.W) if out is None else out
         _check(self.L, self.L.rs_bootstrap_lut_dev(self.h, self._ck_dev(out, self.W), self._ck_dev(x, self.W),
-                                                    self._ck_dev(lut, self.p.N), lut.shape[0], B, self._stream()))
+                                                    self._ck_dev(lut, self.p.N), lut.shape[0], int(first), B, self._stream()))
         return out
 
     def gate(self, op, a, b, out=None):

@@ -180,7 +180,9 @@ int ready(rs_ctx* c) {
 
 struct Combo { const int32_t* in0; const int32_t* in1; int32_t c0, c1, bconst; int32_t* u; };
 
-rs::BlindRotateArgs br_args(rs_ctx* c, Lane* ln, int mode, const Combo& x, int32_t mu, const int32_t* lut, size_t lut_count, size_t B) {
+struct Lut { const int32_t* table = nullptr; size_t count = 0, first = 0; };
+
+rs::BlindRotateArgs br_args(rs_ctx* c, Lane* ln, int mode, const Combo& x, int32_t mu, const Lut& lut, size_t B) {
   rs::BlindRotateArgs a;
   a.in0 = x.in0; a.in1 = x.in1; a.c0 = x.c0; a.c1 = x.c1; a.bconst = x.bconst; a.mu = mu;
   a.bk_x = mode == 1 ? c->d_bk_fft : c->d_bk_ntt;
@@ -189,7 +191,7 @@ rs::BlindRotateArgs br_args(rs_ctx* c, Lane* ln, int mode, const Combo& x, int32
   a.n = c->p.n; a.W = c->p.n + 1; a.B = (long)B; a.u_out = x.u;
   a.counter = ln->d_counter;
   a.dev_flag = nullptr;
-  a.lut = lut; a.lut_count = (int32_t)lut_count;
+  a.lut = lut.table; a.lut_count = (int32_t)lut.count; a.lut_first = (int32_t)lut.first;
   return a;
 }
 
@@ -202,7 +204,7 @@ rs::BlindRotateArgs br_args(rs_ctx* c, Lane* ln, int mode, const Combo& x, int32
 //               the guaranteed-exact result before the keyswitch reads them. No host round trip, stream-ordered,
 //               so every *_dev result is exact (= RS_MODE_EXACT_NTT = the CPU oracle) by construction.
 int run_bootstrap(rs_ctx* c, hipStream_t st, int32_t* out, const Combo* combos, int count, int32_t ks_bconst, int32_t mu,
-                  const int32_t* lut, size_t lut_count, size_t B) {
+                  const Lut& lut, size_t B) {
   Lane* ln = nullptr;
   int rc = lane_of(c, st, &ln);
   if (rc) return rc;
@@ -217,7 +219,7 @@ int run_bootstrap(rs_ctx* c, hipStream_t st, int32_t* out, const Combo* combos, 
     unsigned long long* slot = ln->d_cert + (ln->slot_next++ % kCertSlots);
     RS_HIP(hipMemsetAsync(slot, 0, sizeof *slot, st));
     for (int k = 0; k < count; ++k) {
-      rs::BlindRotateArgs a = br_args(c, ln, 1, cs[k], mu, lut, lut_count, B);
+      rs::BlindRotateArgs a = br_args(c, ln, 1, cs[k], mu, lut, B);
       a.dev_flag = slot;
       RS_HIP(rs::launch_blind_rotate(c->cfg, 1, a, wpb, c->num_cus, c->opts, st, &ln->last));
     }
@@ -225,7 +227,7 @@ int run_bootstrap(rs_ctx* c, hipStream_t st, int32_t* out, const Combo* combos, 
     const double lim = c->cert_limit;
     memcpy(&limit_bits, &lim, sizeof limit_bits);
     for (int k = 0; k < count; ++k) {
-      rs::BlindRotateArgs a = br_args(c, ln, 0, cs[k], mu, lut, lut_count, B);
+      rs::BlindRotateArgs a = br_args(c, ln, 0, cs[k], mu, lut, B);
       a.gate_flag = slot; a.gate_limit_bits = limit_bits;
       a.running_flag = k == 0 ? ln->d_cert + kCertSlots : nullptr;
       a.fallback_count = k == 0 ? ln->d_cert + kCertSlots + 1 : nullptr;
@@ -233,7 +235,7 @@ int run_bootstrap(rs_ctx* c, hipStream_t st, int32_t* out, const Combo* combos, 
     }
   } else {
     for (int k = 0; k < count; ++k)
-      RS_HIP(rs::launch_blind_rotate(c->cfg, 0, br_args(c, ln, 0, cs[k], mu, lut, lut_count, B), wpb, c->num_cus, c->opts, st, &ln->last));
+      RS_HIP(rs::launch_blind_rotate(c->cfg, 0, br_args(c, ln, 0, cs[k], mu, lut, B), wpb, c->num_cus, c->opts, st, &ln->last));
   }
   if (c->timing) RS_HIP(hipEventRecord(ln->ev[1], st));
   if (out) {
@@ -380,17 +382,20 @@ int rs_bootstrap_dev(rs_ctx* c, int32_t* out, const int32_t* in, int32_t mu, siz
   if (B == 0) return RS_OK;
   if (!out || !in) return fail(RS_ERR_INVALID, "null ciphertext pointer");
   const Combo x{in, nullptr, 1, 0, 0, nullptr};
-  return run_bootstrap(c, (hipStream_t)stream, out, &x, 1, 0, mu, nullptr, 0, B);
+  return run_bootstrap(c, (hipStream_t)stream, out, &x, 1, 0, mu, Lut{}, B);
 }
 
-int rs_bootstrap_lut_dev(rs_ctx* c, int32_t* out, const int32_t* in, const int32_t* lut, size_t lut_count, size_t B, void* stream) {
+int rs_bootstrap_lut_dev(rs_ctx* c, int32_t* out, const int32_t* in, const int32_t* lut, size_t lut_count, size_t lut_first, size_t B,
+                         void* stream) {
   int rc = ready(c);
   if (rc) return rc;
   if (B == 0) return RS_OK;
   if (!out || !in || !lut) return fail(RS_ERR_INVALID, "null pointer");
   if (lut_count < 1 || lut_count > 0x7fffffffu) return fail(RS_ERR_INVALID, "lut_count must be >= 1");
   const Combo x{in, nullptr, 1, 0, 0, nullptr};
-  return run_bootstrap(c, (hipStream_t)stream, out, &x, 1, 0, 0, lut, lut_count, B);
+  Lut l;
+  l.table = lut; l.count = lut_count; l.first = lut_first % lut_count;
+  return run_bootstrap(c, (hipStream_t)stream, out, &x, 1, 0, 0, l, B);
 }
 
 int rs_gate_mu_dev(rs_ctx* c, rs_gate_op op, int32_t* out, const int32_t* a, const int32_t* b, int32_t mu, size_t B, void* stream) {
@@ -401,7 +406,7 @@ int rs_gate_mu_dev(rs_ctx* c, rs_gate_op op, int32_t* out, const int32_t* a, con
   if (B == 0) return RS_OK;
   if (!out || !a || !b) return fail(RS_ERR_INVALID, "null ciphertext pointer");
   const Combo x{a, b, g.sa, g.sb, g.bconst, nullptr};
-  return run_bootstrap(c, (hipStream_t)stream, out, &x, 1, 0, mu, nullptr, 0, B);
+  return run_bootstrap(c, (hipStream_t)stream, out, &x, 1, 0, mu, Lut{}, B);
 }
 
 int rs_gate_dev(rs_ctx* c, rs_gate_op op, int32_t* out, const int32_t* a, const int32_t* b, size_t B, void* stream) {
@@ -425,7 +430,7 @@ int rs_mux_dev(rs_ctx* c, int32_t* out, const int32_t* a, const int32_t* b, cons
   const int32_t e8 = 1 << 29;
   // u1 = woKS(AND(a,b)), u2 = woKS(ANDNY(a,c)); out = KS((0,1/8) + u1 + u2)
   const Combo xs[2] = {{a, b, 1, 1, -e8, nullptr}, {a, cc, -1, 1, -e8, nullptr}};
-  return run_bootstrap(c, (hipStream_t)stream, out, xs, 2, e8, e8, nullptr, 0, B);
+  return run_bootstrap(c, (hipStream_t)stream, out, xs, 2, e8, e8, Lut{}, B);
 }
 
 int rs_bootstrap_wo_ks_dev(rs_ctx* c, int32_t* u, const int32_t* in, int32_t mu, size_t B, void* stream) {
@@ -436,7 +441,7 @@ int rs_bootstrap_wo_ks_dev(rs_ctx* c, int32_t* u, const int32_t* in, int32_t mu,
   // rotate into the lane workspace (so that the gated exact recomputation applies), then hand the samples over
   const Combo x{in, nullptr, 1, 0, 0, nullptr};
   hipStream_t st = (hipStream_t)stream;
-  rc = run_bootstrap(c, st, nullptr, &x, 1, 0, mu, nullptr, 0, B);
+  rc = run_bootstrap(c, st, nullptr, &x, 1, 0, mu, Lut{}, B);
   if (rc) return rc;
   Lane* ln = nullptr;
   rc = lane_of(c, st, &ln);
@@ -701,6 +706,15 @@ int rs_copy_to_host(rs_ctx* c, void* dst, const void* src, size_t bytes) {
   int rc = use_device(c);
   if (rc) return rc;
   RS_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return RS_OK;
+}
+int rs_copy_dev_to_dev(rs_ctx* dc, void* dst, rs_ctx* sc, const void* src, size_t bytes) {
+  if (!dc || !sc) return fail(RS_ERR_INVALID, "null context");
+  if (bytes == 0) return RS_OK;
+  if (!dst || !src) return fail(RS_ERR_INVALID, "null pointer");
+  RS_HIP(hipSetDevice(dc->device));
+  if (dc->device == sc->device) RS_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
+  else RS_HIP(hipMemcpyPeer(dst, dc->device, src, sc->device, bytes));   // staged through the host where peer access is off
   return RS_OK;
 }
 int rs_sync(rs_ctx* c) {

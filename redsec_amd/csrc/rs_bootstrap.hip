@@ -239,7 +239,7 @@ __device__ __forceinline__ void publish_certificate(double dev, unsigned long lo
 // the programmable form, the ciphertext's own polynomial lut[ct % lut_count] (tfhe_blindRotateAndExtract_FFT).
 __device__ __forceinline__ int32_t test_vector(const BlindRotateArgs& a, long ct, int j, int rot) {
   if (!a.lut) return rotated_const(a.mu, j, rot);
-  const int32_t* v = a.lut + (size_t)(ct % a.lut_count) * kN;
+  const int32_t* v = a.lut + (size_t)((ct + a.lut_first) % a.lut_count) * kN;
   const int aa = rot & (kN - 1), nb = (rot >> 10) & 1;
   const uint32_t x = (uint32_t)v[(j - aa) & (kN - 1)];
   return (int32_t)((((j < aa) ? 1 : 0) ^ nb) ? 0u - x : x);

@@ -29,6 +29,7 @@ struct BlindRotateArgs {
   // lut[(b % lut_count)][N] instead of the constant mu. nullptr = constant test vector.
   const int32_t* lut = nullptr;
   int32_t lut_count = 0;
+  int32_t lut_first = 0;   // table of ciphertext 0 (a caller's shard offset modulo lut_count)
   // Conditional exact recomputation (exact-NTT kernels launched behind an FFT call): the grid reads the
   // FFT call's certificate slot and returns at once unless it reached `gate_limit_bits`; either way it folds
   // the slot into the stream's running maximum and counts the recomputed calls.

@@ -15,6 +15,7 @@
 // (include/redsec_hip.h) on device-resident ciphertext slabs int32[count][n+1]. A layer's output is
 // also kept on the device and keyed by the host pointer it returns, so the next layer's execute()
 // finds its input already in HBM; only the image goes up and the logits come down.
+#include <algorithm>
 #include <cassert>
 #include <cmath>
 #include <cstdio>
@@ -245,12 +246,15 @@ namespace redsec_host {
     if ((call) != 0) { fprintf(stderr, "redsec layers: %s: %s\n", #call, rs_last_error()); abort(); } \
   } while (0)
 
+// A ciphertext array on the device(s): one full replica int32[rows][W] per context of the fleet (one context =
+// one GPU; a single GPU unless REDSEC_DEVICES lists several).
 struct DevSlab {
-  int32_t* ptr = nullptr;
+  std::vector<int32_t*> ptr;     // [device]
+  std::vector<rs_ctx*> ctx;      // [device]
   size_t rows = 0;
-  rs_ctx* ctx = nullptr;
   uint64_t tag = 0;   // fingerprint of the host copy handed out with it
   uint64_t seq = 0;   // publication order
+  void release() { for (size_t d = 0; d < ptr.size(); ++d) if (ptr[d]) (void)rs_dev_free(ctx[d], ptr[d]); ptr.clear(); ctx.clear(); }
 };
 
 // Device copies of the ciphertext arrays handed back to the caller, keyed by host pointer. A slab is
@@ -291,7 +295,7 @@ void remember(const void* host, DevSlab s) {
       g_resident.erase(oldest);
     }
   }
-  for (const DevSlab& e : evicted) (void)rs_dev_free(e.ctx, e.ptr);
+  for (DevSlab& e : evicted) e.release();
 }
 bool is_resident(const void* host) {
   std::lock_guard<std::mutex> g(g_lock);
@@ -338,14 +342,13 @@ struct LayerImpl {
   std::vector<int32_t> bias;          // torus words (b of the trivial bias samples)
   std::vector<int32_t> pool_index;    // max-pool taps: [tap][out] row indices, -1 = outside
   int pool_taps = 0;
-  // device copies
-  uint8_t *d_sign = nullptr, *d_zero = nullptr;
-  int32_t *d_bias = nullptr, *d_pool_index = nullptr;
+  // device copies, one set per device of the fleet
+  struct DevWeights { uint8_t *sign = nullptr, *zero = nullptr; int32_t *bias = nullptr, *pool_index = nullptr, *pool_bias = nullptr, *lut = nullptr; };
+  std::vector<DevWeights> dw;
   // fused max-pool (every window inside the image): the window's w sign bits are emitted as +-pool_mu =
   // +-1/(4w), summed, and ONE bootstrap of  sum + (w-1)/(4w)  is their OR (d_pool_bias holds that constant)
   bool pool_fused = false;
   int32_t pool_mu = 0;
-  int32_t* d_pool_bias = nullptr;
   // Encoding: torus32 value of ONE integer step of this layer's input / output (1/4096 = 2^20 for client
   // pixels and sign bits, 1/16384 = 2^18 for ReLU outputs; DESIGN.md "ReLU semantics")
   int32_t unit_in = kUnit4096, unit_out = kUnit4096;
@@ -356,9 +359,8 @@ struct LayerImpl {
   // ReLU (Quantize::relu_shift): slope per channel, shift amount, and the test polynomials [depth][N]
   std::vector<int32_t> slope, raw_bias;
   int shift_bits = 0, relu_shift = 0;
-  int32_t* d_lut = nullptr;
 
-  rs_ctx* ctx() const { return redsec_ctx_of(bk); }
+  rs_ctx** fleet(int* count) const { return redsec_fleet_of(bk, count); }
   int W() const { return bk->params->in_out_params->n + 1; }
 };
 
@@ -547,38 +549,43 @@ std::vector<int32_t> relu_luts(const LayerImpl* L) {
   return lut;
 }
 
+template <class T>
+T* to_device(rs_ctx* c, const std::vector<T>& host) {
+  T* p = nullptr;
+  RS_CHECK(rs_dev_alloc(c, (void**)&p, host.size() * sizeof(T)));
+  RS_CHECK(rs_copy_to_dev(c, p, host.data(), host.size() * sizeof(T)));
+  return p;
+}
+
 void upload_weights(LayerImpl* L) {
-  if (L->d_bias) return;
-  rs_ctx* c = L->ctx();
-  if (!L->sign.empty()) {
-    RS_CHECK(rs_dev_alloc(c, (void**)&L->d_sign, L->sign.size()));
-    RS_CHECK(rs_dev_alloc(c, (void**)&L->d_zero, L->zero.size()));
-    RS_CHECK(rs_copy_to_dev(c, L->d_sign, L->sign.data(), L->sign.size()));
-    RS_CHECK(rs_copy_to_dev(c, L->d_zero, L->zero.data(), L->zero.size()));
-  }
+  if (!L->dw.empty()) return;
+  int D = 0;
+  rs_ctx** fleet = L->fleet(&D);
+  std::vector<int32_t> lut, pool_bias;
   if (L->e_act == E_ACTIVATION_RELU) {
     // the bias lives inside the test polynomial; what joins the linear stage is the quarter turn that moves
     // pre in [-N/2, N/2) steps onto [0, 1/2), and the -1 per negative tap of the plaintext branch
     for (size_t i = 0; i < L->bias.size(); ++i) L->bias[i] = (int32_t)((uint32_t)kQuarter - (uint32_t)neg_fold(L, i) * (uint32_t)L->unit_in);
-    const std::vector<int32_t> lut = relu_luts(L);
-    RS_CHECK(rs_dev_alloc(c, (void**)&L->d_lut, lut.size() * 4));
-    RS_CHECK(rs_copy_to_dev(c, L->d_lut, lut.data(), lut.size() * 4));
+    lut = relu_luts(L);
   }
-  RS_CHECK(rs_dev_alloc(c, (void**)&L->d_bias, L->bias.size() * 4));
-  RS_CHECK(rs_copy_to_dev(c, L->d_bias, L->bias.data(), L->bias.size() * 4));
   if (!L->pool_index.empty()) {
-    RS_CHECK(rs_dev_alloc(c, (void**)&L->d_pool_index, L->pool_index.size() * 4));
-    RS_CHECK(rs_copy_to_dev(c, L->d_pool_index, L->pool_index.data(), L->pool_index.size() * 4));
     bool full = L->pool_taps >= 2;
     for (int32_t v : L->pool_index) full = full && v >= 0;
     const char* mode = getenv("REDSEC_MAXPOOL");          // "chain" selects the OR chain of BinOps::max calls
     L->pool_fused = full && !(mode && strcmp(mode, "chain") == 0);
     if (L->pool_fused) {
       L->pool_mu = (int32_t)((1ull << 32) / (4ull * (unsigned)L->pool_taps));
-      const int32_t b = (int32_t)((uint32_t)(L->pool_taps - 1) * (uint32_t)L->pool_mu);
-      RS_CHECK(rs_dev_alloc(c, (void**)&L->d_pool_bias, 4));
-      RS_CHECK(rs_copy_to_dev(c, L->d_pool_bias, &b, 4));
+      pool_bias.push_back((int32_t)((uint32_t)(L->pool_taps - 1) * (uint32_t)L->pool_mu));
     }
+  }
+  L->dw.resize((size_t)D);
+  for (int d = 0; d < D; ++d) {
+    LayerImpl::DevWeights& w = L->dw[d];
+    if (!L->sign.empty()) { w.sign = to_device(fleet[d], L->sign); w.zero = to_device(fleet[d], L->zero); }
+    w.bias = to_device(fleet[d], L->bias);
+    if (!lut.empty()) w.lut = to_device(fleet[d], lut);
+    if (!L->pool_index.empty()) w.pool_index = to_device(fleet[d], L->pool_index);
+    if (!pool_bias.empty()) w.pool_bias = to_device(fleet[d], pool_bias);
   }
 }
 
@@ -588,111 +595,168 @@ int32_t* dev_rows(rs_ctx* c, size_t rows, int W) {
   return p;
 }
 
-// One layer on the device: x is the input slab (consumed), returns the output slab.
+// contiguous, balanced slice of `total` rows for device d of D (sizes differ by at most one; the same split as
+// redsec_amd/sharding.py::shard_range)
+void shard_range(size_t total, int d, int D, size_t* lo, size_t* hi) {
+  const size_t base = total / (size_t)D, rem = total % (size_t)D;
+  *lo = (size_t)d * base + ((size_t)d < rem ? (size_t)d : rem);
+  *hi = *lo + base + ((size_t)d < rem ? 1 : 0);
+}
+
+// The devices a layer runs on, and the two ways a stage uses them.
+struct Fleet {
+  rs_ctx** c;
+  int D;
+  int W;
+  // the same launch on every device, each on its own full replica (linear stages: every device needs the whole
+  // input of the next bootstrap stage, and recomputing < 2 % of a layer beats exchanging it)
+  template <class F>
+  std::vector<int32_t*> replicated(size_t rows, F launch) const {
+    std::vector<int32_t*> y((size_t)D);
+    for (int d = 0; d < D; ++d) { y[d] = dev_rows(c[d], rows, W); launch(d, c[d], y[d]); }
+    for (int d = 0; d < D; ++d) RS_CHECK(rs_sync(c[d]));
+    return y;
+  }
+  // a stage of independent ciphertexts (every bootstrap: lib/BinFunc.cpp:1056-1071 has no cross-iteration dependence):
+  // device d computes its contiguous slice into its own replica, then every device pulls the other slices, so that the
+  // next linear stage finds the whole vector everywhere. One device: no exchange at all.
+  template <class F>
+  std::vector<int32_t*> sharded(size_t rows, F launch) const {
+    std::vector<int32_t*> y((size_t)D);
+    for (int d = 0; d < D; ++d) {
+      y[d] = dev_rows(c[d], rows, W);
+      size_t lo, hi;
+      shard_range(rows, d, D, &lo, &hi);
+      if (hi > lo) launch(d, c[d], y[d] + lo * (size_t)W, lo, hi - lo);
+    }
+    for (int d = 0; d < D; ++d) RS_CHECK(rs_sync(c[d]));
+    for (int d = 0; d < D; ++d)
+      for (int e = 0; e < D; ++e) {
+        if (e == d) continue;
+        size_t lo, hi;
+        shard_range(rows, e, D, &lo, &hi);
+        RS_CHECK(rs_copy_dev_to_dev(c[d], y[d] + lo * (size_t)W, c[e], y[e] + lo * (size_t)W, (hi - lo) * (size_t)W * 4));
+      }
+    return y;
+  }
+  void release(std::vector<int32_t*>& v) const {
+    for (int d = 0; d < D; ++d) if (v[d]) RS_CHECK(rs_dev_free(c[d], v[d]));
+    v.clear();
+  }
+};
+
+// One layer on the device(s): x is the input slab (consumed), returns the output slab.
 DevSlab run_layer(LayerImpl* L, DevSlab x) {
-  rs_ctx* c = L->ctx();
-  const int W = L->W();
+  Fleet f{nullptr, 0, L->W()};
+  f.c = L->fleet(&f.D);
   const int32_t mu4096 = modSwitchToTorus32(1, 4096), mu8 = modSwitchToTorus32(1, 8);
   upload_weights(L);
+  const std::vector<LayerImpl::DevWeights>& dw = L->dw;
   const bool pool_sum = L->e_pool == E_SUMPOOL;
+  auto replace = [&](std::vector<int32_t*> y, size_t rows) { f.release(x.ptr); x.ptr = std::move(y); x.rows = rows; };
   // IntFunc constants: ternary-zero and padding taps contribute the trivial -1/4096 (IntFunc.cpp:268,277)
   // (REDSEC_INTCONV=enc; the default follows the plaintext branch, whose constant is folded into the bias:
   // the two disagree and only the plaintext one matches the trained biases, DESIGN.md "ReLU semantics")
   const int32_t tap_const = (L->is_int && !L->int_conv_plain) ? -mu4096 : 0;
   if (L->e_conv != E_NO_CONV) {
     const Geometry& g = L->conv;
-    const int rows = g.Ho * g.Wo * (int)L->depth;
-    int32_t* y = dev_rows(c, (size_t)rows, W);
-    const int32_t* bias = pool_sum ? nullptr : L->d_bias;   // bias joins at the last linear op before the activation
-    if (g.win_h == 1 && g.win_w == 1 && g.H == 1 && g.Wd == 1) {
-      RS_CHECK(rs_linear_fc_dev(c, y, x.ptr, L->d_sign, L->d_zero, g.C, (int32_t)L->depth, tap_const, bias, L->quant_depth, nullptr));
-    } else {
-      rs_conv_shape s{g.H, g.Wd, g.C, (int32_t)L->depth, g.win_h, g.win_w, g.st_h, g.st_w, g.off_h, g.off_w, g.Ho, g.Wo};
-      RS_CHECK(rs_conv_ternary_dev(c, y, x.ptr, L->d_sign, L->d_zero, &s, tap_const, tap_const, bias, L->quant_depth, nullptr));
-    }
-    RS_CHECK(rs_sync(c));
-    RS_CHECK(rs_dev_free(c, x.ptr));
-    x.ptr = y; x.rows = (size_t)rows;
+    const size_t rows = (size_t)g.Ho * g.Wo * L->depth;
+    replace(f.replicated(rows, [&](int d, rs_ctx* c, int32_t* y) {
+      const int32_t* bias = pool_sum ? nullptr : dw[d].bias;   // bias joins at the last linear op before the activation
+      if (g.win_h == 1 && g.win_w == 1 && g.H == 1 && g.Wd == 1) {
+        RS_CHECK(rs_linear_fc_dev(c, y, x.ptr[d], dw[d].sign, dw[d].zero, g.C, (int32_t)L->depth, tap_const, bias, L->quant_depth, nullptr));
+      } else {
+        rs_conv_shape s{g.H, g.Wd, g.C, (int32_t)L->depth, g.win_h, g.win_w, g.st_h, g.st_w, g.off_h, g.off_w, g.Ho, g.Wo};
+        RS_CHECK(rs_conv_ternary_dev(c, y, x.ptr[d], dw[d].sign, dw[d].zero, &s, tap_const, tap_const, bias, L->quant_depth, nullptr));
+      }
+    }), rows);
   }
   if (pool_sum || L->e_conv == E_NO_CONV) {
     // SumPooling::execute; a layer with neither conv nor pooling still needs its bias: 1x1 window
     Geometry g = L->pool;
     if (!pool_sum) { g = Geometry{1, (int)x.rows / L->quant_depth, L->quant_depth, 1, (int)x.rows / L->quant_depth, 1, 1, 1, 1, 0, 0}; }
-    const int rows = g.Ho * g.Wo * g.C;
-    int32_t* y = dev_rows(c, (size_t)rows, W);
-    rs_pool_shape s{g.H, g.Wd, g.C, g.win_h, g.win_w, g.st_h, g.st_w, g.off_h, g.off_w, g.Ho, g.Wo};
-    RS_CHECK(rs_sumpool_dev(c, y, x.ptr, &s, L->d_bias, L->quant_depth, nullptr));
-    RS_CHECK(rs_sync(c));
-    RS_CHECK(rs_dev_free(c, x.ptr));
-    x.ptr = y; x.rows = (size_t)rows;
+    const size_t rows = (size_t)g.Ho * g.Wo * g.C;
+    replace(f.replicated(rows, [&](int d, rs_ctx* c, int32_t* y) {
+      rs_pool_shape s{g.H, g.Wd, g.C, g.win_h, g.win_w, g.st_h, g.st_w, g.off_h, g.off_w, g.Ho, g.Wo};
+      RS_CHECK(rs_sumpool_dev(c, y, x.ptr[d], &s, dw[d].bias, L->quant_depth, nullptr));
+    }), rows);
   }
   assert((int)x.rows == L->quant_count);
   if (L->e_act == E_ACTIVATION_RELU) {
     // Quantize::relu_shift, corrected: ONE programmable bootstrap per neuron evaluates the plaintext
     // branch's staircase (lib/IntFunc.cpp:964-967) on the mod-switched phase of the pre-activation
-    int32_t* y = dev_rows(c, x.rows, W);
-    RS_CHECK(rs_bootstrap_lut_dev(c, y, x.ptr, L->d_lut, (size_t)L->quant_depth, x.rows, nullptr));
-    RS_CHECK(rs_sync(c));
-    RS_CHECK(rs_dev_free(c, x.ptr));
-    x.ptr = y;
+    replace(f.sharded(x.rows, [&](int d, rs_ctx* c, int32_t* y, size_t lo, size_t count) {
+      RS_CHECK(rs_bootstrap_lut_dev(c, y, x.ptr[d] + lo * (size_t)f.W, dw[d].lut, (size_t)L->quant_depth, lo, count, nullptr));
+    }), x.rows);
   }
   if (L->e_act == E_ACTIVATION_SIGN) {
     const bool maxpool = !L->pool_index.empty();
     // Quantize::execute: one sign bootstrap per neuron (BinOps_enc.cpp:182-186). Ahead of a max-pool
     // the bits are emitted as +-1/8 so that the OR gates see the encoding they assume.
-    int32_t* y = dev_rows(c, x.rows, W);
-    RS_CHECK(rs_bootstrap_dev(c, y, x.ptr, !maxpool ? mu4096 : (L->pool_fused ? L->pool_mu : mu8), x.rows, nullptr));
-    RS_CHECK(rs_sync(c));
-    RS_CHECK(rs_dev_free(c, x.ptr));
-    x.ptr = y;
+    const int32_t mu = !maxpool ? mu4096 : (L->pool_fused ? L->pool_mu : mu8);
+    replace(f.sharded(x.rows, [&](int d, rs_ctx* c, int32_t* y, size_t lo, size_t count) {
+      RS_CHECK(rs_bootstrap_dev(c, y, x.ptr[d] + lo * (size_t)f.W, mu, count, nullptr));
+    }), x.rows);
     if (maxpool && L->pool_fused) {
       // OR over a full window of w bits in ONE bootstrap: with the bits at +-1/(4w) the windowed LWE sum
       // plus (w-1)/(4w) is >= +1/(4w) unless every bit is false (then -1/(4w)) and stays below 1/2 - 1/(4w):
       // its sign bootstrap IS the OR, emitted at +-1/4096 for the next linear stage (SURVEY.md hard part 6).
       const Geometry& g = L->pool;
       const size_t out = (size_t)L->out_count;
-      int32_t* z = dev_rows(c, out, W);
-      int32_t* o = dev_rows(c, out, W);
-      rs_pool_shape s{g.H, g.Wd, g.C, g.win_h, g.win_w, g.st_h, g.st_w, 0, 0, g.Ho, g.Wo};
-      RS_CHECK(rs_sumpool_dev(c, z, x.ptr, &s, L->d_pool_bias, 1, nullptr));
-      RS_CHECK(rs_bootstrap_dev(c, o, z, mu4096, out, nullptr));
-      RS_CHECK(rs_sync(c));
-      RS_CHECK(rs_dev_free(c, z)); RS_CHECK(rs_dev_free(c, x.ptr));
-      x.ptr = o; x.rows = out;
+      std::vector<int32_t*> z = f.replicated(out, [&](int d, rs_ctx* c, int32_t* y) {
+        rs_pool_shape s{g.H, g.Wd, g.C, g.win_h, g.win_w, g.st_h, g.st_w, 0, 0, g.Ho, g.Wo};
+        RS_CHECK(rs_sumpool_dev(c, y, x.ptr[d], &s, dw[d].pool_bias, 1, nullptr));
+      });
+      std::vector<int32_t*> o = f.sharded(out, [&](int d, rs_ctx* c, int32_t* y, size_t lo, size_t count) {
+        RS_CHECK(rs_bootstrap_dev(c, y, z[d] + lo * (size_t)f.W, mu4096, count, nullptr));
+      });
+      f.release(z);
+      replace(std::move(o), out);
     } else if (maxpool) {
       // MaxPooling::execute: OR over the window in (fh, fw) order; the first tap is copied (the
       // reference ORs into an uninitialised accumulator, BinFunc.cpp:891,917), the last OR re-encodes
       // to +-1/4096 for the next linear stage.
       const size_t out = (size_t)L->out_count;
-      int32_t* accv = dev_rows(c, out, W);
-      int32_t* tap = dev_rows(c, out, W);
-      int32_t* tmp = dev_rows(c, out, W);
-      RS_CHECK(rs_gather_rows_dev(c, accv, x.ptr, L->d_pool_index, out, nullptr));
+      auto gather = [&](int t) {
+        return f.replicated(out, [&](int d, rs_ctx* c, int32_t* y) {
+          RS_CHECK(rs_gather_rows_dev(c, y, x.ptr[d], dw[d].pool_index + (size_t)t * out, out, nullptr));
+        });
+      };
+      std::vector<int32_t*> accv = gather(0);
       for (int t = 1; t < L->pool_taps; ++t) {
-        RS_CHECK(rs_gather_rows_dev(c, tap, x.ptr, L->d_pool_index + (size_t)t * out, out, nullptr));
+        std::vector<int32_t*> tap = gather(t);
         const bool last = t == L->pool_taps - 1;
         // a tap outside the image gathers the zero sample: OR(acc, 0-phase) keeps acc's sign only if
         // windows are full, which holds for every shipped net (even feature maps, 2x2 windows)
-        RS_CHECK(rs_gate_mu_dev(c, RS_OR, tmp, accv, tap, last ? mu4096 : mu8, out, nullptr));
-        RS_CHECK(rs_sync(c));
-        std::swap(accv, tmp);
+        std::vector<int32_t*> next = f.sharded(out, [&](int d, rs_ctx* c, int32_t* y, size_t lo, size_t count) {
+          RS_CHECK(rs_gate_mu_dev(c, RS_OR, y, accv[d] + lo * (size_t)f.W, tap[d] + lo * (size_t)f.W, last ? mu4096 : mu8, count, nullptr));
+        });
+        f.release(tap);
+        f.release(accv);
+        accv = std::move(next);
       }
-      if (L->pool_taps == 1) { RS_CHECK(rs_bootstrap_dev(c, tmp, accv, mu4096, out, nullptr)); RS_CHECK(rs_sync(c)); std::swap(accv, tmp); }
-      RS_CHECK(rs_dev_free(c, tap)); RS_CHECK(rs_dev_free(c, tmp)); RS_CHECK(rs_dev_free(c, x.ptr));
-      x.ptr = accv; x.rows = out;
+      if (L->pool_taps == 1) {
+        std::vector<int32_t*> next = f.sharded(out, [&](int d, rs_ctx* c, int32_t* y, size_t lo, size_t count) {
+          RS_CHECK(rs_bootstrap_dev(c, y, accv[d] + lo * (size_t)f.W, mu4096, count, nullptr));
+        });
+        f.release(accv);
+        accv = std::move(next);
+      }
+      replace(std::move(accv), out);
     }
   }
-  x.ctx = c;
+  x.ctx.assign(f.c, f.c + f.D);
   return x;
 }
 
 // host array of LweSample -> device slab (or the resident copy a previous layer left)
 DevSlab stage_input(LayerImpl* L, const void* key, const std::vector<const LweSample*>& samples) {
   DevSlab s;
-  rs_ctx* c = L->ctx();
+  int D = 0;
+  rs_ctx** fleet = L->fleet(&D);
   const int W = L->W(), n = W - 1;
   const bool had = take(key, &s);
-  if (had && s.rows == samples.size() && s.ctx == c) {
+  if (had && s.rows == samples.size() && (int)s.ctx.size() == D && std::equal(s.ctx.begin(), s.ctx.end(), fleet)) {
     // same fingerprint as at publication: sampled rows only (packing 131,072 x 351 words per layer just to
     // compare them would cost more than the check is worth)
     const size_t rows = samples.size(), picks = rows < 64 ? rows : 64;
@@ -705,13 +769,16 @@ DevSlab stage_input(LayerImpl* L, const void* key, const std::vector<const LweSa
     }
     if (h == s.tag) return s;
   }
-  if (had) RS_CHECK(rs_dev_free(s.ctx, s.ptr));   // stale or foreign: release it and upload what the host holds
+  if (had) s.release();   // stale or foreign: release it and upload what the host holds
   s = DevSlab{};
   std::vector<int32_t> host(samples.size() * (size_t)W);
   for (size_t i = 0; i < samples.size(); ++i) redsec_pack(&host[i * W], samples[i], n);
-  s.ptr = dev_rows(c, samples.size(), W);
-  s.rows = samples.size(); s.ctx = c;
-  RS_CHECK(rs_copy_to_dev(c, s.ptr, host.data(), host.size() * 4));
+  s.rows = samples.size();
+  for (int d = 0; d < D; ++d) {
+    s.ctx.push_back(fleet[d]);
+    s.ptr.push_back(dev_rows(fleet[d], samples.size(), W));
+    RS_CHECK(rs_copy_to_dev(fleet[d], s.ptr[d], host.data(), host.size() * 4));
+  }
   return s;
 }
 
@@ -719,7 +786,7 @@ std::vector<int32_t> download(const DevSlab& s, int W) {
   std::vector<int32_t> host(s.rows * (size_t)W);
   // nothing to certify here: in FFT mode every bootstrapped call is followed on the device by its gated exact
   // recomputation (include/redsec_hip.h), so what comes down is exact by construction
-  RS_CHECK(rs_copy_to_host(s.ctx, host.data(), s.ptr, host.size() * 4));
+  RS_CHECK(rs_copy_to_host(s.ctx[0], host.data(), s.ptr[0], host.size() * 4));
   return host;
 }
 

@@ -91,6 +91,8 @@ struct TFheGateBootstrappingParameterSet;
 struct LweBootstrappingKeyFFT {
   const LweParams* in_out_params;
   rs_ctx* ctx;                                      // created on first bootstrap (client tools never touch the GPU)
+  rs_ctx** fleet;                                   // ctx plus one more context per further device of REDSEC_DEVICES
+  int fleet_size;
   const TFheGateBootstrappingParameterSet* params;  // what the lazy creation needs
   const LweBootstrappingKey* src;
 };
@@ -175,6 +177,10 @@ void bootsMUX(LweSample* result, const LweSample* a, const LweSample* b, const L
 // ---- extensions used by the batched layer code (not part of TFHE) ----
 // GPU context behind an evaluation key, and (un)packing between LweSample and the ABI's W-word rows.
 rs_ctx* redsec_ctx_of(const TFheGateBootstrappingCloudKeySet* bk);
+// REDSEC_DEVICES=0,1,...: one context (full key replica) per listed device, the layer code shards every bootstrapped
+// stage across them (the reference's shape: one host thread per GPU over enc_segs[NUM_GPUS], lib/GPU/BinFunc_gpu.cu:119-137).
+// Unset: the single device REDSEC_DEVICE (default 0). redsec_fleet_of returns the contexts, *count how many.
+rs_ctx** redsec_fleet_of(const TFheGateBootstrappingCloudKeySet* bk, int* count);
 void redsec_pack(int32_t* words, const LweSample* s, int32_t n);
 void redsec_unpack(LweSample* s, const int32_t* words, int32_t n);
 

@@ -104,13 +104,16 @@ LweBootstrappingKeyFFT* new_bkfft(const TFheGateBootstrappingParameterSet* p, co
   LweBootstrappingKeyFFT* f = new LweBootstrappingKeyFFT;
   f->in_out_params = p->in_out_params;
   f->ctx = nullptr;  // created on first use: client tools never touch the GPU
+  f->fleet = nullptr;
+  f->fleet_size = 0;
   f->params = p;
   f->src = src;
   return f;
 }
 
 // Created on the first bootstrap; the per-ciphertext wrappers are called from OpenMP regions of the caller
-// (lib/BinFunc.cpp:217,896,1056), so creation is serialised.
+// (lib/BinFunc.cpp:217,896,1056), so creation is serialised. One context per device of REDSEC_DEVICES (a device
+// may be listed twice: two contexts on one GPU walk the multi-device code path on a one-GPU machine).
 rs_ctx* ctx_of_fft(const LweBootstrappingKeyFFT* cf) {
   LweBootstrappingKeyFFT* f = const_cast<LweBootstrappingKeyFFT*>(cf);
   static std::mutex mu;
@@ -119,9 +122,25 @@ rs_ctx* ctx_of_fft(const LweBootstrappingKeyFFT* cf) {
   const TFheGateBootstrappingParameterSet* p = f->params;
   const TLweParams* tp = p->tgsw_params->tlwe_params;
   rs_params rp = {p->in_out_params->n, tp->N, tp->k, p->tgsw_params->l, p->tgsw_params->Bgbit, p->ks_t, p->ks_basebit};
-  const char* dev = getenv("REDSEC_DEVICE");
-  if (rs_create(&f->ctx, &rp, dev ? atoi(dev) : 0) != 0) die("rs_create");
-  if (rs_load_keys(f->ctx, f->src->bk_words, f->src->ksk_words) != 0) die("rs_load_keys");
+  std::vector<int> devices;
+  if (const char* list = getenv("REDSEC_DEVICES")) {
+    for (const char* q = list; *q;) {
+      char* end = nullptr;
+      const long d = strtol(q, &end, 10);
+      if (end == q) break;
+      devices.push_back((int)d);
+      q = *end == ',' ? end + 1 : end;
+    }
+  }
+  if (devices.empty()) { const char* dev = getenv("REDSEC_DEVICE"); devices.push_back(dev ? atoi(dev) : 0); }
+  rs_ctx** fleet = (rs_ctx**)calloc(devices.size(), sizeof(rs_ctx*));
+  for (size_t i = 0; i < devices.size(); ++i) {
+    if (rs_create(&fleet[i], &rp, devices[i]) != 0) die("rs_create");
+    if (rs_load_keys(fleet[i], f->src->bk_words, f->src->ksk_words) != 0) die("rs_load_keys");
+  }
+  f->fleet = fleet;
+  f->fleet_size = (int)devices.size();
+  f->ctx = fleet[0];
   return f->ctx;
 }
 
@@ -295,7 +314,11 @@ TFheGateBootstrappingSecretKeySet* new_random_gate_bootstrapping_secret_keyset(c
 }
 
 static void free_cloud_parts(const TFheGateBootstrappingCloudKeySet* c) {
-  if (c->bkFFT) { if (c->bkFFT->ctx) rs_destroy(c->bkFFT->ctx); delete c->bkFFT; }
+  if (c->bkFFT) {
+    for (int i = 0; i < c->bkFFT->fleet_size; ++i) rs_destroy(c->bkFFT->fleet[i]);
+    free(c->bkFFT->fleet);
+    delete c->bkFFT;
+  }
   if (c->bk) { free(c->bk->bk_words); free(c->bk->ksk_words); delete c->bk; }
 }
 void delete_gate_bootstrapping_secret_keyset(TFheGateBootstrappingSecretKeySet* ks) {
@@ -543,6 +566,11 @@ void import_gate_bootstrapping_ciphertext_fromFile(FILE* f, LweSample* s, const 
 
 // ---- GPU ----
 rs_ctx* redsec_ctx_of(const TFheGateBootstrappingCloudKeySet* bk) { return ctx_of_fft(bk->bkFFT); }
+rs_ctx** redsec_fleet_of(const TFheGateBootstrappingCloudKeySet* bk, int* count) {
+  (void)ctx_of_fft(bk->bkFFT);
+  *count = bk->bkFFT->fleet_size;
+  return bk->bkFFT->fleet;
+}
 void redsec_pack(int32_t* words, const LweSample* s, int32_t n) {
   memcpy(words, s->a, sizeof(int32_t) * (size_t)n);
   words[n] = s->b;

@@ -111,3 +111,43 @@ def test_unmodified_cifar_binarynet_full_driver(tmp_path):
     dec = np.where(dec > 2048, dec - 4096, dec)
     assert int(np.argmax(dec)) == int(np.argmax(plain[i])) == int(labels[i])
     assert np.corrcoef(dec, plain[i])[0, 1] > 0.5
+
+
+@pytest.mark.parametrize("family,net,devices", [("mnist", "sign1024x1", "0,0"), ("mnist", "relu1024x1", "0,0,0"), ("cifar", "binarynet_small", "0,0")])
+def test_driver_sharded_over_several_contexts_equals_single_device(tmp_path, monkeypatch, family, net, devices):
+    """Gate-parallel evaluation of ONE image inside the C++ layer mirror (the reference's shape: enc_segs[NUM_GPUS], one host
+    thread per GPU, lib/GPU/BinFunc_gpu.cu:119-137): REDSEC_DEVICES lists the devices, every bootstrapped stage is split
+    contiguously across one context per entry and the slices are exchanged device to device before the next linear stage.
+    On a one-GPU box the same device is listed several times -- several contexts, the same code path, ragged slices with
+    three -- and the unmodified driver's network_output.ctxt must equal the single-device run BYTE FOR BYTE."""
+    import shutil
+    from redsec_amd import client
+    exe = "%s_%s_enc.out" % (family, net)
+    if not os.path.exists(os.path.join(rd.REFNETS, exe)):
+        pytest.skip("build/refnets not shipped")
+    cdir = str(tmp_path / "client")
+    netdir = str(tmp_path / "nets" / family / net)
+    os.makedirs(cdir); os.makedirs(netdir)
+    shutil.copyfile(os.path.join(rd.GOLD, "%s_%s_var_prep.dat" % (family, net)), os.path.join(netdir, "var_prep.dat"))
+    assert rd.run("client_gen_secure_keyset.out", cdir).returncode == 0
+    keys = client.read_tfhe_keyset(open(os.path.join(cdir, "secret.key"), "rb"), secret=True)
+    sk = client.SecretKeySet("redsec_small_v2", seed=1)
+    sk.lwe_key = keys["lwe_key"]
+    if family == "mnist":
+        labels, pixels = pm.load_images()
+        ct = sk.encrypt_image(pixels[4], seed=9, preprocess="relu" if net.startswith("relu") else "sign")
+    else:
+        labels, pixels = pm.load_cifar_images()
+        ct = sk.encrypt_image(pixels[1], seed=9)
+    with open(os.path.join(cdir, "image.ctxt"), "wb") as f:
+        client.write_ciphertexts(f, ct)
+    outs = []
+    for dev in (None, devices):
+        if dev is None:
+            monkeypatch.delenv("REDSEC_DEVICES", raising=False)
+        else:
+            monkeypatch.setenv("REDSEC_DEVICES", dev)
+        r = rd.run(exe, netdir)
+        assert r.returncode == 0 and "Result ctxts loaded" in r.stdout, r.stdout + r.stderr
+        outs.append(open(os.path.join(cdir, "network_output.ctxt"), "rb").read())
+    assert len(outs[0]) == 10 * (4 * 350 + 16) and outs[0] == outs[1]
