@@ -141,6 +141,14 @@ class Backend:
     /root/reference/lib/BinOps_enc.cpp: every primitive takes `bk` as its last argument)."""
 
     def __init__(self, p, device=0):
+        # torch's HIP runtime must be initialised BEFORE this library initialises its own in the same process: the
+        # other order leaves torch with "No HIP GPUs are available" (measured on the MI355X boxes, ROCm 7.2 + torch 2.10)
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
         self.L = load_library()
         self.p = p
         self.W = p.n + 1
