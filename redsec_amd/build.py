@@ -76,7 +76,7 @@ HOST = os.path.join(HERE, "host")
 LAYERS_LIB = os.path.join(HERE, "libredsec_layers.so")
 LAYERS_SOURCES = [os.path.join(HOST, "tfhe_shim.cpp"), os.path.join(HOST, "layers.cpp")]
 LAYERS_DEPS = LAYERS_SOURCES + [os.path.join(HOST, "tfhe", f) for f in ("tfhe.h", "tfhe_io.h", "tfhe_garbage_collector.h")] + \
-    [os.path.join(HOST, "lib", f) for f in ("Layer.h", "BinLayer.h", "IntLayer.h", "BinOps_enc.h", "IntOps_enc.h")] + \
+    [os.path.join(HOST, "lib", f) for f in ("Layer.h", "BinLayer.h", "IntLayer.h", "BinOps_enc.h", "IntOps_enc.h", "BinFunc.h", "IntFunc.h")] + \
     [os.path.join(INCLUDE, "redsec_hip.h")]
 
 

@@ -335,6 +335,9 @@ struct LayerImpl {
   tNetParams np;
   TFheGateBootstrappingCloudKeySet* bk;
   bool prepared = false;
+  // one-stage use through the BinFunc::* / IntFunc::* classes: a convolution, sum-pool or max-pool on its own reads no
+  // bias record and adds none
+  bool no_bias = false;
   // geometry fixed by prep()
   Geometry conv{}, pool{};
   int in_count = 0, quant_count = 0, quant_depth = 0, out_count = 0;
@@ -457,7 +460,10 @@ tDimensions* prep_impl(LayerImpl* L, FILE* fd, tDimensions* dim, tDimensions* in
   // Quantize::prep: bias = int32[in_dep] -> trivial samples of bias/4096
   L->quant_depth = (int)dim->in_dep;
   L->quant_count = dim->hw.h * dim->hw.w * (int)dim->in_dep;
-  {
+  if (L->no_bias) {
+    L->raw_bias.assign((size_t)L->quant_depth, 0);
+    L->bias.assign((size_t)L->quant_depth, 0);
+  } else {
     assert(fd != NULL);
     uint8_t tag = 0;
     size_t got = fread(&tag, 1, 1, fd); (void)got;
@@ -662,7 +668,7 @@ DevSlab run_layer(LayerImpl* L, DevSlab x) {
     const Geometry& g = L->conv;
     const size_t rows = (size_t)g.Ho * g.Wo * L->depth;
     replace(f.replicated(rows, [&](int d, rs_ctx* c, int32_t* y) {
-      const int32_t* bias = pool_sum ? nullptr : dw[d].bias;   // bias joins at the last linear op before the activation
+      const int32_t* bias = (pool_sum || L->no_bias) ? nullptr : dw[d].bias;   // bias joins at the last linear op before the activation
       if (g.win_h == 1 && g.win_w == 1 && g.H == 1 && g.Wd == 1) {
         RS_CHECK(rs_linear_fc_dev(c, y, x.ptr[d], dw[d].sign, dw[d].zero, g.C, (int32_t)L->depth, tap_const, bias, L->quant_depth, nullptr));
       } else {
@@ -671,14 +677,14 @@ DevSlab run_layer(LayerImpl* L, DevSlab x) {
       }
     }), rows);
   }
-  if (pool_sum || L->e_conv == E_NO_CONV) {
+  if (pool_sum || (L->e_conv == E_NO_CONV && !L->no_bias)) {
     // SumPooling::execute; a layer with neither conv nor pooling still needs its bias: 1x1 window
     Geometry g = L->pool;
     if (!pool_sum) { g = Geometry{1, (int)x.rows / L->quant_depth, L->quant_depth, 1, (int)x.rows / L->quant_depth, 1, 1, 1, 1, 0, 0}; }
     const size_t rows = (size_t)g.Ho * g.Wo * g.C;
     replace(f.replicated(rows, [&](int d, rs_ctx* c, int32_t* y) {
       rs_pool_shape s{g.H, g.Wd, g.C, g.win_h, g.win_w, g.st_h, g.st_w, g.off_h, g.off_w, g.Ho, g.Wo};
-      RS_CHECK(rs_sumpool_dev(c, y, x.ptr[d], &s, dw[d].bias, L->quant_depth, nullptr));
+      RS_CHECK(rs_sumpool_dev(c, y, x.ptr[d], &s, L->no_bias ? nullptr : dw[d].bias, L->quant_depth, nullptr));
     }), rows);
   }
   assert((int)x.rows == L->quant_count);
@@ -813,20 +819,162 @@ void* publish(LayerImpl* L, DevSlab out) {
 
 using redsec_host::LayerImpl;
 
+namespace redsec_host {
+
+// execute() of a layer or of a single stage: stage the input (or find it resident), free it as the reference's callee
+// does (BinFunc.cpp:327, IntFunc.cpp:698), run, hand back fresh host arrays with the device copy remembered
+void* execute_bits(LayerImpl* impl, tBit* p_in) {
+  assert(impl->prepared);
+  std::vector<const LweSample*> in((size_t)impl->in_count);
+  for (size_t i = 0; i < in.size(); ++i) in[i] = &p_in[i];
+  DevSlab x = stage_input(impl, p_in, in);
+  bit_free((uint32_t)impl->in_count, p_in);
+  return publish(impl, run_layer(impl, x));
+}
+void* execute_mbits(LayerImpl* impl, tMultiBit* p_in) {
+  assert(impl->prepared);
+  std::vector<const LweSample*> in((size_t)impl->in_count);
+  for (size_t i = 0; i < in.size(); ++i) in[i] = &p_in[i].ctxt[0];
+  const bool ours = is_resident(p_in);     // produced by one of these layers (calloc) or by the driver (new[])
+  DevSlab x = stage_input(impl, p_in, in);
+  for (int i = 0; i < impl->in_count; ++i) delete_gate_bootstrapping_ciphertext_array((int32_t)p_in[i].size, p_in[i].ctxt);
+  if (ours) free(p_in); else delete[] p_in;
+  return publish(impl, run_layer(impl, x));
+}
+
+// a LayerImpl that is ONE stage (the BinFunc::* / IntFunc::* classes)
+LayerImpl* make_stage(bool is_int, eConvType ec, uint32_t dep, ePoolType ep, eQuantType eq, bool no_bias) {
+  LayerImpl* L = new LayerImpl;
+  L->is_int = is_int; L->e_conv = ec; L->e_pool = ep; L->e_act = eq; L->depth = dep; L->bk = nullptr; L->no_bias = no_bias;
+  memset(&L->np, 0, sizeof L->np);
+  L->np.e_bias = E_BNORM;                                // a ReLU stage reads its slope record
+  L->np.conv.stride.h = L->np.conv.stride.w = 1;
+  const char* ic = getenv("REDSEC_INTCONV");
+  L->int_conv_plain = !(ic && strcmp(ic, "enc") == 0);
+  return L;
+}
+tDimensions* prep_stage(LayerImpl* L, FILE* fd, tDimensions* dim, TFheGateBootstrappingCloudKeySet* bk) {
+  tDimensions in_dim, out_dim;
+  L->bk = bk;
+  if (L->np.pool.stride.h == 0) L->np.pool.stride.h = L->np.pool.window.h;   // SumPooling/MaxPooling ctor
+  if (L->np.pool.stride.w == 0) L->np.pool.stride.w = L->np.pool.window.w;
+  return prep_impl(L, fd, dim, &in_dim, &out_dim);
+}
+// Quantize::prep hands the records it read to the caller's arrays, as the reference does (get_intfilters into p_bias:
+// trivial samples of bias/4096; get_intfilters_ptxt into p_slope)
+void export_bias(const LayerImpl* L, tMultiBit* p_bias, uint32_t* p_slope) {
+  const LweParams* p = L->bk->params->in_out_params;
+  for (int i = 0; p_bias && i < L->quant_depth; ++i) {
+    p_bias[i].size = 1;
+    p_bias[i].ctxt = new_LweSample(p);
+    lweNoiselessTrivial(&p_bias[i].ctxt[0], modSwitchToTorus32(L->raw_bias[(size_t)i], 4096), p);
+  }
+  for (size_t i = 0; p_slope && i < L->slope.size(); ++i) p_slope[i] = (uint32_t)L->slope[i];
+}
+
+}  // namespace redsec_host
+
+// ---- BinFunc / IntFunc: the reference's per-stage classes (lib/BinFunc.h:37-173, lib/IntFunc.h:27-140), each ONE batched
+// stage of the same engine the layers use. Chained through their host arrays they stay device-resident like the layers. ----
+#include "lib/BinFunc.h"
+#include "lib/IntFunc.h"
+using redsec_host::make_stage;
+using redsec_host::prep_stage;
+
+BinFunc::Convolution::Convolution(uint32_t out_depth, tConvParams* in_params) {
+  impl = make_stage(false, E_CONV, out_depth, E_NO_POOL, E_ACTIVATION_NONE, true);
+  impl->np.conv = *in_params;
+}
+tDimensions* BinFunc::Convolution::prep(FILE* fd_filt, tDimensions* ret_dim, TFheGateBootstrappingCloudKeySet* in_bk) { return prep_stage(impl, fd_filt, ret_dim, in_bk); }
+tMultiBit* BinFunc::Convolution::execute(tBit* p_inputs) { return (tMultiBit*)redsec_host::execute_bits(impl, p_inputs); }
+void BinFunc::Convolution::get_outhw(tRectangle* r) { r->h = (int16_t)impl->conv.Ho; r->w = (int16_t)impl->conv.Wo; }
+void BinFunc::Convolution::get_outdep(uint32_t* d) { *d = impl->depth; }
+
+BinFunc::SumPooling::SumPooling(tPoolParams* in_params) {
+  impl = make_stage(false, E_NO_CONV, 0, E_SUMPOOL, E_ACTIVATION_NONE, true);
+  impl->np.pool = *in_params;
+}
+tDimensions* BinFunc::SumPooling::prep(tDimensions* ret_dim, TFheGateBootstrappingCloudKeySet* in_bk) { return prep_stage(impl, NULL, ret_dim, in_bk); }
+tMultiBit* BinFunc::SumPooling::execute(tMultiBit* p_inputs) { return (tMultiBit*)redsec_host::execute_mbits(impl, p_inputs); }
+void BinFunc::SumPooling::get_outhw(tRectangle* r) { r->h = (int16_t)impl->pool.Ho; r->w = (int16_t)impl->pool.Wo; }
+void BinFunc::SumPooling::get_outdep(uint32_t* d) { *d = (uint32_t)impl->quant_depth; }
+
+// On its own a max-pool receives +-1/4096 sign bits (Quantize::execute's output), which no OR can separate from the
+// mod-switch noise: the stage first re-encodes every bit to +-1/(4w) (one sign bootstrap each), then ORs each window in one
+// bootstrap (DESIGN.md "Max-pool semantics"). Inside a BinLayer the re-encoding is the layer's own sign bootstrap.
+BinFunc::MaxPooling::MaxPooling(tPoolParams* in_params) {
+  impl = make_stage(false, E_NO_CONV, 0, E_MAXPOOL, E_ACTIVATION_SIGN, true);
+  impl->np.pool = *in_params;
+}
+tDimensions* BinFunc::MaxPooling::prep(tDimensions* ret_dim, TFheGateBootstrappingCloudKeySet* in_bk) { return prep_stage(impl, NULL, ret_dim, in_bk); }
+tBit* BinFunc::MaxPooling::execute(tBit* p_inputs) { return (tBit*)redsec_host::execute_bits(impl, p_inputs); }
+
+BinFunc::Quantize::Quantize(tQParams* qparam) {
+  assert(qparam != NULL && qparam->shift_bits > 0);
+  impl = make_stage(false, E_NO_CONV, 0, E_NO_POOL, qparam->shift_bits > 1 ? E_ACTIVATION_RELU : E_ACTIVATION_SIGN, false);
+  impl->np.quant = *qparam;
+  impl->shift_bits = qparam->shift_bits;
+}
+tDimensions* BinFunc::Quantize::prep(FILE* fd_bias, tDimensions* ret_dim, tMultiBit* p_bias, uint32_t* p_slope, TFheGateBootstrappingCloudKeySet* in_bk) {
+  tDimensions* d = prep_stage(impl, fd_bias, ret_dim, in_bk);
+  redsec_host::export_bias(impl, p_bias, p_slope);
+  return d;
+}
+// the bias the stage applies is the record prep() read (the one it also wrote into p_bias)
+tBit* BinFunc::Quantize::execute(tMultiBit* p_inputs, tMultiBit*) { assert(impl->e_act == E_ACTIVATION_SIGN); return (tBit*)redsec_host::execute_mbits(impl, p_inputs); }
+tMultiBit* BinFunc::Quantize::add_bias(tMultiBit* p_inputs, tMultiBit*) {
+  const eQuantType keep = impl->e_act;
+  impl->e_act = E_ACTIVATION_NONE;
+  tMultiBit* r = (tMultiBit*)redsec_host::execute_mbits(impl, p_inputs);
+  impl->e_act = keep;
+  return r;
+}
+tFixedPoint* BinFunc::Quantize::relu_shift(tMultiBit* p_inputs, tMultiBit*, uint32_t*) { assert(impl->e_act == E_ACTIVATION_RELU); return (tFixedPoint*)redsec_host::execute_mbits(impl, p_inputs); }
+
+IntFunc::Convolution::Convolution(uint16_t out_depth, tConvParams* in_params) {
+  impl = make_stage(true, E_CONV, out_depth, E_NO_POOL, E_ACTIVATION_NONE, true);
+  impl->np.conv = *in_params;
+}
+tDimensions* IntFunc::Convolution::prep(FILE* fd_filt, tDimensions* ret_dim, TFheGateBootstrappingCloudKeySet* in_bk) { return prep_stage(impl, fd_filt, ret_dim, in_bk); }
+tFixedPoint* IntFunc::Convolution::execute(tFixedPoint* p_inputs) { return (tFixedPoint*)redsec_host::execute_mbits(impl, p_inputs); }
+
+IntFunc::SumPooling::SumPooling(tPoolParams* in_params) {
+  impl = make_stage(true, E_NO_CONV, 0, E_SUMPOOL, E_ACTIVATION_NONE, true);
+  impl->np.pool = *in_params;
+}
+tDimensions* IntFunc::SumPooling::prep(tDimensions* ret_dim, TFheGateBootstrappingCloudKeySet* in_bk) { return prep_stage(impl, NULL, ret_dim, in_bk); }
+tFixedPoint* IntFunc::SumPooling::execute(tFixedPoint* p_inputs) { return (tFixedPoint*)redsec_host::execute_mbits(impl, p_inputs); }
+
+IntFunc::Quantize::Quantize(tQParams* qparam) {   // shift_bits 0: no activation, 1: sign, > 1: ReLU (lib/IntFunc.cpp:819-838)
+  assert(qparam != NULL);
+  const eQuantType eq = qparam->shift_bits == 0 ? E_ACTIVATION_NONE : (qparam->shift_bits == 1 ? E_ACTIVATION_SIGN : E_ACTIVATION_RELU);
+  impl = make_stage(true, E_NO_CONV, 0, E_NO_POOL, eq, false);
+  impl->np.quant = *qparam;
+  impl->shift_bits = qparam->shift_bits;
+}
+tDimensions* IntFunc::Quantize::prep(FILE* fd_bias, tDimensions* ret_dim, tMultiBit* p_bias, uint32_t* p_slope, TFheGateBootstrappingCloudKeySet* in_bk) {
+  if (p_slope == NULL && impl->e_act == E_ACTIVATION_RELU) impl->np.e_bias = E_NO_BIAS;   // no slope record to read (IntFunc.cpp:802)
+  tDimensions* d = prep_stage(impl, fd_bias, ret_dim, in_bk);
+  redsec_host::export_bias(impl, p_bias, p_slope);
+  return d;
+}
+tBit* IntFunc::Quantize::execute(tFixedPoint* p_inputs, tMultiBit*) { assert(impl->e_act == E_ACTIVATION_SIGN); return (tBit*)redsec_host::execute_mbits(impl, p_inputs); }
+tFixedPoint* IntFunc::Quantize::add_bias(tFixedPoint* p_inputs, tMultiBit*) {
+  const eQuantType keep = impl->e_act;
+  impl->e_act = E_ACTIVATION_NONE;
+  tFixedPoint* r = (tFixedPoint*)redsec_host::execute_mbits(impl, p_inputs);
+  impl->e_act = keep;
+  return r;
+}
+tFixedPoint* IntFunc::Quantize::relu_shift(tFixedPoint* p_inputs, tMultiBit*, uint32_t*) { assert(impl->e_act == E_ACTIVATION_RELU); return (tFixedPoint*)redsec_host::execute_mbits(impl, p_inputs); }
+
 // ---- BinLayer ----
 BinLayer::BinLayer(eConvType ec, uint16_t dep, ePoolType ep, eQuantType eq, tNetParams* np, TFheGateBootstrappingCloudKeySet* in_bk) {
   assert(ec != E_NO_CONV);
   impl = redsec_host::make_impl(false, ec, dep, ep, eq, np, in_bk);
 }
 tDimensions* BinLayer::prep(FILE* fd, tDimensions* dim) { return redsec_host::prep_impl(impl, fd, dim, &in_dim, &out_dim); }
-void* BinLayer::execute(tBit* p_in) {
-  assert(impl->prepared);
-  std::vector<const LweSample*> in((size_t)impl->in_count);
-  for (size_t i = 0; i < in.size(); ++i) in[i] = &p_in[i];
-  redsec_host::DevSlab x = redsec_host::stage_input(impl, p_in, in);
-  bit_free((uint32_t)impl->in_count, p_in);                  // callee frees its input (BinFunc.cpp:327)
-  return redsec_host::publish(impl, redsec_host::run_layer(impl, x));
-}
+void* BinLayer::execute(tBit* p_in) { return redsec_host::execute_bits(impl, p_in); }
 void BinLayer::export_weights(FILE*) { printf("Weight convert not defined\r\n"); }
 
 // ---- IntLayer ----
@@ -834,15 +982,5 @@ IntLayer::IntLayer(eConvType ec, uint16_t dep, ePoolType ep, eQuantType eq, tNet
   impl = redsec_host::make_impl(true, ec, dep, ep, eq, np, in_bk);
 }
 tDimensions* IntLayer::prep(FILE* fd, tDimensions* dim) { return redsec_host::prep_impl(impl, fd, dim, &in_dim, &out_dim); }
-void* IntLayer::execute(tMultiBit* p_in) {
-  assert(impl->prepared);
-  std::vector<const LweSample*> in((size_t)impl->in_count);
-  for (size_t i = 0; i < in.size(); ++i) in[i] = &p_in[i].ctxt[0];
-  const bool ours = redsec_host::is_resident(p_in);     // produced by one of these layers (calloc) or by the driver (new[])
-  redsec_host::DevSlab x = redsec_host::stage_input(impl, p_in, in);
-  // callee frees its input (IntFunc.cpp:698): the samples, then the struct array
-  for (int i = 0; i < impl->in_count; ++i) delete_gate_bootstrapping_ciphertext_array((int32_t)p_in[i].size, p_in[i].ctxt);
-  if (ours) free(p_in); else delete[] p_in;
-  return redsec_host::publish(impl, redsec_host::run_layer(impl, x));
-}
+void* IntLayer::execute(tMultiBit* p_in) { return redsec_host::execute_mbits(impl, p_in); }
 void IntLayer::export_weights(FILE*) { printf("Weight convert not defined\r\n"); }

@@ -1,0 +1,205 @@
+// func_driver.cpp -- test program (tests/test_gpu_ops_wrappers.py): the reference's per-stage classes BinFunc::* / IntFunc::*
+// (lib/BinFunc.h:37-173, lib/IntFunc.h:27-140) against the layer classes built from them (lib/BinLayer.cpp:150-241,
+// lib/IntLayer.cpp:153-235): the same weights, key and inputs through
+//   BinLayer(E_FC, SIGN)                     vs  BinFunc::Convolution -> BinFunc::Quantize::execute
+//   IntLayer(E_NO_CONV, E_SUMPOOL, SIGN)     vs  IntFunc::SumPooling -> IntFunc::Quantize::execute
+// must give the SAME ciphertext words (a bias folded into the linear kernel or added after it is the same wrap-around sum),
+// and BinFunc::MaxPooling / IntFunc::Quantize::{add_bias, relu_shift} on their own must decrypt to the plaintext function.
+// Prints PASS/FAIL lines; exit code = number of failures.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "lib/BinFunc.h"
+#include "lib/BinLayer.h"
+#include "lib/IntFunc.h"
+#include "lib/IntLayer.h"
+
+static TFheGateBootstrappingSecretKeySet* g_sk;
+static TFheGateBootstrappingCloudKeySet* g_bk;
+static int g_fail = 0;
+static void check(const char* what, bool ok) { printf("%s %s\n", ok ? "PASS" : "FAIL", what); if (!ok) ++g_fail; }
+static int dec_int(const LweSample* s, int msize) {
+  const int v = modSwitchFromTorus32(lweSymDecrypt(s, g_sk->lwe_key, msize), msize);
+  return v > msize / 2 ? v - msize : v;
+}
+static bool same(const LweSample* a, const LweSample* b, int n) { return a->b == b->b && memcmp(a->a, b->a, 4 * (size_t)n) == 0; }
+
+// weight file records (lib/BinOps_enc.cpp:247-305): tag 2 + 2 bits per ternary weight (sign, is-zero), MSB first; tag 4 + int32[]
+static void put_ternary(FILE* f, const std::vector<int>& w) {   // w in {-1, 0, +1}
+  fputc(2, f);
+  std::vector<unsigned char> pack((w.size() * 2 + 7) / 8, 0);
+  for (size_t i = 0; i < w.size(); ++i) {
+    if (w[i] > 0) pack[(2 * i) >> 3] |= 0x80 >> ((2 * i) & 7);
+    if (w[i] == 0) pack[(2 * i + 1) >> 3] |= 0x80 >> ((2 * i + 1) & 7);
+  }
+  fwrite(pack.data(), 1, pack.size(), f);
+}
+static void put_ints(FILE* f, const std::vector<int32_t>& v) { fputc(4, f); fwrite(v.data(), 4, v.size(), f); }
+static tDimensions dims(int h, int w, int dep) {
+  tDimensions d; memset(&d, 0, sizeof d);
+  d.hw.h = (int16_t)h; d.hw.w = (int16_t)w; d.in_dep = (uint32_t)dep; d.in_bits = 1; d.out_bits = SINGLE_BIT; d.filter_bits = SINGLE_BIT;
+  d.bias_bits = SINGLE_BIT; d.up_bound = 1; d.scale = 1;
+  return d;
+}
+
+int main() {
+  LweParams* lp = new_LweParams(350, pow(2., -25), pow(2., -13));
+  TLweParams* tp = new_TLweParams(1024, 1, pow(2., -30), pow(2., -13));
+  TGswParams* gp = new_TGswParams(10, 3, tp);
+  TFheGateBootstrappingParameterSet* params = new TFheGateBootstrappingParameterSet(9, 3, lp, gp);
+  uint32_t seed[] = {4, 5, 6};
+  tfhe_random_generator_setSeed(seed, 3);
+  g_sk = new_random_gate_bootstrapping_secret_keyset(params);
+  g_bk = const_cast<TFheGateBootstrappingCloudKeySet*>(&g_sk->cloud);
+  const int n = 350;
+  const Torus32 u = modSwitchToTorus32(1, 4096);
+
+  // ---- BinLayer(E_FC, SIGN) vs Convolution + Quantize ----
+  const int K = 48, M = 12;
+  std::vector<int> w((size_t)K * M);
+  std::vector<int32_t> bias(M);
+  unsigned r = 12345;
+  auto rnd = [&]() { r = r * 1664525u + 1013904223u; return r >> 8; };
+  for (auto& x : w) { const unsigned t = rnd() % 10; x = t < 3 ? 0 : (t < 7 ? 1 : -1); }
+  for (auto& b : bias) b = (int32_t)(rnd() % 17) - 8;
+  std::vector<int> bits(K);
+  for (auto& b : bits) b = (rnd() & 1) ? 1 : -1;
+  FILE* f = tmpfile();
+  put_ternary(f, w); put_ints(f, bias);          // the layer's records
+  put_ternary(f, w); put_ints(f, bias);          // and again for the stage-by-stage instance
+  rewind(f);
+  auto enc_bits = [&]() {
+    tBit* x = new_gate_bootstrapping_ciphertext_array(K, params);
+    uint32_t s2[] = {7, 7, 7};
+    tfhe_random_generator_setSeed(s2, 3);        // the same fresh encryptions both times
+    for (int i = 0; i < K; ++i) lweSymEncrypt(&x[i], bits[i] * u, 1.0 / 32768, g_sk->lwe_key);
+    return x;
+  };
+  tNetParams np; memset(&np, 0, sizeof np);
+  np.conv.window.h = np.conv.window.w = 1; np.conv.stride.h = np.conv.stride.w = 1; np.conv.same_pad = true; np.e_bias = E_BNORM; np.version = 2;
+  np.pool.window.h = np.pool.window.w = 2; np.pool.stride.h = np.pool.stride.w = 2;
+  tDimensions d1 = dims(1, 1, K);
+  BinLayer layer(E_FC, M, E_NO_POOL, E_ACTIVATION_SIGN, &np, g_bk);
+  layer.prep(f, &d1);
+  tBit* out_layer = (tBit*)layer.execute(enc_bits());
+  tDimensions d2 = dims(1, 1, K);
+  BinFunc::Convolution conv(M, &np.conv);
+  tQParams q1; q1.shift_bits = 1;
+  BinFunc::Quantize quant(&q1);
+  std::vector<tMultiBit> pb(M);
+  conv.prep(f, &d2, g_bk);
+  quant.prep(f, &d2, pb.data(), NULL, g_bk);
+  tBit* out_func = quant.execute(conv.execute(enc_bits()), pb.data());
+  bool eq = true, right = true;
+  for (int m = 0; m < M; ++m) {
+    eq = eq && same(&out_layer[m], &out_func[m], n);
+    int pre = bias[m];
+    for (int k = 0; k < K; ++k) pre += w[(size_t)k * M + m] * bits[k];
+    if (pre >= 8 || pre <= -8) right = right && dec_int(&out_func[m], 4096) == (pre >= 0 ? 1 : -1);
+  }
+  check("BinFunc::Convolution + Quantize::execute == BinLayer(E_FC, SIGN), word for word", eq);
+  check("  ... and decrypts to sign(w.x + bias) on clear margins", right);
+  check("Quantize::prep hands out the bias record", dec_int(&pb[3].ctxt[0], 4096) == bias[3]);
+  fclose(f);
+
+  // ---- IntLayer(NO_CONV, SUMPOOL, SIGN) vs IntFunc::SumPooling + IntFunc::Quantize ----
+  const int H = 4;
+  std::vector<int> px(H * H);
+  for (auto& p : px) p = (int)(rnd() % 41) - 20;
+  std::vector<int32_t> b0(1, 3);
+  f = tmpfile();
+  put_ints(f, b0); put_ints(f, b0);
+  rewind(f);
+  auto enc_px = [&]() {
+    tMultiBit* x = new tMultiBit[H * H];
+    uint32_t s2[] = {9, 9, 9};
+    tfhe_random_generator_setSeed(s2, 3);
+    for (int i = 0; i < H * H; ++i) {
+      x[i].size = 1; x[i].ctxt = new_gate_bootstrapping_ciphertext_array(1, params);
+      lweSymEncrypt(&x[i].ctxt[0], px[i] * u, 1.0 / 32768, g_sk->lwe_key);
+    }
+    return x;
+  };
+  tDimensions d3 = dims(H, H, 1);
+  IntLayer il(E_NO_CONV, 1, E_SUMPOOL, E_ACTIVATION_SIGN, &np, g_bk);
+  il.prep(f, &d3);
+  tBit* o1 = (tBit*)il.execute(enc_px());
+  tDimensions d4 = dims(H, H, 1);
+  IntFunc::SumPooling sp(&np.pool);
+  IntFunc::Quantize iq(&q1);
+  std::vector<tMultiBit> pb0(1);
+  sp.prep(&d4, g_bk);
+  iq.prep(f, &d4, pb0.data(), NULL, g_bk);
+  tBit* o2 = iq.execute(sp.execute(enc_px()), pb0.data());
+  eq = true;
+  for (int i = 0; i < 4; ++i) eq = eq && same(&o1[i], &o2[i], n);
+  check("IntFunc::SumPooling + Quantize::execute == IntLayer(NO_CONV, SUMPOOL, SIGN), word for word", eq);
+  fclose(f);
+
+  // ---- BinFunc::MaxPooling on its own: 4x4x2 sign bits -> 2x2x2, OR of every 2x2 window ----
+  {
+    const int C = 2;
+    std::vector<int> sb(4 * 4 * C);
+    for (auto& b : sb) b = (rnd() % 3 == 0) ? 1 : -1;
+    sb[0] = sb[1 * C] = sb[4 * C] = sb[5 * C] = -1;          // one all-false window (channel 0, top left)
+    tBit* x = new_gate_bootstrapping_ciphertext_array(4 * 4 * C, params);
+    for (size_t i = 0; i < sb.size(); ++i) lweSymEncrypt(&x[i], sb[i] * u, 1.0 / 32768, g_sk->lwe_key);
+    tDimensions d5 = dims(4, 4, C);
+    BinFunc::MaxPooling mp(&np.pool);
+    mp.prep(&d5, g_bk);
+    tBit* y = mp.execute(x);
+    bool ok = d5.hw.h == 2 && d5.hw.w == 2;
+    for (int oh = 0; oh < 2; ++oh) for (int ow = 0; ow < 2; ++ow) for (int c = 0; c < C; ++c) {
+      int any = -1;
+      for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) if (sb[((2 * oh + a) * 4 + 2 * ow + b) * C + c] > 0) any = 1;
+      ok = ok && dec_int(&y[(oh * 2 + ow) * C + c], 4096) == any;
+    }
+    check("BinFunc::MaxPooling::execute = OR over each window", ok);
+  }
+
+  // ---- IntFunc::Quantize add_bias and relu_shift on their own ----
+  {
+    const int D = 6;
+    // gentle slopes: the mod-switch moves the input by sigma ~ 8 integer steps (SURVEY.md hard part 7), i.e. by
+    // slope * 8 / 64 output levels; the first and last neuron sit far inside the clamped regions
+    std::vector<int32_t> bb = {-3000, 400, 500, 96, 640, 4000}, slope = {4, 4, 2, 4, 1, 3};
+    std::vector<int> in = {10, 20, -30, 7, -30, 33};
+    f = tmpfile();
+    put_ints(f, bb);
+    put_ints(f, bb); put_ints(f, slope);
+    rewind(f);
+    auto enc = [&]() {
+      tMultiBit* x = new tMultiBit[D];
+      for (int i = 0; i < D; ++i) { x[i].size = 1; x[i].ctxt = new_gate_bootstrapping_ciphertext_array(1, params); lweSymEncrypt(&x[i].ctxt[0], in[i] * u, 1.0 / 65536, g_sk->lwe_key); }
+      return x;
+    };
+    tQParams q0; q0.shift_bits = 0;
+    IntFunc::Quantize ab(&q0);
+    tDimensions d6 = dims(1, 1, D);
+    std::vector<tMultiBit> pbb(D);
+    ab.prep(f, &d6, pbb.data(), NULL, g_bk);
+    tFixedPoint* y = ab.add_bias(enc(), pbb.data());
+    bool ok = true;
+    for (int i = 0; i < D; ++i) ok = ok && dec_int(&y[i].ctxt[0], 4096) == in[i] + bb[i];
+    check("IntFunc::Quantize::add_bias", ok);
+    tQParams q4; q4.shift_bits = 4;
+    IntFunc::Quantize rq(&q4);
+    tDimensions d7 = dims(1, 1, D);
+    d7.scale = 4;                                      // slope_bits = 8 + 2 - 4 = 6, as in relu1024x1's first hidden layer
+    std::vector<uint32_t> ps(D);
+    rq.prep(f, &d7, pbb.data(), ps.data(), g_bk);
+    tFixedPoint* z = rq.relu_shift(enc(), pbb.data(), ps.data());
+    ok = ps[2] == 16;
+    for (int i = 0; i < D; ++i) {
+      const long x = (long)slope[i] * in[i] + bb[i];
+      const int want = x < 0 ? 0 : (int)((x >> 6) > 15 ? 15 : (x >> 6));
+      const int got = dec_int(&z[i].ctxt[0], 16384);
+      ok = ok && (i == 0 || i == D - 1 ? got == want : (got >= want - 2 && got <= want + 2));
+    }
+    check("IntFunc::Quantize::relu_shift = clamp((slope x + bias) >> 6, 0, 15) in units of 1/16384", ok);
+    fclose(f);
+  }
+  printf("failures: %d\n", g_fail);
+  return g_fail;
+}

@@ -51,5 +51,8 @@ def test_layers_library_exports_reference_api():
                  "BinLayer::prep(_IO_FILE*, _DIMS*)", "BinLayer::execute(LweSample*)",
                  "IntLayer::IntLayer(_CONVTYPE, unsigned short, _POOLTYPE, _QUANT_TYPE, _NET_PARAMS*, TFheGateBootstrappingCloudKeySet*)",
                  "IntLayer::execute(tMultiBits*)", "BinOps::binarize_int(", "BinOps::max(", "BinOps::add(", "IntOps::relu(",
-                 "BinOps::get_ternfilters(", "mbit_calloc(", "bit_free(", "tfhe_bootstrap_FFT(", "bootsMUX(", "lweAddMulTo("):
+                 "BinOps::get_ternfilters(", "mbit_calloc(", "bit_free(", "tfhe_bootstrap_FFT(", "bootsMUX(", "lweAddMulTo(",
+                 "BinFunc::Convolution::execute(LweSample*)", "BinFunc::MaxPooling::execute(LweSample*)", "BinFunc::SumPooling::execute(tMultiBits*)",
+                 "BinFunc::Quantize::relu_shift(tMultiBits*, tMultiBits*, unsigned int*)", "IntFunc::Convolution::execute(tMultiBits*)",
+                 "IntFunc::Quantize::add_bias(tMultiBits*, tMultiBits*)", "IntFunc::SumPooling::prep(_DIMS*, TFheGateBootstrappingCloudKeySet*)"):
         assert want in syms, want
