@@ -338,6 +338,9 @@ struct LayerImpl {
   // one-stage use through the BinFunc::* / IntFunc::* classes: a convolution, sum-pool or max-pool on its own reads no
   // bias record and adds none
   bool no_bias = false;
+  // a max-pool on its own (BinFunc::MaxPooling) receives bare +-1/4096 bits: they are multiplied by this factor ahead
+  // of the re-encoding bootstrap so that the bit stands clear of the mod-switch rounding noise (see the class below)
+  int32_t prescale = 1;
   // geometry fixed by prep()
   Geometry conv{}, pool{};
   int in_count = 0, quant_count = 0, quant_depth = 0, out_count = 0;
@@ -695,6 +698,11 @@ DevSlab run_layer(LayerImpl* L, DevSlab x) {
       RS_CHECK(rs_bootstrap_lut_dev(c, y, x.ptr[d] + lo * (size_t)f.W, dw[d].lut, (size_t)L->quant_depth, lo, count, nullptr));
     }), x.rows);
   }
+  if (L->prescale != 1) {
+    replace(f.replicated(x.rows, [&](int d, rs_ctx* c, int32_t* y) {
+      RS_CHECK(rs_lincomb_dev(c, y, x.ptr[d], L->prescale, nullptr, 0, 0, x.rows, nullptr));
+    }), x.rows);
+  }
   if (L->e_act == E_ACTIVATION_SIGN) {
     const bool maxpool = !L->pool_index.empty();
     // Quantize::execute: one sign bootstrap per neuron (BinOps_enc.cpp:182-186). Ahead of a max-pool
@@ -899,12 +907,16 @@ tMultiBit* BinFunc::SumPooling::execute(tMultiBit* p_inputs) { return (tMultiBit
 void BinFunc::SumPooling::get_outhw(tRectangle* r) { r->h = (int16_t)impl->pool.Ho; r->w = (int16_t)impl->pool.Wo; }
 void BinFunc::SumPooling::get_outdep(uint32_t* d) { *d = (uint32_t)impl->quant_depth; }
 
-// On its own a max-pool receives +-1/4096 sign bits (Quantize::execute's output), which no OR can separate from the
-// mod-switch noise: the stage first re-encodes every bit to +-1/(4w) (one sign bootstrap each), then ORs each window in one
-// bootstrap (DESIGN.md "Max-pool semantics"). Inside a BinLayer the re-encoding is the layer's own sign bootstrap.
+// On its own a max-pool receives +-1/4096 sign bits (Quantize::execute's output). That is half a step of the 2N = 2048
+// mod-switch, whose rounding noise alone has sigma ~ 2^-9 (n = 350), so neither an OR gate nor a sign bootstrap can read
+// such a bit directly. The stage therefore multiplies every input by 128 (bits at +-1/32; a fresh or bootstrapped
+// sample's noise of <= 2^-15 becomes <= 2^-8: 7 sigma of margin), re-encodes each bit to +-1/(4w) with one sign
+// bootstrap, then ORs each window in one bootstrap (DESIGN.md "Max-pool semantics"). Inside a BinLayer none of this is
+// needed: the re-encoding is the layer's own sign bootstrap of the pre-activation.
 BinFunc::MaxPooling::MaxPooling(tPoolParams* in_params) {
   impl = make_stage(false, E_NO_CONV, 0, E_MAXPOOL, E_ACTIVATION_SIGN, true);
   impl->np.pool = *in_params;
+  impl->prescale = 128;
 }
 tDimensions* BinFunc::MaxPooling::prep(tDimensions* ret_dim, TFheGateBootstrappingCloudKeySet* in_bk) { return prep_stage(impl, NULL, ret_dim, in_bk); }
 tBit* BinFunc::MaxPooling::execute(tBit* p_inputs) { return (tBit*)redsec_host::execute_bits(impl, p_inputs); }
