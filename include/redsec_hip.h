@@ -48,10 +48,10 @@ typedef enum rs_status {
  * Bgbit, tlwe_params->N, k) as constructed at client/gen_secure_keyset.cpp:82-90. */
 typedef struct rs_params {
   int32_t n;          /* LWE dimension */
-  int32_t N;          /* ring degree; this backend supports N = 1024 */
+  int32_t N;          /* ring degree: 1024, 2048, 4096 or 8192 */
   int32_t k;          /* must be 1 */
-  int32_t bk_l;       /* gadget length: 3 (with bk_Bgbit 7) or 10 (with bk_Bgbit 3) */
-  int32_t bk_Bgbit;
+  int32_t bk_l;       /* gadget length l and base 2^Bgbit, l * Bgbit <= 32. N = 1024 with 3/7 or 10/3 (the shipped sets) */
+  int32_t bk_Bgbit;   /* has all three modes below; every other set runs in RS_MODE_FFT_SPLIT only */
   int32_t ks_t;
   int32_t ks_basebit;
 } rs_params;
@@ -68,7 +68,10 @@ const char* rs_version(void);
 
 /* Parameter sets shipped with the reference / TFHE. */
 int rs_params_default128(rs_params* p);        /* TFHE default 128-bit set (NAND microbench) */
-int rs_params_redsec_small_v2(rs_params* p);   /* client/gen_secure_keyset.cpp:70-91 */
+int rs_params_redsec_small_v2(rs_params* p);   /* client/gen_secure_keyset.cpp:70-91 (the set the client ships with) */
+int rs_params_redsec_small(rs_params* p);      /* client/gen_secure_keyset.cpp:47-68:  n=500  N=1024 l=3 Bgbit=10 */
+int rs_params_redsec_medium(rs_params* p);     /* client/gen_secure_keyset.cpp:28-45:  n=3072 N=4096 l=3 Bgbit=10 */
+int rs_params_redsec_large(rs_params* p);      /* client/gen_secure_keyset.cpp:9-26:   n=6144 N=8192 l=3 Bgbit=10 */
 
 /* Context bound to one HIP device (device index as in hipSetDevice). */
 int rs_create(rs_ctx** out, const rs_params* p, int device);
@@ -91,12 +94,21 @@ int rs_load_keys(rs_ctx* ctx, const int32_t* bk, const int32_t* ksk);
  *                      downstream reads it. No host round trip; holds for the *_dev calls and the host calls alike.
  *   RS_MODE_EXACT_NTT  exact negacyclic NTT over a 51-bit prime carried in FP64: exact by construction,
  *                      2.3x the FP64 operations.
- * Results are identical word for word in both modes (= the CPU oracle).
- * Default RS_MODE_FFT (environment REDSEC_MODE=exact selects the NTT at context creation; the environment
- * is read ONCE, in rs_create). rs_set_mode must not race with launches of the same context. */
-enum { RS_MODE_EXACT_NTT = 0, RS_MODE_FFT = 1 };
+ *   RS_MODE_FFT_SPLIT  the same FP64 FFT with the key split into two signed 16-bit halves (twice the pointwise
+ *                      products and inverse transforms). Every half product stays below 2^40, where the FFT's
+ *                      WORST-CASE error is orders of magnitude below 1/2 (a-priori bound, rs_split_bound): exact
+ *                      by construction, no certificate involved. General kernels: any N in {1024 ... 8192}, any
+ *                      gadget; the only mode of the sets outside the specialised N = 1024 kernels.
+ * Results are identical word for word in all modes (= the CPU oracle).
+ * Default RS_MODE_FFT where available (environment REDSEC_MODE=exact | split selects another at context creation;
+ * the environment is read ONCE, in rs_create). rs_set_mode must not race with launches of the same context. */
+enum { RS_MODE_EXACT_NTT = 0, RS_MODE_FFT = 1, RS_MODE_FFT_SPLIT = 2 };
 int rs_set_mode(rs_ctx* ctx, int mode);
 int rs_get_mode(rs_ctx* ctx, int* mode);
+/* The a-priori bound on |computed - true coefficient| of a split-key product for this context's parameters
+ * (Percival 2003, Thm 5.1 with the operands' 2-norms; derivation in csrc/rs_general.h). The mode is offered when
+ * it is below 1/4. */
+int rs_split_bound(rs_ctx* ctx, double* bound);
 /* A call whose certificate reaches this limit is recomputed exactly on the device (default 0.25: an error
  * of +-1 needs a distance > 0.5). limit = 0 forces the recomputation of every call (tests). */
 #define RS_CERTIFICATE_LIMIT 0.25
@@ -211,7 +223,7 @@ int rs_last_kernel_ms_stream(rs_ctx* ctx, void* stream, float* blind_rotate_ms, 
 
 /* Facts used by bench.py's roofline accounting. rs_last_launch: what the last blind rotation on `stream`
  * actually ran -- form 0 per-wave, 1 lock-step workgroups, 2 duo, 3 / 4 cooperative (2 / 4 waves per
- * ciphertext) -- its waves per workgroup, and `resident` = ciphertexts sharing one sweep of the key (R of the
+ * ciphertext), 5 general (one workgroup of N/16 threads per ciphertext) -- its waves per workgroup, and `resident` = ciphertexts sharing one sweep of the key (R of the
  * algorithmic-bytes formula). rs_info's waves_per_block is that of the default stream's last launch. */
 int rs_last_launch(rs_ctx* ctx, void* stream, int32_t* form, int32_t* waves_per_block, int64_t* resident);
 int rs_info(rs_ctx* ctx, int64_t* bk_device_bytes, int64_t* ksk_device_bytes, int32_t* waves_per_block,

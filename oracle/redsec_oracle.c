@@ -38,6 +38,30 @@ void ro_params_redsec_small_v2(ro_params* p) {
   p->bk_stdev = ldexp(1.0, -30);   /* bootkey_std_dev */
 }
 
+/* client/gen_secure_keyset.cpp:47-68, 28-45, 9-26: the sets the reference defines beside the one it ships
+ * ("for wide networks, the medium and large parameters are better suited", :96). */
+void ro_params_redsec_small(ro_params* p) {
+  p->n = 500; p->N = 1024; p->k = 1;
+  p->bk_l = 3; p->bk_Bgbit = 10;
+  p->ks_t = 18; p->ks_basebit = 1;
+  p->lwe_stdev = ldexp(1.0, -25);
+  p->bk_stdev = ldexp(1.0, -36);
+}
+void ro_params_redsec_medium(ro_params* p) {
+  p->n = 3072; p->N = 4096; p->k = 1;
+  p->bk_l = 3; p->bk_Bgbit = 10;
+  p->ks_t = 18; p->ks_basebit = 1;
+  p->lwe_stdev = ldexp(1.0, -40);
+  p->bk_stdev = ldexp(1.0, -45);
+}
+void ro_params_redsec_large(ro_params* p) {
+  p->n = 6144; p->N = 8192; p->k = 1;
+  p->bk_l = 3; p->bk_Bgbit = 10;
+  p->ks_t = 18; p->ks_basebit = 1;
+  p->lwe_stdev = ldexp(1.0, -41);
+  p->bk_stdev = ldexp(1.0, -46);
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Torus helpers. TFHE numeric_functions.cpp: modSwitchToTorus32 / modSwitchFromTorus32 /
  * approxPhase. REDsec call sites: BinOps_enc.cpp:137,184,190,293; client/encrypt_image.cpp:77;

@@ -39,7 +39,7 @@ extern "C" {
 
 typedef struct ro_params {
   int32_t n;          /* LWE dimension (in_out_params->n)                         */
-  int32_t N;          /* ring degree (tlwe_params->N), power of two <= 1024 here  */
+  int32_t N;          /* ring degree (tlwe_params->N), a power of two (1024 ... 8192)  */
   int32_t k;          /* TRLWE mask polynomials; every REDsec/TFHE set uses 1     */
   int32_t bk_l;       /* gadget length l                                          */
   int32_t bk_Bgbit;   /* log2 of gadget base Bg                                   */
@@ -54,6 +54,11 @@ typedef struct ro_params {
 void ro_params_default128(ro_params* p);
 /* REDsec shipped set: /root/reference/client/gen_secure_keyset.cpp:70-91 (redsec_params_small_v2). */
 void ro_params_redsec_small_v2(ro_params* p);
+/* The other sets of client/gen_secure_keyset.cpp: :47-68 (n=500 N=1024 l=3 Bgbit=10 t=18 basebit=1), :28-45 (n=3072
+ * N=4096), :9-26 (n=6144 N=8192). */
+void ro_params_redsec_small(ro_params* p);
+void ro_params_redsec_medium(ro_params* p);
+void ro_params_redsec_large(ro_params* p);
 
 /* ---- torus helpers (TFHE lwe-functions / numeric_functions) ---- */
 int32_t ro_modswitch_to_torus32(int32_t mu, int32_t Msize);

@@ -22,6 +22,7 @@ ABI_SYMBOLS = [
     "rs_sumpool_dev", "rs_lincomb_dev", "rs_dev_alloc", "rs_dev_free", "rs_copy_to_dev", "rs_copy_to_host", "rs_sync",
     "rs_set_timing", "rs_last_kernel_ms", "rs_info", "rs_set_mode", "rs_get_mode", "rs_rounding_certificate", "rs_fft_fallbacks",
     "rs_bootstrap_lut_dev", "rs_set_certificate_limit", "rs_certify", "rs_reserve_stream", "rs_last_kernel_ms_stream", "rs_last_launch", "rs_copy_dev_to_dev",
+    "rs_params_redsec_small", "rs_params_redsec_medium", "rs_params_redsec_large", "rs_split_bound",
 ]
 
 GATES = {"NAND": 0, "OR": 1, "AND": 2, "NOR": 3, "XOR": 4, "XNOR": 5, "ANDNY": 6, "ANDYN": 7, "ORNY": 8, "ORYN": 9}
@@ -68,6 +69,10 @@ def load_library(path=None):
     vp = C.c_void_p
     L.rs_params_default128.argtypes = [P]
     L.rs_params_redsec_small_v2.argtypes = [P]
+    L.rs_params_redsec_small.argtypes = [P]
+    L.rs_params_redsec_medium.argtypes = [P]
+    L.rs_params_redsec_large.argtypes = [P]
+    L.rs_split_bound.argtypes = [vp, C.POINTER(C.c_double)]
     L.rs_create.argtypes = [C.POINTER(vp), P, C.c_int]
     L.rs_destroy.argtypes = [vp]
     L.rs_load_keys.argtypes = [vp, _i32p, _i32p]
@@ -117,13 +122,16 @@ def _check(L, rc):
 
 
 def params(name, n=None):
-    """'default128' | 'redsec_small_v2'; `n` overrides the LWE dimension (reduced-size test keys)."""
+    """'default128' | 'redsec_small_v2' | 'redsec_small' | 'redsec_medium' | 'redsec_large'; `n` overrides the LWE
+    dimension (reduced-size test keys)."""
     L = load_library()
     p = RsParams()
     if name == "default128":
         _check(L, L.rs_params_default128(C.byref(p)))
     elif name == "redsec_small_v2":
         _check(L, L.rs_params_redsec_small_v2(C.byref(p)))
+    elif name in ("redsec_small", "redsec_medium", "redsec_large"):
+        _check(L, getattr(L, "rs_params_" + name)(C.byref(p)))
     else:
         raise KeyError(name)
     if n is not None:
@@ -333,13 +341,20 @@ class Backend:
 
     # ---- arithmetic mode ----
     def set_mode(self, mode):
-        """'fft' (default) or 'exact' (guaranteed-exact NTT)."""
-        _check(self.L, self.L.rs_set_mode(self.h, {"exact": 0, "ntt": 0, "fft": 1}[mode]))
+        """'fft' (default), 'exact' (exact NTT) or 'split' (split-key FFT, exact by an a-priori bound; the only mode of
+        the parameter sets outside the specialised N = 1024 kernels)."""
+        _check(self.L, self.L.rs_set_mode(self.h, {"exact": 0, "ntt": 0, "fft": 1, "split": 2}[mode]))
 
     def mode(self):
         m = C.c_int()
         _check(self.L, self.L.rs_get_mode(self.h, C.byref(m)))
-        return "fft" if m.value == 1 else "exact"
+        return {0: "exact", 1: "fft", 2: "split"}[m.value]
+
+    def split_bound(self):
+        """A-priori bound on the rounding distance of the split-key product for this parameter set."""
+        d = C.c_double()
+        _check(self.L, self.L.rs_split_bound(self.h, C.byref(d)))
+        return d.value
 
     def rounding_certificate(self, reset=True):
         d = C.c_double()
@@ -366,7 +381,7 @@ class Backend:
         """(form, waves per workgroup, ciphertexts per key sweep) of the last blind rotation on the current stream."""
         f, w, r = C.c_int32(), C.c_int32(), C.c_int64()
         _check(self.L, self.L.rs_last_launch(self.h, self._stream(), C.byref(f), C.byref(w), C.byref(r)))
-        return {"form": ["per_wave", "workgroup", "duo", "coop2", "coop4"][f.value], "waves_per_block": w.value, "resident": r.value}
+        return {"form": ["per_wave", "workgroup", "duo", "coop2", "coop4", "general"][f.value], "waves_per_block": w.value, "resident": r.value}
 
     # ---- timing / facts ----
     def set_timing(self, on=True):

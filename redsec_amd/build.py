@@ -18,10 +18,10 @@ INCLUDE = os.path.join(ROOT, "include")
 HIP_LIB = os.path.join(HERE, "libredsec_hip.so")
 EMU_LIB = os.path.join(HERE, "librs_emulate.so")
 
-HIP_SOURCES = ["rs_bootstrap.hip", "rs_kernels.hip", "rs_api.cpp"]
-HIP_DEPS = HIP_SOURCES + ["rs_kernels.h", "rs_ntt.h", "rs_fft.h", "rs_host.h", os.path.join(INCLUDE, "redsec_hip.h")]
+HIP_SOURCES = ["rs_bootstrap.hip", "rs_general.hip", "rs_kernels.hip", "rs_api.cpp"]
+HIP_DEPS = HIP_SOURCES + ["rs_kernels.h", "rs_ntt.h", "rs_fft.h", "rs_general.h", "rs_host.h", os.path.join(INCLUDE, "redsec_hip.h")]
 EMU_SOURCES = ["rs_emulate.cpp"]
-EMU_DEPS = EMU_SOURCES + ["rs_ntt.h", "rs_fft.h", "rs_host.h"]
+EMU_DEPS = EMU_SOURCES + ["rs_ntt.h", "rs_fft.h", "rs_general.h", "rs_host.h"]
 
 
 def _abs(paths):

@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +20,7 @@
 #include <vector>
 
 #include "rs_host.h"
+#include "rs_general.h"
 #include "rs_kernels.h"
 
 namespace {
@@ -53,6 +55,7 @@ struct Lane {
   int32_t* d_u0 = nullptr;
   int32_t* d_u1 = nullptr;
   size_t ws_batch = 0;
+  size_t sample_words = rs::kN + 1;       // words of one extracted sample (N + 1)
   unsigned int* d_counter = nullptr;      // work counter of the persistent blind-rotate launches
   unsigned long long* d_cert = nullptr;   // [kCertSlots + 2]
   unsigned slot_next = 0;
@@ -75,6 +78,13 @@ struct rs_ctx {
   double* d_tw_fft = nullptr;      // FFT tables (kFftTwDoubles doubles)
   double* d_bk_ntt = nullptr;      // key in the NTT domain
   double* d_bk_fft = nullptr;      // key in the FFT domain
+  // general ring path (rs_general.h): every parameter set has it; sets outside the specialised N = 1024 kernels
+  // (`general`) have nothing else
+  bool general = false;
+  int logn = 10;
+  double split_bound = 0.0;        // a-priori error bound of the split-key product (< 1/4 or the mode is not offered)
+  double* d_tw_gen = nullptr;      // gen_make_twiddles(logn)
+  double* d_bk_gen = nullptr;      // split key in the FFT domain
   int32_t* d_ksk = nullptr;
   size_t bk_bytes = 0, ksk_bytes = 0;
   bool keys = false;
@@ -128,6 +138,7 @@ int lane_of(rs_ctx* c, hipStream_t st, Lane** out) {
   if (it != c->lanes.end()) { *out = it->second.get(); return RS_OK; }
   std::unique_ptr<Lane> ln(new Lane);
   ln->stream = st;
+  ln->sample_words = (size_t)c->p.N + 1;
   const size_t cert_bytes = sizeof(unsigned long long) * (kCertSlots + 2);
   if (hipMalloc(&ln->d_cert, cert_bytes) != hipSuccess || hipMemset(ln->d_cert, 0, cert_bytes) != hipSuccess ||
       (!c->opts.no_persist && hipMalloc(&ln->d_counter, 256) != hipSuccess)) {
@@ -146,7 +157,7 @@ int ensure_ws(Lane* ln, size_t B) {
   if (ln->d_u0) { (void)hipFree(ln->d_u0); ln->d_u0 = nullptr; }
   if (ln->d_u1) { (void)hipFree(ln->d_u1); ln->d_u1 = nullptr; }
   ln->ws_batch = 0;
-  const size_t bytes = B * (size_t)(rs::kN + 1) * sizeof(int32_t);
+  const size_t bytes = B * ln->sample_words * sizeof(int32_t);
   RS_HIP(hipMalloc(&ln->d_u0, bytes));
   RS_HIP(hipMalloc(&ln->d_u1, bytes));
   ln->ws_batch = B;
@@ -215,7 +226,20 @@ int run_bootstrap(rs_ctx* c, hipStream_t st, int32_t* out, const Combo* combos, 
   Combo cs[2];
   for (int k = 0; k < count; ++k) { cs[k] = combos[k]; cs[k].u = k == 0 ? ln->d_u0 : ln->d_u1; }
   if (c->timing) RS_HIP(hipEventRecord(ln->ev[0], st));
-  if (mode == RS_MODE_FFT) {
+  if (mode == RS_MODE_FFT_SPLIT) {
+    // exact by the a-priori bound of rs_general.h: nothing to certify, nothing to recompute
+    for (int k = 0; k < count; ++k) {
+      rs::GenArgs a;
+      a.in0 = cs[k].in0; a.in1 = cs[k].in1; a.c0 = cs[k].c0; a.c1 = cs[k].c1; a.bconst = cs[k].bconst; a.mu = mu;
+      a.bk_x = c->d_bk_gen; a.tw = c->d_tw_gen;
+      a.n = c->p.n; a.W = c->p.n + 1; a.l = c->p.bk_l; a.bgbit = c->p.bk_Bgbit; a.B = (long)B; a.u_out = cs[k].u;
+      a.lut = lut.table; a.lut_count = (int32_t)lut.count; a.lut_first = (int32_t)lut.first;
+      a.dev_flag = ln->d_cert + kCertSlots;   // running maximum only: a diagnostic against the bound
+      RS_HIP(rs::launch_gen_blind_rotate(c->logn, a, c->num_cus, st));
+    }
+    ln->last.form = rs::kFormGeneral; ln->last.waves_per_block = (c->p.N / 16) / 64;
+    ln->last.resident = std::min<long>((long)B, rs::gen_resident_ciphertexts(c->logn, c->num_cus));
+  } else if (mode == RS_MODE_FFT) {
     unsigned long long* slot = ln->d_cert + (ln->slot_next++ % kCertSlots);
     RS_HIP(hipMemsetAsync(slot, 0, sizeof *slot, st));
     for (int k = 0; k < count; ++k) {
@@ -241,7 +265,7 @@ int run_bootstrap(rs_ctx* c, hipStream_t st, int32_t* out, const Combo* combos, 
   if (out) {
     rs::KeyswitchArgs k;
     k.u0 = ln->d_u0; k.u1 = count == 2 ? ln->d_u1 : nullptr; k.bconst = ks_bconst; k.ksk = c->d_ksk;
-    k.W = c->p.n + 1; k.t = c->p.ks_t; k.basebit = c->p.ks_basebit; k.B = (long)B; k.out = out;
+    k.W = c->p.n + 1; k.t = c->p.ks_t; k.basebit = c->p.ks_basebit; k.B = (long)B; k.out = out; k.N = c->p.N;
     RS_HIP(rs::launch_keyswitch(k, st));
   }
   if (c->timing) { RS_HIP(hipEventRecord(ln->ev[2], st)); ln->ev_valid = true; }
@@ -250,6 +274,7 @@ int run_bootstrap(rs_ctx* c, hipStream_t st, int32_t* out, const Combo* combos, 
 
 void destroy_ctx(rs_ctx* c) {
   (void)hipFree(c->d_tw); (void)hipFree(c->d_tw_fft); (void)hipFree(c->d_bk_ntt); (void)hipFree(c->d_bk_fft); (void)hipFree(c->d_ksk);
+  (void)hipFree(c->d_tw_gen); (void)hipFree(c->d_bk_gen);
   for (auto& kv : c->lanes) free_lane(kv.second.get());
   for (auto& p : c->d_io) (void)hipFree(p);
   delete c;
@@ -262,7 +287,7 @@ bool env_on(const char* name) { const char* v = getenv(name); return v && *v && 
 extern "C" {
 
 const char* rs_last_error(void) { return g_err.c_str(); }
-const char* rs_version(void) { return "redsec_hip 0.3 (gfx950; fp64 fft with on-device exact recomputation + exact fp64-carried ntt)"; }
+const char* rs_version(void) { return "redsec_hip 0.4 (gfx950; fp64 fft with on-device exact recomputation + exact fp64-carried ntt + split-key fft, N up to 8192)"; }
 
 int rs_params_default128(rs_params* p) {
   if (!p) return fail(RS_ERR_INVALID, "null params");
@@ -275,15 +300,40 @@ int rs_params_redsec_small_v2(rs_params* p) {
   return RS_OK;
 }
 
+// client/gen_secure_keyset.cpp:9-68: the sets the reference defines beside the one it ships
+int rs_params_redsec_small(rs_params* p) {
+  if (!p) return fail(RS_ERR_INVALID, "null params");
+  *p = {500, 1024, 1, 3, 10, 18, 1};
+  return RS_OK;
+}
+int rs_params_redsec_medium(rs_params* p) {
+  if (!p) return fail(RS_ERR_INVALID, "null params");
+  *p = {3072, 4096, 1, 3, 10, 18, 1};
+  return RS_OK;
+}
+int rs_params_redsec_large(rs_params* p) {
+  if (!p) return fail(RS_ERR_INVALID, "null params");
+  *p = {6144, 8192, 1, 3, 10, 18, 1};
+  return RS_OK;
+}
+
 int rs_create(rs_ctx** out, const rs_params* p, int device) {
   if (!out || !p) return fail(RS_ERR_INVALID, "null argument");
   *out = nullptr;
-  if (p->N != rs::kN || p->k != 1) return fail(RS_ERR_INVALID, "unsupported ring: N=%d k=%d (need N=1024, k=1)", p->N, p->k);
-  if (p->n < 1 || p->n + 1 > 1024) return fail(RS_ERR_INVALID, "unsupported LWE dimension n=%d", p->n);
+  int logn = 0;
+  while ((1 << logn) < p->N) ++logn;
+  if (p->k != 1 || (1 << logn) != p->N || logn < rs::kGenMinLogN || logn > rs::kGenMaxLogN)
+    return fail(RS_ERR_INVALID, "unsupported ring: N=%d k=%d (need k=1 and N in {1024, 2048, 4096, 8192})", p->N, p->k);
+  if (p->n < 1 || p->n > 16384) return fail(RS_ERR_INVALID, "unsupported LWE dimension n=%d", p->n);
   if (p->ks_t < 1 || p->ks_basebit < 1 || p->ks_t * p->ks_basebit > 31) return fail(RS_ERR_INVALID, "bad keyswitch parameters");
-  rs::PrimeSpec ps;
-  if (!rs::prime_for(p->bk_l, p->bk_Bgbit, &ps))
-    return fail(RS_ERR_INVALID, "unsupported gadget l=%d Bgbit=%d (supported: 3/7, 10/3)", p->bk_l, p->bk_Bgbit);
+  if (p->bk_l < 1 || p->bk_Bgbit < 1 || p->bk_l * p->bk_Bgbit > 32) return fail(RS_ERR_INVALID, "bad gadget l=%d Bgbit=%d", p->bk_l, p->bk_Bgbit);
+  rs::PrimeSpec ps{};
+  // the specialised kernels (exact NTT and unsplit FFT) exist for N = 1024 with the two shipped gadgets; every other
+  // set runs on the general split-key path alone
+  const bool special = p->N == rs::kN && rs::prime_for(p->bk_l, p->bk_Bgbit, &ps);
+  const double split_bound = rs::gen_error_bound(logn, p->bk_l, p->bk_Bgbit);
+  if (!special && !(split_bound < 0.25))
+    return fail(RS_ERR_INVALID, "gadget l=%d Bgbit=%d on N=%d: split-key product bound %.3g is not below 1/4", p->bk_l, p->bk_Bgbit, p->N, split_bound);
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(RS_ERR_NO_DEVICE, "no HIP device visible");
   if (device < 0 || device >= count) return fail(RS_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, count);
@@ -291,14 +341,21 @@ int rs_create(rs_ctx** out, const rs_params* p, int device) {
   if (!c) return fail(RS_ERR_INVALID, "out of host memory");
   c->p = *p;
   c->device = device;
-  c->cfg = (p->bk_l == 3) ? 0 : 1;
-  const unsigned fwd_mask = c->cfg == 0 ? rs::CfgDefault128::FWD_MASK : rs::CfgRedsecV2::FWD_MASK;
-  const unsigned inv_mask = c->cfg == 0 ? rs::CfgDefault128::INV_MASK : rs::CfgRedsecV2::INV_MASK;
-  const int fuse = c->cfg == 0 ? rs::CfgDefault128::FUSE : rs::CfgRedsecV2::FUSE;
-  const bool mid = c->cfg == 0 ? rs::CfgDefault128::MID_REDUCE : rs::CfgRedsecV2::MID_REDUCE;
-  c->tables = rs::make_tables(ps, fuse);
-  const std::string why = rs::validate_schedule(c->tables.f.p, p->bk_l, p->bk_Bgbit, fwd_mask, inv_mask, fuse, mid);
-  if (!why.empty()) { destroy_ctx(c); return fail(RS_ERR_INVALID, "transform schedule not exact: %s", why.c_str()); }
+  c->general = !special;
+  c->logn = logn;
+  c->split_bound = split_bound;
+  c->cfg = special ? ((p->bk_l == 3) ? 0 : 1) : -1;
+  if (special) {
+    const unsigned fwd_mask = c->cfg == 0 ? rs::CfgDefault128::FWD_MASK : rs::CfgRedsecV2::FWD_MASK;
+    const unsigned inv_mask = c->cfg == 0 ? rs::CfgDefault128::INV_MASK : rs::CfgRedsecV2::INV_MASK;
+    const int fuse = c->cfg == 0 ? rs::CfgDefault128::FUSE : rs::CfgRedsecV2::FUSE;
+    const bool mid = c->cfg == 0 ? rs::CfgDefault128::MID_REDUCE : rs::CfgRedsecV2::MID_REDUCE;
+    c->tables = rs::make_tables(ps, fuse);
+    const std::string why = rs::validate_schedule(c->tables.f.p, p->bk_l, p->bk_Bgbit, fwd_mask, inv_mask, fuse, mid);
+    if (!why.empty()) { destroy_ctx(c); return fail(RS_ERR_INVALID, "transform schedule not exact: %s", why.c_str()); }
+  } else {
+    c->mode = RS_MODE_FFT_SPLIT;
+  }
   if (hipSetDevice(device) != hipSuccess) { destroy_ctx(c); return fail(RS_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device); }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
@@ -308,16 +365,29 @@ int rs_create(rs_ctx** out, const rs_params* p, int device) {
       return fail(RS_ERR_NO_DEVICE, "device %d is %s; this library ships gfx950 code only", device, prop.gcnArchName);
     }
   }
-  const std::vector<double> fft_tw = rs::make_fft_tables();
-  if (hipMalloc(&c->d_tw, sizeof(double) * rs::kTwTotal) != hipSuccess ||
-      hipMemcpy(c->d_tw, c->tables.tw.data(), sizeof(double) * rs::kTwTotal, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMalloc(&c->d_tw_fft, sizeof(double) * rs::kFftTwDoubles) != hipSuccess ||
-      hipMemcpy(c->d_tw_fft, fft_tw.data(), sizeof(double) * rs::kFftTwDoubles, hipMemcpyHostToDevice) != hipSuccess) {
-    destroy_ctx(c);   // releases whatever was allocated
-    return fail(RS_ERR_HIP, "twiddle table upload failed");
+  if (special) {
+    const std::vector<double> fft_tw = rs::make_fft_tables();
+    if (hipMalloc(&c->d_tw, sizeof(double) * rs::kTwTotal) != hipSuccess ||
+        hipMemcpy(c->d_tw, c->tables.tw.data(), sizeof(double) * rs::kTwTotal, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc(&c->d_tw_fft, sizeof(double) * rs::kFftTwDoubles) != hipSuccess ||
+        hipMemcpy(c->d_tw_fft, fft_tw.data(), sizeof(double) * rs::kFftTwDoubles, hipMemcpyHostToDevice) != hipSuccess) {
+      destroy_ctx(c);   // releases whatever was allocated
+      return fail(RS_ERR_HIP, "twiddle table upload failed");
+    }
+  }
+  if (split_bound < 0.25) {
+    std::vector<double> gtw((size_t)p->N);   // M complex entries
+    rs::gen_make_twiddles(logn, gtw.data());
+    if (hipMalloc(&c->d_tw_gen, sizeof(double) * gtw.size()) != hipSuccess ||
+        hipMemcpy(c->d_tw_gen, gtw.data(), sizeof(double) * gtw.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      destroy_ctx(c);
+      return fail(RS_ERR_HIP, "twiddle table upload failed");
+    }
   }
   // the environment is read here, once: launches never call getenv
-  if (const char* m = getenv("REDSEC_MODE")) c->mode = (strcmp(m, "exact") == 0 || strcmp(m, "ntt") == 0) ? 0 : 1;
+  if (const char* m = getenv("REDSEC_MODE")) {
+    if (special) c->mode = (strcmp(m, "exact") == 0 || strcmp(m, "ntt") == 0) ? RS_MODE_EXACT_NTT : (strcmp(m, "split") == 0 && c->d_tw_gen ? RS_MODE_FFT_SPLIT : RS_MODE_FFT);
+  }
   c->opts.no_coop = env_on("RS_NO_COOP"); c->opts.no_wg = env_on("RS_NO_WG"); c->opts.no_duo = env_on("RS_NO_DUO");
   c->opts.no_persist = env_on("RS_NO_PERSIST"); c->opts.no_conv_tiled = env_on("RS_NO_CONV_TILED");
   Lane* ln = nullptr;
@@ -340,26 +410,36 @@ int rs_load_keys(rs_ctx* c, const int32_t* bk, const int32_t* ksk) {
   if (!bk || !ksk) return fail(RS_ERR_INVALID, "null key pointer");
   const rs_params& p = c->p;
   const size_t n_polys = (size_t)p.n * (size_t)(2 * p.bk_l) * 2;
-  const size_t bk_words = n_polys * rs::kN;
-  const size_t ksk_words = (size_t)rs::kN * p.ks_t * ((size_t)1 << p.ks_basebit) * (size_t)(p.n + 1);
+  const size_t bk_words = n_polys * (size_t)p.N;
+  const size_t ksk_words = (size_t)p.N * p.ks_t * ((size_t)1 << p.ks_basebit) * (size_t)(p.n + 1);
   if (c->d_bk_ntt) { (void)hipFree(c->d_bk_ntt); c->d_bk_ntt = nullptr; }
   if (c->d_bk_fft) { (void)hipFree(c->d_bk_fft); c->d_bk_fft = nullptr; }
+  if (c->d_bk_gen) { (void)hipFree(c->d_bk_gen); c->d_bk_gen = nullptr; }
   if (c->d_ksk) { (void)hipFree(c->d_ksk); c->d_ksk = nullptr; }
   c->keys = false;
   int32_t* d_bk = nullptr;
   RS_HIP(hipMalloc(&d_bk, bk_words * sizeof(int32_t)));
   RS_HIP(hipMemcpy(d_bk, bk, bk_words * sizeof(int32_t), hipMemcpyHostToDevice));
-  // both transform domains are kept resident (62 + 62 MB default-128, 115 + 115 MB REDsec): the FFT mode's
-  // gated exact recomputation needs the NTT-domain key, and the mode can be switched per call
-  RS_HIP(hipMalloc(&c->d_bk_ntt, bk_words * sizeof(double)));
-  RS_HIP(hipMalloc(&c->d_bk_fft, bk_words * sizeof(double)));
-  RS_HIP(rs::launch_bk_transform(c->cfg, 0, d_bk, c->d_bk_ntt, c->d_tw, c->tables.f, c->tables.ninv, (long)n_polys, nullptr));
-  RS_HIP(rs::launch_bk_transform(c->cfg, 1, d_bk, c->d_bk_fft, c->d_tw_fft, c->tables.f, 0.0, (long)n_polys, nullptr));
+  c->bk_bytes = 0;
+  if (!c->general) {
+    // both transform domains are kept resident (62 + 62 MB default-128, 115 + 115 MB REDsec): the FFT mode's
+    // gated exact recomputation needs the NTT-domain key, and the mode can be switched per call
+    RS_HIP(hipMalloc(&c->d_bk_ntt, bk_words * sizeof(double)));
+    RS_HIP(hipMalloc(&c->d_bk_fft, bk_words * sizeof(double)));
+    RS_HIP(rs::launch_bk_transform(c->cfg, 0, d_bk, c->d_bk_ntt, c->d_tw, c->tables.f, c->tables.ninv, (long)n_polys, nullptr));
+    RS_HIP(rs::launch_bk_transform(c->cfg, 1, d_bk, c->d_bk_fft, c->d_tw_fft, c->tables.f, 0.0, (long)n_polys, nullptr));
+    c->bk_bytes = bk_words * sizeof(double);
+  }
+  if (c->d_tw_gen) {
+    // the split key: two transformed halves per polynomial (twice the bytes of one domain)
+    RS_HIP(hipMalloc(&c->d_bk_gen, 2 * bk_words * sizeof(double)));
+    RS_HIP(rs::launch_gen_bk_transform(c->logn, d_bk, c->d_bk_gen, c->d_tw_gen, (long)n_polys, c->num_cus, nullptr));
+    if (c->general) c->bk_bytes = 2 * bk_words * sizeof(double);
+  }
   RS_HIP(hipDeviceSynchronize());
   RS_HIP(hipFree(d_bk));
   RS_HIP(hipMalloc(&c->d_ksk, ksk_words * sizeof(int32_t)));
   RS_HIP(hipMemcpy(c->d_ksk, ksk, ksk_words * sizeof(int32_t), hipMemcpyHostToDevice));
-  c->bk_bytes = bk_words * sizeof(double);
   c->ksk_bytes = ksk_words * sizeof(int32_t);
   c->keys = true;
   return RS_OK;
@@ -446,7 +526,7 @@ int rs_bootstrap_wo_ks_dev(rs_ctx* c, int32_t* u, const int32_t* in, int32_t mu,
   Lane* ln = nullptr;
   rc = lane_of(c, st, &ln);
   if (rc) return rc;
-  RS_HIP(hipMemcpyAsync(u, ln->d_u0, B * (size_t)(rs::kN + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  RS_HIP(hipMemcpyAsync(u, ln->d_u0, B * ln->sample_words * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   return RS_OK;
 }
 
@@ -457,7 +537,7 @@ int rs_keyswitch_dev(rs_ctx* c, int32_t* out, const int32_t* u, size_t B, void* 
   if (!out || !u) return fail(RS_ERR_INVALID, "null ciphertext pointer");
   rs::KeyswitchArgs k;
   k.u0 = u; k.u1 = nullptr; k.bconst = 0; k.ksk = c->d_ksk;
-  k.W = c->p.n + 1; k.t = c->p.ks_t; k.basebit = c->p.ks_basebit; k.B = (long)B; k.out = out;
+  k.W = c->p.n + 1; k.t = c->p.ks_t; k.basebit = c->p.ks_basebit; k.B = (long)B; k.out = out; k.N = c->p.N;
   RS_HIP(rs::launch_keyswitch(k, (hipStream_t)stream));
   return RS_OK;
 }
@@ -519,15 +599,19 @@ int rs_debug_polymul(rs_ctx* c, int32_t* out, const int32_t* a_small, const int3
   Lane* ln = nullptr;
   rc = lane_of(c, nullptr, &ln);
   if (rc) return rc;
-  const size_t bytes = count * rs::kN * sizeof(int32_t);
+  const size_t bytes = count * (size_t)c->p.N * sizeof(int32_t);
   int32_t *da = nullptr, *db = nullptr, *dout = nullptr;
   double* scratch = nullptr;
   RS_HIP(hipMalloc(&da, bytes)); RS_HIP(hipMalloc(&db, bytes)); RS_HIP(hipMalloc(&dout, bytes));
-  RS_HIP(hipMalloc(&scratch, count * rs::kN * sizeof(double)));
+  RS_HIP(hipMalloc(&scratch, 2 * count * (size_t)c->p.N * sizeof(double)));
   RS_HIP(hipMemcpy(da, a_small, bytes, hipMemcpyHostToDevice));
   RS_HIP(hipMemcpy(db, b_torus, bytes, hipMemcpyHostToDevice));
-  RS_HIP(rs::launch_polymul(c->cfg, c->mode, da, db, dout, scratch, c->mode == 1 ? c->d_tw_fft : c->d_tw, c->tables.f, c->tables.ninv,
-                            (long)count, c->mode == 1 ? ln->d_cert + kCertSlots : nullptr, nullptr));
+  if (c->mode == RS_MODE_FFT_SPLIT) {
+    RS_HIP(rs::launch_gen_polymul(c->logn, da, db, dout, scratch, c->d_tw_gen, (long)count, ln->d_cert + kCertSlots, c->num_cus, nullptr));
+  } else {
+    RS_HIP(rs::launch_polymul(c->cfg, c->mode, da, db, dout, scratch, c->mode == 1 ? c->d_tw_fft : c->d_tw, c->tables.f, c->tables.ninv,
+                              (long)count, c->mode == 1 ? ln->d_cert + kCertSlots : nullptr, nullptr));
+  }
   RS_HIP(hipDeviceSynchronize());
   RS_HIP(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
   (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout); (void)hipFree(scratch);
@@ -536,8 +620,18 @@ int rs_debug_polymul(rs_ctx* c, int32_t* out, const int32_t* a_small, const int3
 
 int rs_set_mode(rs_ctx* c, int mode) {
   if (!c) return fail(RS_ERR_INVALID, "null context");
-  if (mode != RS_MODE_EXACT_NTT && mode != RS_MODE_FFT) return fail(RS_ERR_INVALID, "unknown mode %d", mode);
+  if (mode != RS_MODE_EXACT_NTT && mode != RS_MODE_FFT && mode != RS_MODE_FFT_SPLIT) return fail(RS_ERR_INVALID, "unknown mode %d", mode);
+  if (c->general && mode != RS_MODE_FFT_SPLIT)
+    return fail(RS_ERR_INVALID, "this parameter set (N=%d l=%d Bgbit=%d) runs on the split-key path only", c->p.N, c->p.bk_l, c->p.bk_Bgbit);
+  if (mode == RS_MODE_FFT_SPLIT && !c->d_tw_gen)
+    return fail(RS_ERR_INVALID, "split-key mode not offered for this set: a-priori bound %.3g", c->split_bound);
   c->mode = mode;
+  return RS_OK;
+}
+
+int rs_split_bound(rs_ctx* c, double* bound) {
+  if (!c || !bound) return fail(RS_ERR_INVALID, "null argument");
+  *bound = c->split_bound;
   return RS_OK;
 }
 

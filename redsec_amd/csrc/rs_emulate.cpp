@@ -7,8 +7,10 @@
 // library has no CPU compute path. Built by redsec_amd/build.py as librs_emulate.so.
 #include <cstdint>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
+#include "rs_general.h"
 #include "rs_host.h"
 #include "rs_ntt.h"
 
@@ -282,6 +284,114 @@ int emu_blind_rotate_fft(int n, const int32_t* in0, const int32_t* in1, int32_t 
   return 0;
 }
 
+
+// ---- general ring path (rs_general.h): the workgroup's threads run phase by phase, two arrays stand in for the LDS planes ----
+template <int LOGN>
+struct GenEmu {
+  using G = rs::Gen<LOGN>;
+  std::vector<double> tw, re, im;
+  std::vector<double> x;   // [T][16]
+  GenEmu() : tw((size_t)G::N), re(G::kPlane), im(G::kPlane), x((size_t)G::T * 16) { rs::gen_make_twiddles(LOGN, tw.data()); }
+  double (&regs(int t))[kRegs] { return *reinterpret_cast<double (*)[kRegs]>(&x[(size_t)t * 16]); }
+
+  template <int P>
+  void pass_fwd() {
+    if constexpr (P > 0) {
+      for (int t = 0; t < G::T; ++t) rs::gen_store<LOGN, P - 1, P - 1>(regs(t), t, re.data(), im.data());
+      for (int t = 0; t < G::T; ++t) rs::gen_load<LOGN, P, P - 1>(regs(t), t, re.data(), im.data());
+    }
+    for (int t = 0; t < G::T; ++t) {
+      rs::GenPassTw w;
+      rs::gen_pass_tw<LOGN, P>(w, t, tw.data());
+      rs::gen_pass_fwd<LOGN, P>(regs(t), w);
+    }
+    if constexpr (P + 1 < G::P) pass_fwd<P + 1>();
+  }
+  template <int P>
+  void pass_inv() {
+    for (int t = 0; t < G::T; ++t) {
+      rs::GenPassTw w;
+      rs::gen_pass_tw<LOGN, P>(w, t, tw.data());
+      rs::gen_pass_inv<LOGN, P>(regs(t), w);
+    }
+    if constexpr (P > 0) {
+      for (int t = 0; t < G::T; ++t) rs::gen_store<LOGN, P, P - 1>(regs(t), t, re.data(), im.data());
+      for (int t = 0; t < G::T; ++t) rs::gen_load<LOGN, P - 1, P - 1>(regs(t), t, re.data(), im.data());
+      pass_inv<P - 1>();
+    }
+  }
+  void load_poly(const int32_t* poly, int piece /* -1: as is, 0 lo, 1 hi */) {
+    for (int t = 0; t < G::T; ++t)
+      for (int r = 0; r < 16; ++r) {
+        const int32_t c = poly[t + G::T * (r & 7) + (r >> 3) * G::M];
+        int32_t lo = c, hi = c;
+        if (piece >= 0) rs::gen_split_key(c, lo, hi);
+        regs(t)[r] = (double)(piece == 1 ? hi : lo);
+      }
+  }
+  int polymul(const int32_t* a_small, const int32_t* b_torus, int32_t* out, double* max_dev) {
+    std::vector<double> key[2];
+    for (int piece = 0; piece < 2; ++piece) {
+      load_poly(b_torus, piece);
+      pass_fwd<0>();
+      key[piece].assign(x.begin(), x.end());
+    }
+    load_poly(a_small, -1);
+    pass_fwd<0>();
+    const std::vector<double> xa = x;
+    std::vector<uint32_t> acc((size_t)G::N, 0u);
+    double dev = 0.0;
+    for (int piece = 0; piece < 2; ++piece) {
+      for (int t = 0; t < G::T; ++t)
+        for (int r = 0; r < 8; ++r) {
+          double sr = 0.0, si = 0.0;
+          const size_t o = (size_t)t * 16 + r;
+          rs::fft_cmac(sr, si, xa[o], xa[o + 8], key[piece][o] * (1.0 / G::M), key[piece][o + 8] * (1.0 / G::M));
+          x[o] = sr; x[o + 8] = si;
+        }
+      pass_inv<G::P - 1>();
+      for (int t = 0; t < G::T; ++t)
+        for (int r = 0; r < 16; ++r) {
+          const int j = t + G::T * (r & 7) + (r >> 3) * G::M;
+          acc[j] += (uint32_t)rs::fft_round_torus32(regs(t)[r], dev) << (16 * piece);
+        }
+    }
+    for (int j = 0; j < G::N; ++j) out[j] = (int32_t)acc[j];
+    if (max_dev) *max_dev = dev;
+    return 0;
+  }
+  // (a) register r sits at register 0's position plus the compile-time offset the device code uses; (b) the 8-byte accesses
+  // of every 32-lane group hit 32 different bank pairs on both sides of every exchange. Returns the number of violations.
+  template <int XP>
+  static long layout_violations() {
+    long bad = 0;
+    if constexpr (XP + 1 < G::P) {
+      auto side = [&](auto lay_c) {
+        constexpr int LAY = decltype(lay_c)::value;
+        for (int r = 0; r < 8; ++r) {
+          for (int t = 0; t < G::T; ++t)
+            bad += rs::gen_phys(rs::gen_idx(t, G::H(LAY), r), G::H(XP + 1)) !=
+                   rs::gen_phys(rs::gen_idx(t, G::H(LAY), 0), G::H(XP + 1)) + rs::gen_reg_offset<LOGN, LAY, XP>(r);
+          for (int g = 0; g < G::T; g += 32) {
+            unsigned seen = 0;
+            for (int t = g; t < g + 32; ++t) {
+              const int pos = rs::gen_phys(rs::gen_idx(t, G::H(LAY), r), G::H(XP + 1));
+              if (pos < 0 || pos >= G::kPlane) ++bad;
+              const unsigned bit = 1u << (pos & 31);
+              if (seen & bit) ++bad;
+              seen |= bit;
+            }
+          }
+        }
+      };
+      side(std::integral_constant<int, XP>{});
+      side(std::integral_constant<int, XP + 1>{});
+      bad += layout_violations<XP + 1>();
+    }
+    return bad;
+  }
+};
+
 }  // namespace
 
 extern "C" {
@@ -425,6 +535,43 @@ uint64_t rs_emu_prime(int cfg) {
   rs::PrimeSpec ps;
   if (!rs::prime_for(cfg == 0 ? 3 : 10, cfg == 0 ? 7 : 3, &ps)) return 0;
   return ps.p;
+}
+
+
+// General ring path: split-key product through the device's own pass / exchange functions (rs_general.h)
+int rs_emu_gen_polymul(int logn, const int32_t* a_small, const int32_t* b_torus, int32_t* out, double* max_dev) {
+  switch (logn) {
+    case 10: return GenEmu<10>().polymul(a_small, b_torus, out, max_dev);
+    case 11: return GenEmu<11>().polymul(a_small, b_torus, out, max_dev);
+    case 12: return GenEmu<12>().polymul(a_small, b_torus, out, max_dev);
+    case 13: return GenEmu<13>().polymul(a_small, b_torus, out, max_dev);
+  }
+  return -1;
+}
+long rs_emu_gen_layout_violations(int logn) {
+  switch (logn) {
+    case 10: return GenEmu<10>::layout_violations<0>();
+    case 11: return GenEmu<11>::layout_violations<0>();
+    case 12: return GenEmu<12>::layout_violations<0>();
+    case 13: return GenEmu<13>::layout_violations<0>();
+  }
+  return -1;
+}
+double rs_emu_gen_error_bound(int logn, int l, int bgbit) { return rs::gen_error_bound(logn, l, bgbit); }
+// run-time gadget digits of the general path against TFHE's formula
+long rs_emu_gen_digit_mismatches(int l, int bgbit, uint32_t start, uint32_t step, long count) {
+  long bad = 0;
+  const uint32_t off = rs::gen_gadget_offset(l, bgbit);
+  uint32_t d = start;
+  for (long t = 0; t < count; ++t, d += step) {
+    const int32_t dx = rs::gen_gadget_prepare((int32_t)d, off);
+    for (int q = 0; q < l; ++q) {
+      const int decal = 32 - (q + 1) * bgbit;
+      const int32_t want = (int32_t)(((d + off) >> decal) & ((1u << bgbit) - 1u)) - (1 << (bgbit - 1));
+      bad += rs::gen_gadget_digit(dx, q, bgbit) != want;
+    }
+  }
+  return bad;
 }
 
 }  // extern "C"

@@ -1,0 +1,302 @@
+// rs_general.hip -- kernels of the general ring path (rs_general.h): N in {1024, 2048, 4096, 8192}, any gadget,
+// key split into two 16-bit halves so that the FP64 FFT product is exact by an a-priori bound (RS_MODE_FFT_SPLIT).
+//
+//   gen_bk_transform_kernel    key polynomial -> two transformed half polynomials (the bkFFT analogue)
+//   gen_blind_rotate_kernel    gate pre-combination + modswitch + n CMUX steps + sample extract
+//                              (tfhe_bootstrap_woKS_FFT / tfhe_blindRotateAndExtract_FFT; REDsec: lib/BinOps_enc.cpp:185,191)
+//   gen_polymul_kernel         debug/parity tap through the same transform path
+//
+// One workgroup of T = N/16 threads owns one ciphertext: its TRLWE accumulator (2 x N int32) and the two exchange
+// planes live in LDS (17 N bytes), every thread keeps 8 complex values of the transform in flight and the
+// 2 halves x 2 columns of pointwise sums in registers. Workgroups are persistent over the batch.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "rs_general.h"
+#include "rs_kernels.h"
+
+namespace rs {
+
+namespace {
+
+__device__ __forceinline__ void gen_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int T>
+__device__ __forceinline__ void gen_sync() {
+  if constexpr (T == 64) gen_wave_sync(); else __syncthreads();
+}
+
+__device__ __forceinline__ void gen_publish(double dev, unsigned long long* flag) {
+  if (!flag) return;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_xor(dev, off, 64);
+    dev = o > dev ? o : dev;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(flag, (unsigned long long)__double_as_longlong(dev));
+}
+
+}  // namespace
+
+template <int LOGN>
+__global__ __launch_bounds__(Gen<LOGN>::T) void gen_bk_transform_kernel(const int32_t* __restrict__ bk, double* __restrict__ bk_x,
+                                                                         const double* __restrict__ tw, long n_polys) {
+  using G = Gen<LOGN>;
+  constexpr int N = G::N, M = G::M, T = G::T;
+  __shared__ double s_re[G::kPlane], s_im[G::kPlane];
+  const int t = threadIdx.x;
+  auto sync = [] { gen_sync<T>(); };
+  for (long poly = blockIdx.x; poly < n_polys; poly += gridDim.x) {
+    const int32_t* src = bk + poly * N;
+#pragma unroll 1
+    for (int piece = 0; piece < 2; ++piece) {
+      double x[kRegs];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        int32_t lo, hi;
+        gen_split_key(src[t + T * r], lo, hi);
+        x[r] = (double)(piece ? hi : lo);
+        gen_split_key(src[t + T * r + M], lo, hi);
+        x[r + 8] = (double)(piece ? hi : lo);
+      }
+      gen_fft_fwd<LOGN>(x, t, tw, s_re, s_im, sync);
+      // [row pair index][piece][column][8][T] complex, scaled by 1/M (a power of two: exact)
+      double2* dst = reinterpret_cast<double2*>(bk_x) + ((size_t)(poly >> 1) * 4 + (size_t)piece * 2 + (size_t)(poly & 1)) * M;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) dst[r * T + t] = make_double2(x[r] * (1.0 / M), x[r + 8] * (1.0 / M));
+    }
+  }
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(Gen<LOGN>::T) void gen_blind_rotate_kernel(GenArgs a) {
+  using G = Gen<LOGN>;
+  constexpr int N = G::N, M = G::M, T = G::T;
+  __shared__ double s_re[G::kPlane], s_im[G::kPlane];
+  __shared__ int32_t s_acc[2][N];
+  const int t = threadIdx.x;
+  auto sync = [] { gen_sync<T>(); };
+  const int l = a.l, bgbit = a.bgbit, n = a.n;
+  const uint32_t goff = gen_gadget_offset(l, bgbit);
+  double dev = 0.0;
+
+  for (long ct = blockIdx.x; ct < a.B; ct += gridDim.x) {
+    const int32_t* row0 = a.in0 + ct * a.W;
+    const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
+    // gate pre-combination (0, bconst) + c0*in0 + c1*in1, evaluated word by word as it is consumed
+    auto word = [&](int i) -> int32_t {
+      uint32_t v = (uint32_t)a.c0 * (uint32_t)row0[i];
+      if (row1) v += (uint32_t)a.c1 * (uint32_t)row1[i];
+      return (int32_t)v;
+    };
+    {
+      const int32_t barb = gen_modswitch((int32_t)((uint32_t)word(n) + (uint32_t)a.bconst), LOGN);
+      const int rot = 2 * N - barb;   // in (0, 2N]
+      const int32_t* lut = a.lut ? a.lut + (size_t)((ct + a.lut_first) % a.lut_count) * N : nullptr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = t + T * (r & 7) + (r >> 3) * M;
+        s_acc[0][j] = 0;
+        if (!lut) {
+          s_acc[1][j] = gen_rotated_const(a.mu, j, rot, LOGN);
+        } else {   // (X^rot * lut)_j: the ciphertext's own test polynomial (tfhe_blindRotateAndExtract_FFT)
+          const int aa = rot & (N - 1), nb = (rot >> LOGN) & 1;
+          const uint32_t x = (uint32_t)lut[(j - aa) & (N - 1)];
+          s_acc[1][j] = (int32_t)((((j < aa) ? 1 : 0) ^ nb) ? 0u - x : x);
+        }
+      }
+    }
+    sync();
+
+    int32_t bara_next = gen_modswitch(word(0), LOGN);
+    for (int i = 0; i < n; ++i) {
+      const int32_t bara = __builtin_amdgcn_readfirstlane(bara_next);   // the same word in every thread
+      bara_next = (i + 1 < n) ? gen_modswitch(word(i + 1), LOGN) : 0;
+      if (bara == 0) continue;   // tfhe_blindRotate_FFT skips the identity CMUX (uniform over the workgroup)
+      double S[2][2][kRegs];     // [key half][column]
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int u = 0; u < kRegs; ++u) S[h][c][u] = 0.0;
+
+#pragma unroll 1
+      for (int comp = 0; comp < 2; ++comp) {
+        int32_t v[kRegs];   // prepared rotated difference of this component, shared by its l digit rows
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = t + T * (r & 7) + (r >> 3) * M;
+          v[r] = gen_gadget_prepare(gen_rotated_diff(s_acc[comp], j, bara, LOGN), goff);
+        }
+#pragma unroll 1
+        for (int q = 0; q < l; ++q) {
+          double x[kRegs];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) x[r] = (double)gen_gadget_digit(v[r], q, bgbit);
+          gen_fft_fwd<LOGN>(x, t, a.tw, s_re, s_im, sync);
+          const double2* kp = reinterpret_cast<const double2*>(a.bk_x) + ((size_t)i * 2 * l + (size_t)comp * l + q) * 4 * M;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            double2 w[4];   // both halves x both columns of this position
+#pragma unroll
+            for (int hc = 0; hc < 4; ++hc) w[hc] = kp[(size_t)hc * M + r * T + t];
+#pragma unroll
+            for (int hc = 0; hc < 4; ++hc) fft_cmac(S[hc >> 1][hc & 1][r], S[hc >> 1][hc & 1][r + 8], x[r], x[r + 8], w[hc].x, w[hc].y);
+          }
+        }
+      }
+
+      // every thread passed at least one barrier since its reads of the accumulator: the update cannot overtake them
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        gen_fft_inv<LOGN>(S[0][c], t, a.tw, s_re, s_im, sync);
+        gen_fft_inv<LOGN>(S[1][c], t, a.tw, s_re, s_im, sync);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = t + T * (r & 7) + (r >> 3) * M;
+          const uint32_t lo = (uint32_t)fft_round_torus32(S[0][c][r], dev);
+          const uint32_t hi = (uint32_t)fft_round_torus32(S[1][c][r], dev);
+          s_acc[c][j] = (int32_t)((uint32_t)s_acc[c][j] + lo + (hi << 16));
+        }
+      }
+      sync();
+    }
+
+    // tLweExtractLweSampleIndex(index 0): a'[0] = acc_a[0], a'[j] = -acc_a[N-j], b' = acc_b[0]
+    int32_t* out = a.u_out + ct * (N + 1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = t + T * (r & 7) + (r >> 3) * M;
+      out[j] = (j == 0) ? s_acc[0][0] : (int32_t)(0u - (uint32_t)s_acc[0][N - j]);
+    }
+    if (t == 0) out[N] = s_acc[1][0];
+    sync();   // the accumulator is re-initialised by the next ciphertext
+  }
+  gen_publish(dev, a.dev_flag);
+}
+
+// out = a_small * b_torus (negacyclic, mod 2^32) through key split, forward, pointwise, inverse, recombination
+template <int LOGN>
+__global__ __launch_bounds__(Gen<LOGN>::T) void gen_polymul_kernel(const int32_t* __restrict__ a_small, const int32_t* __restrict__ b_torus,
+                                                                    int32_t* __restrict__ out, double* __restrict__ scratch,
+                                                                    const double* __restrict__ tw, long count, unsigned long long* dev_flag) {
+  using G = Gen<LOGN>;
+  constexpr int N = G::N, M = G::M, T = G::T;
+  __shared__ double s_re[G::kPlane], s_im[G::kPlane];
+  const int t = threadIdx.x;
+  auto sync = [] { gen_sync<T>(); };
+  double dev = 0.0;
+  for (long idx = blockIdx.x; idx < count; idx += gridDim.x) {
+    const int32_t* pa = a_small + idx * N;
+    const int32_t* pb = b_torus + idx * N;
+    double2* key = reinterpret_cast<double2*>(scratch) + (size_t)idx * 2 * M;   // the two halves, in the key layout
+#pragma unroll 1
+    for (int piece = 0; piece < 2; ++piece) {
+      double x[kRegs];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int32_t lo, hi;
+        gen_split_key(pb[t + T * (r & 7) + (r >> 3) * M], lo, hi);
+        x[r] = (double)(piece ? hi : lo);
+      }
+      gen_fft_fwd<LOGN>(x, t, tw, s_re, s_im, sync);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) key[(size_t)piece * M + r * T + t] = make_double2(x[r] * (1.0 / M), x[r + 8] * (1.0 / M));
+    }
+    double xa[kRegs];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xa[r] = (double)pa[t + T * (r & 7) + (r >> 3) * M];
+    gen_fft_fwd<LOGN>(xa, t, tw, s_re, s_im, sync);
+    double S[2][kRegs];
+#pragma unroll
+    for (int piece = 0; piece < 2; ++piece) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const double2 w = key[(size_t)piece * M + r * T + t];   // this thread's own stores
+        S[piece][r] = 0.0; S[piece][r + 8] = 0.0;
+        fft_cmac(S[piece][r], S[piece][r + 8], xa[r], xa[r + 8], w.x, w.y);
+      }
+    }
+    gen_fft_inv<LOGN>(S[0], t, tw, s_re, s_im, sync);
+    gen_fft_inv<LOGN>(S[1], t, tw, s_re, s_im, sync);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = t + T * (r & 7) + (r >> 3) * M;
+      const uint32_t lo = (uint32_t)fft_round_torus32(S[0][r], dev);
+      const uint32_t hi = (uint32_t)fft_round_torus32(S[1][r], dev);
+      out[idx * N + j] = (int32_t)(lo + (hi << 16));
+    }
+    sync();
+  }
+  gen_publish(dev, dev_flag);
+}
+
+// ---- launchers ----
+// persistent grid: as many workgroups as the device keeps resident (asked from the runtime once per kernel)
+template <class K>
+static long gen_resident(K kernel, int threads, int num_cus) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  return (long)per_cu * num_cus;
+}
+static long gen_grid(int logn, long work, int num_cus) {
+  static long resident[kGenMaxLogN + 1] = {0};
+  if (resident[logn] == 0) {
+    const int T = (1 << logn) / 16;
+    switch (logn) {
+      case 10: resident[logn] = gen_resident(gen_blind_rotate_kernel<10>, T, num_cus); break;
+      case 11: resident[logn] = gen_resident(gen_blind_rotate_kernel<11>, T, num_cus); break;
+      case 12: resident[logn] = gen_resident(gen_blind_rotate_kernel<12>, T, num_cus); break;
+      default: resident[logn] = gen_resident(gen_blind_rotate_kernel<13>, T, num_cus); break;
+    }
+  }
+  return work < resident[logn] ? work : resident[logn];
+}
+long gen_resident_ciphertexts(int logn, int num_cus) { return gen_grid(logn, 1L << 40, num_cus); }
+
+hipError_t launch_gen_blind_rotate(int logn, const GenArgs& a, int num_cus, hipStream_t st) {
+  if (a.B <= 0) return hipSuccess;
+  const dim3 grid((unsigned)gen_grid(logn, a.B, num_cus)), block((1u << logn) / 16);
+  switch (logn) {
+    case 10: hipLaunchKernelGGL((gen_blind_rotate_kernel<10>), grid, block, 0, st, a); break;
+    case 11: hipLaunchKernelGGL((gen_blind_rotate_kernel<11>), grid, block, 0, st, a); break;
+    case 12: hipLaunchKernelGGL((gen_blind_rotate_kernel<12>), grid, block, 0, st, a); break;
+    case 13: hipLaunchKernelGGL((gen_blind_rotate_kernel<13>), grid, block, 0, st, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_gen_bk_transform(int logn, const int32_t* bk, double* bk_x, const double* tw, long n_polys, int num_cus, hipStream_t st) {
+  if (n_polys <= 0) return hipSuccess;
+  const dim3 grid((unsigned)std::min<long>(n_polys, 8L * num_cus)), block((1u << logn) / 16);
+  switch (logn) {
+    case 10: hipLaunchKernelGGL((gen_bk_transform_kernel<10>), grid, block, 0, st, bk, bk_x, tw, n_polys); break;
+    case 11: hipLaunchKernelGGL((gen_bk_transform_kernel<11>), grid, block, 0, st, bk, bk_x, tw, n_polys); break;
+    case 12: hipLaunchKernelGGL((gen_bk_transform_kernel<12>), grid, block, 0, st, bk, bk_x, tw, n_polys); break;
+    case 13: hipLaunchKernelGGL((gen_bk_transform_kernel<13>), grid, block, 0, st, bk, bk_x, tw, n_polys); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_gen_polymul(int logn, const int32_t* a_small, const int32_t* b_torus, int32_t* out, double* scratch, const double* tw,
+                              long count, unsigned long long* dev_flag, int num_cus, hipStream_t st) {
+  if (count <= 0) return hipSuccess;
+  const dim3 grid((unsigned)gen_grid(logn, count, num_cus)), block((1u << logn) / 16);
+  switch (logn) {
+    case 10: hipLaunchKernelGGL((gen_polymul_kernel<10>), grid, block, 0, st, a_small, b_torus, out, scratch, tw, count, dev_flag); break;
+    case 11: hipLaunchKernelGGL((gen_polymul_kernel<11>), grid, block, 0, st, a_small, b_torus, out, scratch, tw, count, dev_flag); break;
+    case 12: hipLaunchKernelGGL((gen_polymul_kernel<12>), grid, block, 0, st, a_small, b_torus, out, scratch, tw, count, dev_flag); break;
+    case 13: hipLaunchKernelGGL((gen_polymul_kernel<13>), grid, block, 0, st, a_small, b_torus, out, scratch, tw, count, dev_flag); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace rs

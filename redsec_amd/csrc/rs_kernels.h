@@ -45,7 +45,7 @@ struct LaunchOpts {
 };
 // What a blind-rotate launch actually ran: kernel form and how many ciphertexts share one sweep of the key
 // from L2/HBM (R of SURVEY.md section 8d).
-enum { kFormPerWave = 0, kFormWorkgroup = 1, kFormDuo = 2, kFormCoop2 = 3, kFormCoop4 = 4 };
+enum { kFormPerWave = 0, kFormWorkgroup = 1, kFormDuo = 2, kFormCoop2 = 3, kFormCoop4 = 4, kFormGeneral = 5 };
 struct LaunchInfo { int form = -1; int waves_per_block = 0; long resident = 0; };
 
 struct KeyswitchArgs {
@@ -56,6 +56,22 @@ struct KeyswitchArgs {
   int32_t W, t, basebit;
   long B;
   int32_t* out;         // [B][W]
+  int32_t N = kN;       // ring degree of the extracted samples (the tiled kernels are N = 1024 only)
+};
+
+// General ring path (rs_general.h / rs_general.hip): any N = 2^logn in [1024, 8192], any gadget, split key.
+struct GenArgs {
+  const int32_t* in0;   // [B][W]
+  const int32_t* in1;   // [B][W] or nullptr
+  int32_t c0, c1, bconst, mu;
+  const double* bk_x;   // [n][2l][2 halves][2 columns][8][N/16][2]
+  const double* tw;     // gen_make_twiddles(logn)
+  int32_t n, W, l, bgbit;
+  long B;
+  int32_t* u_out;       // [B][N+1]
+  const int32_t* lut = nullptr;   // programmable form, as in BlindRotateArgs
+  int32_t lut_count = 0, lut_first = 0;
+  unsigned long long* dev_flag = nullptr;   // optional: largest rounding distance (diagnostic; exactness does not depend on it)
 };
 
 struct ConvShape { int32_t H, Wd, Cin, Cout, fh, fw, stride_h, stride_w, off_h, off_w, Ho, Wo; };
@@ -67,6 +83,11 @@ hipError_t launch_blind_rotate(int cfg, int mode, const BlindRotateArgs& a, int 
 hipError_t launch_bk_transform(int cfg, int mode, const int32_t* bk, double* bk_x, const double* tw, Field f, double scale,
                                long n_polys, hipStream_t st);
 hipError_t launch_keyswitch(const KeyswitchArgs& a, hipStream_t st);
+hipError_t launch_gen_blind_rotate(int logn, const GenArgs& a, int num_cus, hipStream_t st);
+long gen_resident_ciphertexts(int logn, int num_cus);   // workgroups (= ciphertexts) the general kernel keeps resident
+hipError_t launch_gen_bk_transform(int logn, const int32_t* bk, double* bk_x, const double* tw, long n_polys, int num_cus, hipStream_t st);
+hipError_t launch_gen_polymul(int logn, const int32_t* a_small, const int32_t* b_torus, int32_t* out, double* scratch, const double* tw,
+                              long count, unsigned long long* dev_flag, int num_cus, hipStream_t st);
 hipError_t launch_polymul(int cfg, int mode, const int32_t* a_small, const int32_t* b_torus, int32_t* out, double* scratch,
                           const double* tw, Field f, double scale, long count, unsigned long long* dev_flag, hipStream_t st);
 hipError_t launch_lincomb(int32_t* out, const int32_t* x, int32_t cx, const int32_t* y, int32_t cy, int32_t bconst, int W, long B,

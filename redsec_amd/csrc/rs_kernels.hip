@@ -18,20 +18,21 @@ namespace rs {
 // form serves bootsMUX.
 // -------------------------------------------------------------------------------------------------
 constexpr int KS_THREADS = 256;
-constexpr int KS_MAXR = 4;  // output words per thread: W <= 1024
+constexpr int KS_MAXR = 4;  // output words per thread: a workgroup covers 1024 words, blockIdx.y walks wider samples
 
 __global__ __launch_bounds__(KS_THREADS) void keyswitch_kernel(KeyswitchArgs a) {
   const long ct = blockIdx.x;
   const int tid = threadIdx.x;
-  const int32_t* u0 = a.u0 + ct * (kN + 1);
-  const int32_t* u1 = a.u1 ? a.u1 + ct * (kN + 1) : nullptr;
+  const int N = a.N, w_base = (int)blockIdx.y * KS_THREADS * KS_MAXR;
+  const int32_t* u0 = a.u0 + ct * (N + 1);
+  const int32_t* u1 = a.u1 ? a.u1 + ct * (N + 1) : nullptr;
   uint32_t acc[KS_MAXR];
 #pragma unroll
   for (int k = 0; k < KS_MAXR; ++k) acc[k] = 0;
   const int W = a.W, t = a.t, basebit = a.basebit;
   const uint32_t prec_offset = 1u << (32 - (1 + basebit * t));
   const uint32_t mask = (1u << basebit) - 1u;
-  for (int i = 0; i < kN; ++i) {
+  for (int i = 0; i < N; ++i) {
     uint32_t ai = (uint32_t)u0[i];
     if (u1) ai += (uint32_t)u1[i];
     const uint32_t aibar = ai + prec_offset;
@@ -41,18 +42,18 @@ __global__ __launch_bounds__(KS_THREADS) void keyswitch_kernel(KeyswitchArgs a) 
       const int32_t* row = a.ksk + ((((size_t)i * t + j) << basebit) + dgt) * (size_t)W;
 #pragma unroll
       for (int k = 0; k < KS_MAXR; ++k) {
-        const int w = tid + k * KS_THREADS;
+        const int w = w_base + tid + k * KS_THREADS;
         if (w < W) acc[k] += (uint32_t)row[w];
       }
     }
   }
-  uint32_t bw = (uint32_t)u0[kN];
-  if (u1) bw += (uint32_t)u1[kN];
+  uint32_t bw = (uint32_t)u0[N];
+  if (u1) bw += (uint32_t)u1[N];
   bw += (uint32_t)a.bconst;
   int32_t* out = a.out + ct * W;
 #pragma unroll
   for (int k = 0; k < KS_MAXR; ++k) {
-    const int w = tid + k * KS_THREADS;
+    const int w = w_base + tid + k * KS_THREADS;
     if (w < W) out[w] = (int32_t)((w == W - 1 ? bw : 0u) - acc[k]);
   }
 }
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256) void sumpool_kernel(int32_t* __restrict__ out,
 hipError_t launch_keyswitch(const KeyswitchArgs& a, hipStream_t st) {
   if (a.B <= 0) return hipSuccess;
   dim3 grid((unsigned)((a.B + KS_TILE_THREADS - 1) / KS_TILE_THREADS), (unsigned)((a.W + KS_CH - 1) / KS_CH), 1);
-  const bool tiled = (a.t == 8 && a.basebit == 2) || (a.t == 9 && a.basebit == 3);
+  const bool tiled = a.N == kN && ((a.t == 8 && a.basebit == 2) || (a.t == 9 && a.basebit == 3));
   if (tiled) {
     // small batches: slice the input coefficients until ~1024 workgroups exist (latency form)
     unsigned split = 1;
@@ -391,12 +392,14 @@ hipError_t launch_keyswitch(const KeyswitchArgs& a, hipStream_t st) {
       grid.z = split;
     }
   }
-  if (a.t == 8 && a.basebit == 2) {
+  if (tiled && a.t == 8) {
     hipLaunchKernelGGL((keyswitch_tiled_kernel<8, 2, 4>), grid, dim3(KS_TILE_THREADS), 0, st, a);
-  } else if (a.t == 9 && a.basebit == 3) {
+  } else if (tiled) {
     hipLaunchKernelGGL((keyswitch_tiled_kernel<9, 3, 2>), grid, dim3(KS_TILE_THREADS), 0, st, a);
   } else {
-    hipLaunchKernelGGL(keyswitch_kernel, dim3((unsigned)a.B), dim3(KS_THREADS), 0, st, a);  // generic gather form
+    // generic gather form: any ring degree, any (t, basebit), any sample width
+    const unsigned wy = (unsigned)((a.W + KS_THREADS * KS_MAXR - 1) / (KS_THREADS * KS_MAXR));
+    hipLaunchKernelGGL(keyswitch_kernel, dim3((unsigned)a.B, wy), dim3(KS_THREADS), 0, st, a);
   }
   return hipGetLastError();
 }

@@ -17,8 +17,23 @@ def lib():
         L.rs_emu_forward.argtypes = [C.c_int, _i32p, C.POINTER(C.c_double)]
         L.rs_emu_digit_mismatches.restype = C.c_long
         L.rs_emu_digit_mismatches.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_long]
+        L.rs_emu_gen_layout_violations.restype = C.c_long
+        L.rs_emu_gen_error_bound.restype = C.c_double
+        L.rs_emu_gen_error_bound.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.rs_emu_gen_digit_mismatches.restype = C.c_long
+        L.rs_emu_gen_digit_mismatches.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_long]
+        L.rs_emu_gen_polymul.argtypes = [C.c_int, _i32p, _i32p, _i32p, C.POINTER(C.c_double)]
         _lib = L
     return _lib
+
+
+def gen_polymul(logn, a, b):
+    """Split-key product of the general ring path (rs_general.h) -> (product mod 2^32, largest rounding distance)."""
+    a = np.ascontiguousarray(a, np.int32); b = np.ascontiguousarray(b, np.int32)
+    out = np.zeros(1 << logn, np.int32)
+    dev = C.c_double(0)
+    assert lib().rs_emu_gen_polymul(logn, _p(a), _p(b), _p(out), C.byref(dev)) == 0
+    return out, dev.value
 
 
 def _p(a):

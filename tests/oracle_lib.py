@@ -53,6 +53,8 @@ def lib():
     P = C.POINTER(RoParams)
     L.ro_params_default128.argtypes = [P]
     L.ro_params_redsec_small_v2.argtypes = [P]
+    for f in (L.ro_params_redsec_small, L.ro_params_redsec_medium, L.ro_params_redsec_large):
+        f.argtypes = [P]
     for f in (L.ro_modswitch_to_torus32, L.ro_modswitch_from_torus32, L.ro_approx_phase):
         f.argtypes = [C.c_int32, C.c_int32]
         f.restype = C.c_int32
@@ -122,6 +124,16 @@ def params(name):
     elif name == "toy_redsec":
         lib().ro_params_redsec_small_v2(C.byref(p))
         p.n = 20
+    elif name in ("redsec_small", "redsec_medium", "redsec_large"):
+        getattr(lib(), "ro_params_" + name)(C.byref(p))
+    elif name in ("toy_small", "toy_medium", "toy_large"):
+        # the ring, gadget and keyswitch shape of the set, LWE dimension cut down so that keys generate in seconds
+        getattr(lib(), "ro_params_redsec_" + name[4:])(C.byref(p))
+        p.n = {"toy_small": 16, "toy_medium": 10, "toy_large": 6}[name]
+    elif name == "toy_n2048":
+        # a ring degree no shipped set uses: default-128 gadget on N = 2048
+        lib().ro_params_default128(C.byref(p))
+        p.n = 12; p.N = 2048
     else:
         raise KeyError(name)
     return p

@@ -35,15 +35,21 @@ def test_parameter_sets():
 
 def test_rejects_unsupported_parameters():
     L = redsec_amd.load_library()
-    p = redsec_amd.params("default128")
-    p.N = 2048
     h = ctypes.c_void_p()
-    assert L.rs_create(ctypes.byref(h), ctypes.byref(p), 0) == -1
-    assert b"unsupported ring" in L.rs_last_error()
-    p = redsec_amd.params("default128")
-    p.bk_l = 4
-    assert L.rs_create(ctypes.byref(h), ctypes.byref(p), 0) == -1
-    assert b"unsupported gadget" in L.rs_last_error()
+    for field, value, why in (("N", 512, b"unsupported ring"), ("N", 3072, b"unsupported ring"), ("N", 16384, b"unsupported ring"),
+                              ("k", 2, b"unsupported ring"), ("bk_l", 5, b"bad gadget"), ("ks_t", 16, b"bad keyswitch")):
+        p = redsec_amd.params("default128")
+        setattr(p, field, value)          # l * Bgbit = 35 > 32; t * basebit = 32 > 31
+        assert L.rs_create(ctypes.byref(h), ctypes.byref(p), 0) == -1, field
+        assert why in L.rs_last_error(), L.rs_last_error()
+
+
+def test_reference_parameter_sets_beside_the_shipped_one():
+    """client/gen_secure_keyset.cpp:9-68."""
+    for name, want in (("redsec_small", (500, 1024, 1, 3, 10, 18, 1)), ("redsec_medium", (3072, 4096, 1, 3, 10, 18, 1)),
+                       ("redsec_large", (6144, 8192, 1, 3, 10, 18, 1))):
+        r = redsec_amd.params(name)
+        assert (r.n, r.N, r.k, r.bk_l, r.bk_Bgbit, r.ks_t, r.ks_basebit) == want
 
 
 def test_no_cpu_fallback_without_gpu():

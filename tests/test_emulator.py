@@ -168,3 +168,41 @@ def test_signed_field_digits_equal_tfhe_decomposition(cfg):
     assert emu_lib.digit_mismatches(cfg, 0, 1, 1 << 16) == 0
     assert emu_lib.digit_mismatches(cfg, 0xFFFF0000, 1, 1 << 17) == 0
     assert emu_lib.digit_mismatches(cfg, 0x7FFF0000, 1, 1 << 17) == 0
+
+
+# ---- general ring path (csrc/rs_general.h): N = 1024 ... 8192, split key ----
+@pytest.mark.parametrize("logn", [10, 11, 12, 13])
+def test_general_path_layouts(logn):
+    """Every register of every exchange sits at register 0's position plus the compile-time offset the device code
+    uses, inside the padded plane, and each 32-lane group's 8-byte accesses fall into 32 different bank pairs."""
+    assert emu_lib.lib().rs_emu_gen_layout_violations(logn) == 0
+
+
+@pytest.mark.parametrize("logn,half", [(10, 512), (11, 64), (12, 512), (13, 512)])
+def test_general_path_split_product_is_exact(logn, half):
+    N = 1 << logn
+    rng = np.random.default_rng(logn)
+    a = rng.integers(-half, half, N).astype(np.int32)
+    b = rng.integers(-2**31, 2**31, N).astype(np.int32)
+    out, dev = emu_lib.gen_polymul(logn, a, b)
+    assert np.array_equal(out, ol.negacyclic_mul(a, b, "ntt"))
+    # operands of the largest 2-norm the bound allows for (random signs: the worst case for rounding)
+    a = np.where(rng.integers(0, 2, N) == 1, half - 1, -half).astype(np.int32)
+    b = np.where(rng.integers(0, 2, N) == 1, 0x7fff7fff, -0x80008000).astype(np.int32)
+    out, dev2 = emu_lib.gen_polymul(logn, a, b)
+    assert np.array_equal(out, ol.negacyclic_mul(a, b, "ntt"))
+    bgbit = int(np.log2(half)) + 1
+    bound = emu_lib.lib().rs_emu_gen_error_bound(logn, 1, bgbit)      # l = 1: two rows; one product is half of that
+    assert max(dev, dev2) < bound < 0.25
+
+
+def test_general_path_bound_covers_every_reference_parameter_set():
+    for logn, l, bgbit in ((10, 3, 7), (10, 10, 3), (10, 3, 10), (12, 3, 10), (13, 3, 10)):
+        assert emu_lib.lib().rs_emu_gen_error_bound(logn, l, bgbit) < 0.02
+
+
+@pytest.mark.parametrize("l,bgbit", [(3, 10), (3, 7), (10, 3), (2, 16), (4, 8)])
+def test_general_path_digits_equal_tfhe_decomposition(l, bgbit):
+    f = emu_lib.lib().rs_emu_gen_digit_mismatches
+    assert f(l, bgbit, 0x7ffffff0, 1, 64) == 0 and f(l, bgbit, 0xfffffff0, 1, 64) == 0      # the wrap-around boundaries
+    assert f(l, bgbit, 12345, 2654435761, 1 << 18) == 0

@@ -1,0 +1,128 @@
+"""GPU parity of the GENERAL ring path (csrc/rs_general.hip, RS_MODE_FFT_SPLIT) against the CPU oracle, word for word:
+the parameter sets client/gen_secure_keyset.cpp defines beside the one it ships (redsec_params_small / medium / large:
+N = 1024 / 4096 / 8192, l = 3, Bgbit = 10, keyswitch t = 18 basebit = 1), a ring degree no set uses (N = 2048), and the
+split-key mode on the two shipped sets. Keys with a reduced LWE dimension keep the oracle in seconds; one case runs
+redsec_params_small at its full n = 500."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+_CACHE = {}
+
+
+def _setup(toy, name, seed):
+    """(keys, oracle context, backend) for oracle parameter set `toy` on the backend's named set `name`."""
+    if toy not in _CACHE:
+        import torch
+        import redsec_amd
+        assert torch.cuda.is_available(), "GPU tests need a HIP device"
+        p = ol.params(toy)
+        ks = ol.KeySet(p, seed=seed)
+        bp = redsec_amd.params(name, n=p.n)
+        bp.N = p.N
+        be = redsec_amd.Backend(bp, device=0)
+        be.load_keys(ks.bk, ks.ksk)
+        _CACHE[toy] = (ks, ol.Ctx(ks), be)
+    return _CACHE[toy]
+
+
+SETS = [("toy_small", "redsec_small", 11), ("toy_n2048", "default128", 12), ("toy_medium", "redsec_medium", 13),
+        ("toy_large", "redsec_large", 14)]
+SPLIT_ON_SHIPPED = [("toy", "default128", 3), ("toy_redsec", "redsec_small_v2", 4)]
+
+
+def _dev(x):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(x, np.int32)).cuda()
+
+
+@pytest.mark.parametrize("toy,name,seed", SETS + SPLIT_ON_SHIPPED)
+def test_split_product_equals_the_exact_product(toy, name, seed):
+    ks, ctx, be = _setup(toy, name, seed)
+    be.set_mode("split")
+    N, half = ks.p.N, 1 << (ks.p.bk_Bgbit - 1)
+    rng = np.random.default_rng(seed)
+    a = rng.integers(-half, half, (6, N)).astype(np.int32)
+    b = rng.integers(-2**31, 2**31, (6, N)).astype(np.int32)
+    a[4] = -half; b[4] = -2**31                                         # largest magnitudes
+    a[5] = np.where(rng.integers(0, 2, N) == 1, half - 1, -half)        # largest 2-norms, random signs
+    b[5] = np.where(rng.integers(0, 2, N) == 1, 0x7fff7fff, -0x80008000)
+    be.rounding_certificate(reset=True)
+    out = be.polymul_host(a, b)
+    for i in range(6):
+        assert np.array_equal(out[i], ol.negacyclic_mul(a[i], b[i], "ntt")), i
+    # the measured rounding distance stays below the a-priori bound the mode's exactness rests on
+    assert be.rounding_certificate(reset=True) <= be.split_bound() < 0.25
+
+
+@pytest.mark.parametrize("toy,name,seed", SETS + SPLIT_ON_SHIPPED)
+def test_bootstraps_equal_the_oracle_word_for_word(toy, name, seed):
+    ks, ctx, be = _setup(toy, name, seed)
+    be.set_mode("split")
+    assert be.mode() == "split"
+    rng = np.random.default_rng(seed)
+    B = 9
+    e8 = ol.to_torus(1, 8)
+    alpha = 2.0 ** -20
+    ba, bb, bc = (rng.integers(0, 2, B) for _ in range(3))
+    ca, cb, cc = (ks.encrypt(np.where(v == 1, e8, -e8), alpha, 50 + k) for k, v in enumerate((ba, bb, bc)))
+    # blind rotation + extract, then the keyswitch, separately
+    u = be.bootstrap_wo_ks(_dev(ca), e8).cpu().numpy()
+    ref_u = ctx.bootstrap_wo_ks(ca, e8)
+    assert np.array_equal(u, ref_u)
+    assert np.array_equal(be.keyswitch(_dev(ref_u)).cpu().numpy(), ctx.keyswitch(ref_u))
+    # sign bootstrap, gates, MUX
+    got = be.bootstrap(_dev(ca), e8).cpu().numpy()
+    assert np.array_equal(got, ctx.bootstrap_batch(ca, e8))
+    assert np.array_equal((ks.phase(got) > 0).astype(int), ba)
+    for op, truth in (("NAND", 1 - (ba & bb)), ("XOR", ba ^ bb), ("ORNY", (1 - ba) | bb)):
+        g = be.gate(op, _dev(ca), _dev(cb)).cpu().numpy()
+        assert np.array_equal(g, ctx.gate_batch(op, ca, cb)), op
+        assert np.array_equal((ks.phase(g) > 0).astype(int), truth), op
+    m = be.mux(_dev(ca), _dev(cb), _dev(cc)).cpu().numpy()
+    assert np.array_equal(m, ctx.mux_batch(ca, cb, cc))
+    assert np.array_equal((ks.phase(m) > 0).astype(int), np.where(ba == 1, bb, bc))
+    # programmable bootstrap: three test polynomials shared round-robin
+    luts = rng.integers(-2**31, 2**31, (3, ks.p.N)).astype(np.int32)
+    lg = be.bootstrap_lut(_dev(ca), _dev(luts)).cpu().numpy()
+    assert np.array_equal(lg, ctx.bootstrap_lut_batch(ca, luts))
+
+
+def test_only_the_split_mode_exists_outside_the_specialised_kernels():
+    import redsec_amd
+    ks, ctx, be = _setup("toy_medium", "redsec_medium", 13)
+    for mode in ("fft", "exact"):
+        with pytest.raises(redsec_amd.RedsecHipError):
+            be.set_mode(mode)
+    assert be.mode() == "split" and be.last_launch()["form"] == "general"
+
+
+def test_redsec_params_small_at_full_size():
+    """redsec_params_small as the client would generate it (n = 500): sign bootstraps over the 4096-level message space."""
+    ks, ctx, be = _setup("redsec_small", "redsec_small", 21)
+    rng = np.random.default_rng(5)
+    ms = rng.integers(-1500, 1500, 12)
+    ms[np.abs(ms) < 64] += 200
+    ct = ks.encrypt([ol.to_torus(int(m), 4096) for m in ms], 2.0 ** -25, 7)
+    mu = ol.to_torus(1, 4096)
+    got = be.bootstrap(_dev(ct), mu).cpu().numpy()
+    assert np.array_equal(got, ctx.bootstrap_batch(ct, mu))
+    assert np.array_equal(ks.decrypt(got, 4096), np.where(ms > 0, mu, -mu))      # lweSymDecrypt returns the torus value
+
+
+def test_large_batch_fills_the_persistent_grid():
+    """More ciphertexts than resident workgroups (N = 2048: 4 per CU): every workgroup walks several of them."""
+    ks, ctx, be = _setup("toy_n2048", "default128", 12)
+    be.set_mode("split")
+    B = 2500
+    rng = np.random.default_rng(9)
+    e8 = ol.to_torus(1, 8)
+    bits = rng.integers(0, 2, B)
+    ct = ks.encrypt(np.where(bits == 1, e8, -e8), 2.0 ** -20, 3)
+    got = be.bootstrap(_dev(ct), e8).cpu().numpy()
+    assert np.array_equal((ks.phase(got) > 0).astype(int), bits)
+    pick = np.r_[0:8, 1270:1278, B - 8:B]
+    assert np.array_equal(got[pick], ctx.bootstrap_batch(ct[pick], e8))
