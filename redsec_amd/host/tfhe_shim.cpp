@@ -86,7 +86,8 @@ int32_t* alloc_words(size_t words, const char* what) {
 // a key file's header decides allocation sizes: refuse anything outside what the backend supports
 // before allocating (a truncated or foreign file must not turn into a multi-gigabyte malloc)
 void check_header(const ParamHeader& h, const char* what) {
-  const bool ok = h.N == 1024 && h.k == 1 && h.n >= 1 && h.n <= 1023 && h.l >= 1 && h.l <= 16 && h.Bgbit >= 1 &&
+  const bool ring = h.N == 1024 || h.N == 2048 || h.N == 4096 || h.N == 8192;   // what rs_create accepts
+  const bool ok = ring && h.k == 1 && h.n >= 1 && h.n <= 16384 && h.l >= 1 && h.l <= 16 && h.Bgbit >= 1 &&
                   h.l * h.Bgbit <= 32 && h.ks_t >= 1 && h.ks_basebit >= 1 && h.ks_t * h.ks_basebit <= 31;
   if (!ok) { fprintf(stderr, "redsec tfhe shim: implausible parameters in %s header\n", what); abort(); }
 }

@@ -126,3 +126,15 @@ def test_large_batch_fills_the_persistent_grid():
     assert np.array_equal((ks.phase(got) > 0).astype(int), bits)
     pick = np.r_[0:8, 1270:1278, B - 8:B]
     assert np.array_equal(got[pick], ctx.bootstrap_batch(ct[pick], e8))
+
+
+def test_reference_parameter_sets_through_the_cpp_mirror():
+    """tests/cpp/params_driver.cpp: TFHE-constructor parameter sets -> shim keygen -> TFHE-format key file -> gates, the
+    sign bootstrap and a BinLayer, decrypted with the secret key."""
+    import cppbuild
+    exe = cppbuild.build("params_driver")
+    if exe is None:
+        pytest.skip("no host compiler and no prebuilt test program")
+    r = cppbuild.run(exe)
+    assert r.returncode == 0 and "failures: 0" in r.stdout, r.stdout + r.stderr
+    assert r.stdout.count("PASS") == 12
