@@ -54,6 +54,15 @@ def fp64_ops_per_bootstrap_fft(n, l):
     return n * per_lane * 64
 
 
+def fp64_ops_per_bootstrap_split(n, l):
+    """Split-key FFT mode: the forward transforms of the FFT mode, twice its pointwise products (two key halves) and
+    four inverse transforms instead of two."""
+    fwd = 36 * 6 + 16
+    inv = 36 * 8 + 16 * 4
+    per_lane = 2 * l * (fwd + 2 * 2 * 8 * 4) + 4 * inv
+    return n * per_lane * 64
+
+
 def host_cpu_share():
     """CPUs granted to this process: the affinity mask, capped by the cgroup v2 / v1 CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -100,7 +109,7 @@ def main():
                          "overlapped with the next step's kernels (--no-gather leaves the slices where they are)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--params", default="default128", choices=["default128", "redsec_small_v2"])
-    ap.add_argument("--mode", default="fft", choices=["fft", "exact"],
+    ap.add_argument("--mode", default="fft", choices=["fft", "exact", "split"],
                     help="ring arithmetic of the blind rotation: fft = FP64 complex FFT rounded to the integer result, every call "
                          "followed by its certificate-gated exact recomputation on the device (library default); exact = NTT over "
                          "a 51-bit prime (exact by construction)")
@@ -254,6 +263,7 @@ def main():
     # batch compared word for word on the device (outside the timed region) ----
     all_equal_exact = None
     exact_mode = None
+    split_mode = None
     if args.mode == "fft" and not args.no_exact_check:
         be.set_mode("exact")
         ref_exact = be.gate("NAND", ca, cb)                      # warm-up + the reference result
@@ -273,6 +283,24 @@ def main():
             e_elapsed = float(tm.item())
         exact_mode = {"value": round(total_gates * esteps / e_elapsed, 1), "unit": "bootstraps/s", "ms_per_step": round(1e3 * e_elapsed / esteps, 3),
                       "steps": esteps, "note": "RS_MODE_EXACT_NTT (exact by construction), same batch, no gather"}
+        # ... and the split-key FFT mode (exact by an a-priori bound, include/redsec_hip.h): one step, whole batch compared
+        be.set_mode("split")
+        be.gate("NAND", ca, cb, out=ref_exact)
+        torch.cuda.synchronize()
+        split_equal = bool(torch.equal(ref_exact, out))
+        barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        be.gate("NAND", ca, cb, out=ref_exact)
+        torch.cuda.synchronize()
+        s_elapsed = time.perf_counter() - t1
+        if world > 1:
+            import torch.distributed as dist
+            tm = torch.tensor([s_elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            s_elapsed = float(tm.item())
+        split_mode = {"value": round(total_gates / s_elapsed, 1), "unit": "bootstraps/s", "ms_per_step": round(1e3 * s_elapsed, 3), "steps": 1,
+                      "all_words_equal_full_batch": split_equal, "a_priori_bound": be.split_bound(),
+                      "note": "RS_MODE_FFT_SPLIT (key in two 16-bit halves: exact by a worst-case bound), kernel form '%s'" % be.last_launch()["form"]}
         del ref_exact
         be.set_mode("fft")
 
@@ -309,14 +337,14 @@ def main():
             except Exception:
                 pass
         kernel_name = {"workgroup": "blind_rotate_wg_kernel", "duo": "blind_rotate_duo_kernel", "per_wave": "blind_rotate_kernel",
-                       "coop2": "blind_rotate_coop_kernel", "coop4": "blind_rotate_coop_kernel"}[launch["form"]]
+                       "coop2": "blind_rotate_coop_kernel", "coop4": "blind_rotate_coop_kernel", "general": "gen_blind_rotate_kernel"}[launch["form"]]
         roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel_ms": round(last_br, 3), "algorithmic_bytes_per_launch": int(alg_bytes),
                     "resident_ciphertexts_per_key_sweep": R, "waves_per_workgroup": launch["waves_per_block"]}
         fwd_red, inv_red, fused = (2, 3, 36) if p.bk_l == 3 else (0, 1, 48)
         ops_per = fp64_ops_per_bootstrap_fft(p.n, p.bk_l) if args.mode == "fft" else \
-            fp64_ops_per_bootstrap(p.n, p.bk_l, fwd_red, inv_red, fused)
+            (fp64_ops_per_bootstrap_split(p.n, p.bk_l) if args.mode == "split" else fp64_ops_per_bootstrap(p.n, p.bk_l, fwd_red, inv_red, fused))
         ops = ops_per * G
         valu = ops / (last_br * 1e-3) / 1e9
         roofline_valu = {"bound": "fp64-valu-issue", "achieved": round(valu, 1), "peak": round(FP64_VALU_PEAK_GOPS, 1),
@@ -366,13 +394,13 @@ def main():
         line = {
             "metric": "gate bootstraps/sec (N=1024)", "value": round(value, 1), "unit": "bootstraps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "int32 torus; ring products in f64 (%s)" % ("complex FFT, exact after rounding" if args.mode == "fft" else "exact NTT mod a 51-bit prime"),
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "int32 torus; ring products in f64 (%s)" % ({"fft": "complex FFT, exact after rounding", "exact": "exact NTT mod a 51-bit prime", "split": "complex FFT on a split key, exact by an a-priori bound"}[args.mode]),
             "data": "synthetic",
             "config": {"workload": "%d independent bootstrapped NAND gates per GPU per step, %s (n=%d N=%d l=%d Bgbit=%d t=%d basebit=%d)"
                                    % (G, args.params, p.n, p.N, p.bk_l, p.bk_Bgbit, p.ks_t, p.ks_basebit),
                        "gates_per_gpu": G, "total_gates": total_gates, "params": args.params, "mode": args.mode,
                        "parallelism": "gate-sharded x%d%s" % (world, "" if world == 1 else (", outputs all-gathered over RCCL, overlapped with the next step" if gather else ", no gather"))},
-            "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu, "exact_mode": exact_mode,
+            "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu, "exact_mode": exact_mode, "split_mode": split_mode,
             "collective": None if not gather else {"op": "all_gather_into_tensor", "bytes_per_rank": int(width_rows * be.W * 4),
                                                    "bytes_received_per_rank": int(world * width_rows * be.W * 4),
                                                    "ms_alone_unoverlapped": round(gather_ms, 3), "inside_timed_region": True,
