@@ -228,7 +228,16 @@ int run_bootstrap(rs_ctx* c, hipStream_t st, int32_t* out, const Combo* combos, 
   if (c->timing) RS_HIP(hipEventRecord(ln->ev[0], st));
   if (mode == RS_MODE_FFT_SPLIT) {
     // exact by the a-priori bound of rs_general.h: nothing to certify, nothing to recompute
+    bool split_wg = false;
     for (int k = 0; k < count; ++k) {
+      if (!c->general && !c->opts.no_wg) {
+        // N = 1024 with a shipped gadget at throughput batch sizes: lock-step workgroups on the split key
+        rs::BlindRotateArgs w = br_args(c, ln, 1, cs[k], mu, lut, B);
+        w.bk_x = c->d_bk_gen;
+        const hipError_t e = rs::launch_blind_rotate_split_wg(c->cfg, w, c->num_cus, st, &ln->last);
+        if (e == hipSuccess) { split_wg = true; continue; }
+        if (e != hipErrorNotSupported) return fail(RS_ERR_HIP, "split workgroup launch failed: %s", hipGetErrorString(e));
+      }
       rs::GenArgs a;
       a.in0 = cs[k].in0; a.in1 = cs[k].in1; a.c0 = cs[k].c0; a.c1 = cs[k].c1; a.bconst = cs[k].bconst; a.mu = mu;
       a.bk_x = c->d_bk_gen; a.tw = c->d_tw_gen;
@@ -237,8 +246,10 @@ int run_bootstrap(rs_ctx* c, hipStream_t st, int32_t* out, const Combo* combos, 
       a.dev_flag = ln->d_cert + kCertSlots;   // running maximum only: a diagnostic against the bound
       RS_HIP(rs::launch_gen_blind_rotate(c->logn, a, c->num_cus, st));
     }
-    ln->last.form = rs::kFormGeneral; ln->last.waves_per_block = (c->p.N / 16) / 64;
-    ln->last.resident = std::min<long>((long)B, rs::gen_resident_ciphertexts(c->logn, c->num_cus));
+    if (!split_wg) {
+      ln->last.form = rs::kFormGeneral; ln->last.waves_per_block = (c->p.N / 16) / 64;
+      ln->last.resident = std::min<long>((long)B, rs::gen_resident_ciphertexts(c->logn, c->num_cus));
+    }
   } else if (mode == RS_MODE_FFT) {
     unsigned long long* slot = ln->d_cert + (ln->slot_next++ % kCertSlots);
     RS_HIP(hipMemsetAsync(slot, 0, sizeof *slot, st));

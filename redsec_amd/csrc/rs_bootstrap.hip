@@ -690,6 +690,184 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
 }
 
 // -------------------------------------------------------------------------------------------------
+// Blind rotation, lock-step workgroup form on the SPLIT key (RS_MODE_FFT_SPLIT at throughput batch sizes, N = 1024).
+// Same structure as blind_rotate_wg_kernel -- 8 waves walk 8 ciphertexts in lock step and share the key through LDS --
+// but every key row comes as two 16 KB half-rows (the low and the high 16-bit half of the key, rs_general.h), each
+// multiplied into its own pair of column sums: four inverse transforms per CMUX step instead of two, and the result
+// acc += round(lo) + (round(hi) << 16) is exact by the a-priori bound of rs_general.h (no certificate).
+// Four accumulators leave registers for ONE digit transform in flight (the unsplit kernel pairs them); the inverse
+// transforms still run as software-pipelined pairs. LDS: 3 ring slots of 16 KB (the accumulators and exchange planes
+// of 8 ciphertexts leave room for no more), so `bara` lives in a 64-step window refilled from global memory.
+// Half-row h sits in slot h mod 3 and is requested two half-rows ahead: the barrier that publishes h also says every
+// wave has finished h - 1, whose slot then takes h + 2.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mac_half_stream(double (&s0)[kRegs], double (&s1)[kRegs], const double (&x)[kRegs], const double* key, int lane) {
+  const double2* k0 = reinterpret_cast<const double2*>(key);
+  const double2* k1 = k0 + kN / 2;
+  double2 u[2][4];
+  auto issue = [&](int step, double2 (&w)[4]) {
+    const int v = 2 * step;
+    w[0] = k0[v * 64 + lane]; w[1] = k0[(v + 1) * 64 + lane];
+    w[2] = k1[v * 64 + lane]; w[3] = k1[(v + 1) * 64 + lane];
+  };
+  auto fma = [&](int step, const double2 (&w)[4]) {
+    const int v = 2 * step;
+    fft_cmac(s0[v], s0[v + 8], x[v], x[v + 8], w[0].x, w[0].y);
+    fft_cmac(s0[v + 1], s0[v + 9], x[v + 1], x[v + 9], w[1].x, w[1].y);
+    fft_cmac(s1[v], s1[v + 8], x[v], x[v + 8], w[2].x, w[2].y);
+    fft_cmac(s1[v + 1], s1[v + 9], x[v + 1], x[v + 9], w[3].x, w[3].y);
+  };
+  issue(0, u[0]);
+#pragma unroll
+  for (int step = 0; step < 4; ++step) {
+    if (step + 1 < 4) issue(step + 1, u[(step + 1) & 1]);
+    RS_MAC_FENCE();
+    fma(step, u[step & 1]);
+    RS_MAC_FENCE();
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(512) void blind_rotate_wgs_kernel(BlindRotateArgs a) {
+  using Xf = XfFft<C>;
+  constexpr int WPB = 8;
+  constexpr int KPL = 2 * C::L;
+  constexpr int kSlotDoubles = 2 * kN;   // one key half-row: 2 columns x N doubles = 16 KB
+  constexpr int kWin = 64;
+  __shared__ double s_tw[Xf::kTableDoubles + 1];
+  __shared__ double s_buf[WPB][Xf::kWgBufDoubles];
+  __shared__ int32_t s_acc[WPB][2][kN];
+  __shared__ __attribute__((aligned(16))) double s_key[3][kSlotDoubles];
+  __shared__ uint16_t s_bara[WPB][kWin];
+  stage_tables(s_tw, a.tw, 64 * WPB, Xf::kTableDoubles);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  double* buf = s_buf[wave];
+  int32_t* acc0 = s_acc[wave][0];
+  int32_t* acc1 = s_acc[wave][1];
+  typename Xf::State tw;
+  Xf::init(tw, lane, s_tw, a.tw);
+  const int n = a.n;
+  const long n_groups = (a.B + WPB - 1) / WPB;
+  const long total_half = (long)n * KPL * 2;
+  const unsigned lane_off = (unsigned)lane * 16u;
+  auto sync_w = [] { wave_lds_sync(); };
+
+  for (long group = blockIdx.x; group < n_groups; group += gridDim.x) {
+    const long ct = group * WPB + wave;
+    const bool active = ct < a.B;
+    const int32_t* row0 = a.in0 + (active ? ct : 0) * a.W;
+    const int32_t* row1 = a.in1 ? a.in1 + (active ? ct : 0) * a.W : nullptr;
+    auto word = [&](int i) -> int32_t {
+      uint32_t v = (uint32_t)a.c0 * (uint32_t)row0[i];
+      if (row1) v += (uint32_t)a.c1 * (uint32_t)row1[i];
+      return (int32_t)v;
+    };
+    auto fill_window = [&](int i0) {   // bara of steps [i0, i0 + 64): only this wave reads its row
+      const int i = i0 + lane;
+      s_bara[wave][lane] = (active && i < n) ? (uint16_t)modswitch_2N(word(i)) : (uint16_t)0;
+    };
+    if (active) {
+      const int32_t barb = modswitch_2N((int32_t)((uint32_t)word(n) + (uint32_t)a.bconst));
+      const int rot = 2 * kN - barb;  // in (0, 2N]
+#pragma unroll
+      for (int r = 0; r < kRegs; ++r) {
+        const int j = lane + 64 * r;
+        acc0[j] = 0;
+        acc1[j] = test_vector(a, ct, j, rot);
+      }
+    }
+    fill_window(0);
+    // every wave has left the previous group's last multiply-accumulate before the ring is refilled
+    __syncthreads();
+    long h_issue = 0;        // next half-row to request
+    int slot_issue = 0;      // its slot, h_issue mod 3
+    auto issue_next = [&]() {
+      if (h_issue < total_half) {
+        glds_chunks<2>(a.bk_x + (size_t)h_issue * kSlotDoubles + (size_t)(wave * 2) * 128, lane_off, s_key[slot_issue] + (wave * 2) * 128);
+        ++h_issue;
+        slot_issue = slot_issue == 2 ? 0 : slot_issue + 1;
+      }
+    };
+    issue_next();
+    issue_next();
+    long h = 0;              // half-row consumed next
+    int slot = 0;
+    // publishes half-row h (every wave first waits for its own share: at most the next half-row's two loads may still
+    // be in flight) and frees the slot of h - 1 for h + 2
+    // (a bare s_barrier behind explicit counts: __syncthreads() would drain every outstanding load, i.e. also the
+    // half-row requested one barrier ago, and with it half of the prefetch distance)
+    auto publish = [&]() {
+      if (h + 1 < total_half) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      issue_next();
+    };
+    auto consumed = [&]() { ++h; slot = slot == 2 ? 0 : slot + 1; };
+
+    for (int i = 0; i < n; ++i) {
+      if ((i & (kWin - 1)) == 0 && i > 0) { wave_lds_sync(); fill_window(i); }
+      wave_lds_sync();
+      const int32_t bara = __builtin_amdgcn_readfirstlane((int)s_bara[wave][i & (kWin - 1)]);
+      const bool work = bara != 0;   // tfhe_blindRotate_FFT skips the identity CMUX (the barriers still run)
+      double sl0[kRegs], sl1[kRegs], sh0[kRegs], sh1[kRegs];
+#pragma unroll
+      for (int u = 0; u < kRegs; ++u) { sl0[u] = 0.0; sl1[u] = 0.0; sh0[u] = 0.0; sh1[u] = 0.0; }
+      int32_t d[kRegs];
+      auto load_d = [&](auto comp_c) {
+        const int32_t* accc = decltype(comp_c)::value ? acc1 : acc0;
+#pragma unroll
+        for (int r = 0; r < kRegs; ++r) d[r] = gadget_prepare<C>(rotated_diff(accc, lane + 64 * r, bara));
+      };
+      auto row = [&](int q) {
+        double x[kRegs];
+        if (work) {
+          Xf::digits(x, d, q);
+          ffwd_planar(lane, x, tw, buf, sync_w);
+        }
+        publish();
+        if (work) mac_half_stream(sl0, sl1, x, s_key[slot], lane);
+        consumed();
+        publish();
+        if (work) mac_half_stream(sh0, sh1, x, s_key[slot], lane);
+        consumed();
+      };
+      if (work) load_d(std::false_type{});
+#pragma unroll 1
+      for (int q = 0; q < C::L; ++q) row(q);
+      if (work) load_d(std::true_type{});
+#pragma unroll 1
+      for (int q = 0; q < C::L; ++q) row(q);
+
+      if (work) {
+        Xf::inverse_pair_wg(lane, sl0, sl1, tw, buf);
+        uint32_t lo0[kRegs], lo1[kRegs];
+#pragma unroll
+        for (int r = 0; r < kRegs; ++r) { lo0[r] = (uint32_t)f_to_torus32(sl0[r]); lo1[r] = (uint32_t)f_to_torus32(sl1[r]); }
+        Xf::inverse_pair_wg(lane, sh0, sh1, tw, buf);
+#pragma unroll
+        for (int r = 0; r < kRegs; ++r) {
+          const int j = lane + 64 * r;
+          acc0[j] = (int32_t)((uint32_t)acc0[j] + lo0[r] + ((uint32_t)f_to_torus32(sh0[r]) << 16));
+          acc1[j] = (int32_t)((uint32_t)acc1[j] + lo1[r] + ((uint32_t)f_to_torus32(sh1[r]) << 16));
+        }
+        wave_lds_sync();
+      }
+    }
+
+    if (active) {
+      // tLweExtractLweSampleIndex(index 0): a'[0] = acc_a[0], a'[j] = -acc_a[N-j], b' = acc_b[0]
+      int32_t* out = a.u_out + ct * (kN + 1);
+#pragma unroll
+      for (int r = 0; r < kRegs; ++r) {
+        const int j = lane + 64 * r;
+        out[j] = (j == 0) ? acc0[0] : (int32_t)(0u - (uint32_t)acc0[kN - j]);
+      }
+      if (lane == 0) out[kN] = acc1[0];
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
 // Blind rotation, "duo" workgroup form (mid-size batches: 2 x #CUs < B < 8 x #CUs, even l).
 // One wave per ciphertext leaves half the wave slots empty there and every wave streams the whole key
 // by itself (the 1,024-neuron MNIST layer was bound by ~10 TB/s of key reads). Here a workgroup is
@@ -1099,6 +1277,18 @@ hipError_t launch_blind_rotate(int cfg, int mode, const BlindRotateArgs& a, int 
   }
   return cfg == 0 ? launch_br_xf<XfFft<CfgDefault128>>(a, wpb, num_cus, false, opts, st, info)
                   : launch_br_xf<XfFft<CfgRedsecV2>>(a, wpb, num_cus, true, opts, st, info);
+}
+
+// Split-key workgroup form (N = 1024, the two shipped gadgets, B >= 8 x #CUs): a.bk_x = the split key of rs_general.h,
+// a.tw = the FFT tables of rs_fft.h. Returns hipErrorNotSupported when the batch is too small (caller: general kernel).
+hipError_t launch_blind_rotate_split_wg(int cfg, const BlindRotateArgs& a, int num_cus, hipStream_t st, LaunchInfo* info) {
+  if (a.B < 8L * num_cus) return hipErrorNotSupported;
+  const long groups = (a.B + 7) / 8;
+  const long grid = groups < num_cus ? groups : num_cus;
+  if (cfg == 0) hipLaunchKernelGGL((blind_rotate_wgs_kernel<CfgDefault128>), dim3((unsigned)grid), dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((blind_rotate_wgs_kernel<CfgRedsecV2>), dim3((unsigned)grid), dim3(512), 0, st, a);
+  if (info) { info->form = kFormSplitWorkgroup; info->waves_per_block = 8; info->resident = 8 * grid; }
+  return hipGetLastError();
 }
 
 hipError_t launch_bk_transform(int cfg, int mode, const int32_t* bk, double* bk_x, const double* tw, Field f, double scale,

@@ -412,6 +412,15 @@ RS_HD void finv_planar(int lane, double (&x)[kRegs], const TW& t, double* buf, S
   fpl_exchange<kLayB, kLayA, 1>(lane, x, buf, sync);
   fft_stage_inv<2>(x, t); fft_stage_inv<1>(x, t); fft_stage_inv<0>(x, t);
 }
+// single forward transform, planar exchanges (split-key workgroup kernel)
+template <class TW, class Sync>
+RS_HD void ffwd_planar(int lane, double (&x)[kRegs], const TW& t, double* buf, Sync sync) {
+  fft_fwd3_ahead<0>(x, t);
+  fpl_exchange<kLayA, kLayB, 1>(lane, x, buf, sync);
+  fft_fwd3_ahead<1>(x, t);
+  fpl_exchange<kLayB, kLayC, 2>(lane, x, buf, sync);
+  fft_fwd3_ahead<2>(x, t);
+}
 template <bool PLANAR, class TW, class Sync>
 RS_HD void ffwd_pair(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TW& t, double* buf, Sync sync) {
   fft_fwd3<0>(xa, t);

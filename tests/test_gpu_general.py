@@ -138,3 +138,45 @@ def test_reference_parameter_sets_through_the_cpp_mirror():
     r = cppbuild.run(exe)
     assert r.returncode == 0 and "failures: 0" in r.stdout, r.stdout + r.stderr
     assert r.stdout.count("PASS") == 12
+
+
+@pytest.mark.parametrize("toy,name,seed", SPLIT_ON_SHIPPED)
+def test_split_workgroup_kernel_ragged_groups_and_identity_steps(toy, name, seed):
+    """blind_rotate_wgs_kernel (split key, 8 ciphertexts per lock-step workgroup, three-slot key ring, windowed mask
+    words) on a batch that spills past one group per workgroup with a ragged last group, with mask words forced to 0
+    so that some CMUX steps are the identity: equal word for word to the exact-NTT mode on the device and, on a sample
+    drawn from the first, a middle and the ragged last group, to the oracle. n = 20 / 24 < 64 exercises a partial mask
+    window; the full-size keys of bench.py (n = 630) walk ten windows."""
+    import torch
+    ks, ctx, be = _setup(toy, name, seed)
+    cus = be.info()["num_cus"]
+    B = 16 * cus + 3
+    rng = np.random.default_rng(77)
+    e8 = ol.to_torus(1, 8)
+    bits = rng.integers(0, 2, B)
+    ct = ks.encrypt(np.where(bits == 1, e8, -e8), 2.0 ** -15, 4242).copy()
+    ct[5, :3] = 0
+    ct[6, 1::2] = 0
+    ct[B - 1, -3:-1] = 0
+    ct[B - 2, : ks.p.n] = 0
+    d = _dev(ct)
+    be.set_mode("split")
+    got = be.bootstrap(d, e8)
+    assert be.last_launch()["form"] == "split_workgroup"
+    be.set_mode("exact")
+    ref = be.bootstrap(d, e8)
+    be.set_mode("split")
+    assert torch.equal(got, ref)
+    sample = np.r_[0:8, 8 * cus:8 * cus + 8, B - 11:B]
+    assert np.array_equal(got.cpu().numpy()[sample], ctx.bootstrap_batch(ct[sample], e8))
+    # gates (two inputs) and the programmable form through the same kernel
+    cb = ks.encrypt(np.where(rng.integers(0, 2, B) == 1, e8, -e8), 2.0 ** -15, 99)
+    g = be.gate("XNOR", d, _dev(cb))
+    be.set_mode("exact")
+    assert torch.equal(g, be.gate("XNOR", d, _dev(cb)))
+    be.set_mode("split")
+    luts = _dev(rng.integers(-2**31, 2**31, (5, ks.p.N)).astype(np.int32))
+    lg = be.bootstrap_lut(d, luts)
+    be.set_mode("exact")
+    assert torch.equal(lg, be.bootstrap_lut(d, luts))
+    be.set_mode("split")
