@@ -798,8 +798,12 @@ __global__ __launch_bounds__(512) void blind_rotate_wgs_kernel(BlindRotateArgs a
     // (a bare s_barrier behind explicit counts: __syncthreads() would drain every outstanding load, i.e. also the
     // half-row requested one barrier ago, and with it half of the prefetch distance)
     auto publish = [&]() {
+#ifdef RS_WGS_DRAIN   // A/B: wait for every outstanding load, as __syncthreads() would
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
       if (h + 1 < total_half) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
       issue_next();
     };
     auto consumed = [&]() { ++h; slot = slot == 2 ? 0 : slot + 1; };

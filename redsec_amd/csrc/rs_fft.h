@@ -415,11 +415,19 @@ RS_HD void finv_planar(int lane, double (&x)[kRegs], const TW& t, double* buf, S
 // single forward transform, planar exchanges (split-key workgroup kernel)
 template <class TW, class Sync>
 RS_HD void ffwd_planar(int lane, double (&x)[kRegs], const TW& t, double* buf, Sync sync) {
+#ifdef RS_WGS_FWD_NOAHEAD   // A/B: twiddles fetched stage by stage (fewer registers, every fetch exposed)
+  fft_fwd3<0>(x, t);
+  fpl_exchange<kLayA, kLayB, 1>(lane, x, buf, sync);
+  fft_fwd3<1>(x, t);
+  fpl_exchange<kLayB, kLayC, 2>(lane, x, buf, sync);
+  fft_fwd3<2>(x, t);
+#else
   fft_fwd3_ahead<0>(x, t);
   fpl_exchange<kLayA, kLayB, 1>(lane, x, buf, sync);
   fft_fwd3_ahead<1>(x, t);
   fpl_exchange<kLayB, kLayC, 2>(lane, x, buf, sync);
   fft_fwd3_ahead<2>(x, t);
+#endif
 }
 template <bool PLANAR, class TW, class Sync>
 RS_HD void ffwd_pair(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TW& t, double* buf, Sync sync) {

@@ -6,6 +6,6 @@ ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 NAME="$1"; SRC="${2:-$ROOT}"; shift; shift || true
 mkdir -p "$ROOT/variants"
 hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -fPIC -shared -I"$SRC/include" -I"$SRC/redsec_amd/csrc" "$@" \
-  "$SRC/redsec_amd/csrc/rs_bootstrap.hip" "$SRC/redsec_amd/csrc/rs_kernels.hip" "$SRC/redsec_amd/csrc/rs_api.cpp" \
+  "$SRC/redsec_amd/csrc/rs_bootstrap.hip" "$SRC/redsec_amd/csrc/rs_general.hip" "$SRC/redsec_amd/csrc/rs_kernels.hip" "$SRC/redsec_amd/csrc/rs_api.cpp" \
   -o "$ROOT/variants/lib_$NAME.so" 2>&1 | grep -v "hip-link" || true
 ls -la "$ROOT/variants/lib_$NAME.so"
