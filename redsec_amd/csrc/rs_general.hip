@@ -73,7 +73,7 @@ __global__ __launch_bounds__(Gen<LOGN>::T) void gen_bk_transform_kernel(const in
 }
 
 template <int LOGN>
-__global__ __launch_bounds__(Gen<LOGN>::T) void gen_blind_rotate_kernel(GenArgs a) {
+__global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2, 2))) void gen_blind_rotate_kernel(GenArgs a) {
   using G = Gen<LOGN>;
   constexpr int N = G::N, M = G::M, T = G::T;
   __shared__ double s_re[G::kPlane], s_im[G::kPlane];
