@@ -19,6 +19,8 @@
 // Build-time switches, all OFF in the product build (tools/build_variant.sh passes them for same-box A/B runs):
 //   RS_NO_MAC_STREAM, RS_NO_TW_AHEAD, RS_NO_ACC_AHEAD, RS_NO_SPLIT_STORES   the previous form of one optimisation
 //   RS_ISSUE_FENCE_ON                                   sched_barrier after every exchange burst (measured: -0.5 %)
+//   RS_WG_SETPRIO=<p>, RS_WG_BAREBAR                    static priority for waves 4-7 (-0.3 %); bare s_barrier instead of __syncthreads (+-0)
+//   RS_WGS_FWD_NOAHEAD, RS_WGS_DRAIN                    split-key workgroup kernel: twiddles fetched stage by stage (-1.9 %); full drain at barriers (+-0)
 //   RS_NO_CERT, RS_T_NOBAR, RS_T_STAGGER=<n>, RS_T_HALFSTORE, RS_T_HALFLOAD   TIMING PROBES: results are wrong
 #include <hip/hip_runtime.h>
 
@@ -524,6 +526,9 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
   double dev = 0.0;
   const long n_groups = (a.B + WPB - 1) / WPB;
   const long total_rows = (long)n * KPL;
+#ifdef RS_WG_SETPRIO   // A/B: static priority for the second-dispatched half of the workgroup (the arbitration loser)
+  if (wave >= WPB / 2) __builtin_amdgcn_s_setprio(RS_WG_SETPRIO);
+#endif
 
   // my 1/WPB share of key row R -> ring slot R & 1
   const unsigned lane_off = (unsigned)lane * 16u;
@@ -612,8 +617,12 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
           Xf::fwd_pair_wg(lane, xa, xb, tw, buf);
         }
 #ifndef RS_T_NOBAR   // timing experiments only (results are wrong without the barriers)
+#ifdef RS_WG_BAREBAR   // A/B: bare s_barrier behind explicit counts instead of __syncthreads()
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#endif
 #endif
         if (work) {
 #ifdef RS_NO_MAC_STREAM
@@ -624,7 +633,11 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
 #endif
         }
 #ifndef RS_T_NOBAR
+#ifdef RS_WG_BAREBAR
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
         __syncthreads();
+#endif
         R += 2;
         if (R < total_rows) { issue_row(R); issue_row(R + 1); }
 #endif
