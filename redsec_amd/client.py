@@ -19,6 +19,10 @@ PARAM_SETS = {
     "default128": (630, 1024, 1, 3, 7, 8, 2, 2.0 ** -15, 2.0 ** -25),
     # client/gen_secure_keyset.cpp:70-91
     "redsec_small_v2": (350, 1024, 1, 10, 3, 9, 3, 2.0 ** -25, 2.0 ** -30),
+    # client/gen_secure_keyset.cpp:47-68, 28-45, 9-26: the sets the reference defines beside the one it ships
+    "redsec_small": (500, 1024, 1, 3, 10, 18, 1, 2.0 ** -25, 2.0 ** -36),
+    "redsec_medium": (3072, 4096, 1, 3, 10, 18, 1, 2.0 ** -40, 2.0 ** -45),
+    "redsec_large": (6144, 8192, 1, 3, 10, 18, 1, 2.0 ** -41, 2.0 ** -46),
 }
 
 

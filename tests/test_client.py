@@ -11,7 +11,7 @@ from redsec_amd import client
 
 
 def _oracle_ctx(sk):
-    p = ol.params("default128" if sk.l == 3 else "redsec_small_v2")
+    p = ol.params(sk.name)
     p.n = sk.n
 
     class K:  # duck-typed KeySet for ol.Ctx
@@ -20,7 +20,7 @@ def _oracle_ctx(sk):
     return ol.Ctx(k)
 
 
-@pytest.mark.parametrize("name,n", [("default128", 40), ("redsec_small_v2", 32)])
+@pytest.mark.parametrize("name,n", [("default128", 40), ("redsec_small_v2", 32), ("redsec_small", 24), ("redsec_medium", 6)])
 def test_generated_keys_evaluate_gates(name, n):
     sk = client.SecretKeySet(name, seed=11, n=n)
     ctx = _oracle_ctx(sk)
