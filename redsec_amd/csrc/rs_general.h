@@ -213,7 +213,7 @@ RS_HD void gen_split_key(int32_t k, int32_t& lo, int32_t& hi) {
 // twiddle table: entry 2^s + i (s < log2 M, i < 2^s) = exp(i pi (1 + 4 bitrev_s(i)) / 2^(s+2)), interleaved (re, im);
 // odd i stored as EXACTLY i times the even sibling, the value the _i butterflies apply
 inline void gen_make_twiddles(int logn, double* tw /* 2 * M doubles */) {
-  const int logm = logn - 1, M = 1 << logm;
+  const int logm = logn - 1;
   const long double pi = 3.141592653589793238462643383279502884L;
   tw[0] = 1.0; tw[1] = 0.0;
   for (int s = 0; s < logm; ++s)
@@ -227,7 +227,6 @@ inline void gen_make_twiddles(int logn, double* tw /* 2 * M doubles */) {
       tw[2 * idx] = (i & 1) ? -im : re;
       tw[2 * idx + 1] = (i & 1) ? re : im;
     }
-  (void)M;
 }
 
 // A-priori bound on |computed - true| for one coefficient of  sum_{rows} d_row * Khalf_row  through the FP64 FFT
