@@ -21,6 +21,7 @@
 //   RS_ISSUE_FENCE_ON                                   sched_barrier after every exchange burst (measured: -0.5 %)
 //   RS_WG_SETPRIO=<p>, RS_WG_BAREBAR                    static priority for waves 4-7 (-0.3 %); bare s_barrier instead of __syncthreads (+-0)
 //   RS_WGS_FWD_NOAHEAD, RS_WGS_DRAIN                    split-key workgroup kernel: twiddles fetched stage by stage (-1.9 %); full drain at barriers (+-0)
+//   RS_T_WPB4                                           timing: 4 ciphertexts per workgroup = one wave per SIMD (results correct): 78 % of the rate
 //   RS_NO_CERT, RS_T_NOBAR, RS_T_STAGGER=<n>, RS_T_HALFSTORE, RS_T_HALFLOAD   TIMING PROBES: results are wrong
 #include <hip/hip_runtime.h>
 
@@ -1256,6 +1257,14 @@ static hipError_t launch_br_xf(const BlindRotateArgs& a, int wpb, long num_cus, 
     // throughput form once every CU gets a whole 8-ciphertext group: lock-step workgroups, key rows
     // shared in LDS. (Groups of 2 or 4 waves were measured for 512 < B < 2048 and do not beat the
     // per-wave kernel there: with one wave per SIMD the single-wave CMUX latency dominates.)
+#ifdef RS_T_WPB4   // timing experiment: one wave per SIMD (4 ciphertexts per workgroup, still one workgroup per CU by LDS)
+    if (!o.no_wg && a.B >= 8L * num_cus) {
+      const long groups = (a.B + 3) / 4;
+      const long grid = groups < num_cus ? groups : num_cus;
+      hipLaunchKernelGGL((blind_rotate_wg_kernel<Xf, 4>), dim3((unsigned)grid), dim3(256), 0, st, a);
+      return done(kFormWorkgroup, 4, 4 * grid);
+    }
+#endif
     if (!o.no_wg && a.B >= 8L * num_cus) {
       const long groups = (a.B + 7) / 8;
       const long grid = groups < num_cus ? groups : num_cus;
