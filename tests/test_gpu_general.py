@@ -180,3 +180,45 @@ def test_split_workgroup_kernel_ragged_groups_and_identity_steps(toy, name, seed
     be.set_mode("exact")
     assert torch.equal(lg, be.bootstrap_lut(d, luts))
     be.set_mode("split")
+
+
+@pytest.mark.parametrize("toy,name,seed", [("toy_small", "redsec_small", 11), ("toy_medium", "redsec_medium", 13)])
+def test_general_kernel_batch_sizes_around_the_resident_grid(toy, name, seed):
+    """Persistent workgroups: batches of one ciphertext, just below / at / just above the number of resident workgroups,
+    and several rounds with a remainder -- every output equal to the oracle's (full comparison: n is small)."""
+    ks, ctx, be = _setup(toy, name, seed)
+    be.set_mode("split")
+    rng = np.random.default_rng(seed + 100)
+    mu = ol.to_torus(1, 4096)
+    be.bootstrap(_dev(ks.encrypt([mu], 2.0 ** -25, 1)), mu)
+    resident = be.last_launch()["resident"]
+    assert resident == 1                      # a batch of one occupies one workgroup
+    big = _dev(ks.encrypt(rng.integers(-2**31, 2**31, 4096), 2.0 ** -25, 2))
+    be.bootstrap(big, mu)
+    cap = be.last_launch()["resident"]        # workgroups the device keeps resident
+    assert 256 <= cap <= 4096
+    for B in (1, 3, cap - 1, cap, cap + 1, 2 * cap + 7):
+        ct = ks.encrypt(rng.integers(-2**31, 2**31, B), 2.0 ** -25, 10 + B)
+        got = be.bootstrap(_dev(ct), mu).cpu().numpy()
+        assert np.array_equal(got, ctx.bootstrap_batch(ct, mu)), B
+
+
+def test_general_kernel_on_two_streams_of_one_context():
+    """Per-stream workspaces hold for the general path too: two streams, interleaved launches, one context."""
+    import torch
+    ks, ctx, be = _setup("toy_n2048", "default128", 12)
+    be.set_mode("split")
+    e8 = ol.to_torus(1, 8)
+    rng = np.random.default_rng(3)
+    cts = [ks.encrypt(np.where(rng.integers(0, 2, 700) == 1, e8, -e8), 2.0 ** -20, 40 + k) for k in range(4)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [None] * 4
+    devs = [_dev(c) for c in cts]
+    torch.cuda.synchronize()
+    for k in range(4):
+        with torch.cuda.stream(streams[k & 1]):
+            outs[k] = be.gate("NAND", devs[k], devs[(k + 1) & 3])
+    torch.cuda.synchronize()
+    for k in range(4):
+        pick = np.r_[0:6, 694:700]
+        assert np.array_equal(outs[k].cpu().numpy()[pick], ctx.gate_batch("NAND", cts[k][pick], cts[(k + 1) & 3][pick])), k
