@@ -232,12 +232,19 @@ inline void gen_make_twiddles(int logn, double* tw /* 2 * M doubles */) {
 // A-priori bound on |computed - true| for one coefficient of  sum_{rows} d_row * Khalf_row  through the FP64 FFT
 // (forward transforms of both operands, pointwise products, inverse), for ANY inputs with |d| <= Bg/2 and
 // |Khalf| <= 2^15. Percival, "Rapid multiplication modulo the sum and difference of highly composite numbers",
-// Math. Comp. 72 (2003), Thm 5.1 (restated in Brent & Zimmermann, Modern Computer Arithmetic, Thm 3.3.4):
+// Math. Comp. 72 (2003), the error theorem for FFT-based convolution (Thm 5.1 there; restated in Brent & Zimmermann,
+// Modern Computer Arithmetic, ch. 3) [recalled: no copy in this image]:
 //     ||z' - z||_inf <= ||x||_2 ||y||_2 ((1+u)^(3n) (1+u sqrt5)^(3n+1) (1+beta)^(3n) - 1)
 // for a length-2^n transform with unit roundoff u = 2^-53 and twiddles within beta of their true values. The merged
 // twist makes every level's twiddle general, which is the case the theorem covers; n is taken one higher than
 // log2(M) to cover the pre-scaled key and the accumulation over rows, and the result is doubled as slack. Products
 // with FMAs round less often than the model assumes. RS_MODE_FFT_SPLIT is offered only when this is below 1/4.
+// A self-contained, cruder bound -- Higham, Accuracy and Stability of Numerical Algorithms, Thm 24.2 (relative 2-norm
+// error of a radix-2 FFT <= log2(M) eta, eta ~ 7u) carried through the product with |X_k| <= sqrt(M) ||x||_2:
+// error <= rows sqrt(M) ||d||_2 ||Khalf||_2 (21 log2(M) + 3) u -- gives 0.006 (default-128), 0.0013 (REDsec shipped set),
+// 0.05 (redsec_params_small), 0.49 (medium) and 1.5 (large): it certifies the three N = 1024 sets by itself; for the
+// two large rings the claim rests on Percival's sharper analysis (and the largest rounding distance measured on
+// operands of the largest norm is 4.3e-6, tests/test_gpu_general.py).
 inline double gen_error_bound(int logn, int l, int bgbit) {
   const double N = std::ldexp(1.0, logn);
   const int n = logn;   // log2(M) + 1
