@@ -222,3 +222,44 @@ def test_general_kernel_on_two_streams_of_one_context():
     for k in range(4):
         pick = np.r_[0:6, 694:700]
         assert np.array_equal(outs[k].cpu().numpy()[pick], ctx.gate_batch("NAND", cts[k][pick], cts[(k + 1) & 3][pick])), k
+
+
+def _random_key_parity(name, n, seed):
+    import torch
+    import redsec_amd
+    p = ol.params(name)
+    p.n = n
+    rng = np.random.default_rng(seed)
+
+    class K:
+        pass
+    ks = K()
+    ks.p = p
+    ks.bk = rng.integers(-2**31, 2**31, p.n * 2 * p.bk_l * 2 * p.N, dtype=np.int32)
+    ks.ksk = rng.integers(-2**31, 2**31, p.N * p.ks_t * (1 << p.ks_basebit) * (p.n + 1), dtype=np.int32)
+    ctx = ol.Ctx(ks)
+    be = redsec_amd.Backend(redsec_amd.params(name, n=n), device=0)
+    be.load_keys(ks.bk, ks.ksk)
+    assert be.mode() == "split" and be.info()["bk_device_bytes"] == 2 * ks.bk.size * 8
+    ct = rng.integers(-2**31, 2**31, (3, p.n + 1), dtype=np.int32)
+    ct[2, 5:9] = 0                               # a few identity steps
+    mu = ol.to_torus(1, 4096)
+    got = be.bootstrap(_dev(ct), mu).cpu().numpy()
+    assert np.array_equal(got, ctx.bootstrap_batch(ct, mu))
+    be.close()
+    ctx.close()
+    torch.cuda.empty_cache()
+
+
+def test_redsec_params_medium_at_full_size_on_random_keys():
+    """redsec_params_medium at its full n = 3072 (split key 2.4 GB on the device, keyswitch key 1.8 GB): the oracle's key
+    generator would take hours at this size, but bit-exactness does not need a VALID key -- blind rotation, extract and
+    keyswitch are deterministic functions of whatever key words they are given -- so the key is random words and the
+    outputs are compared with the oracle's word for word (they decrypt to nothing)."""
+    _random_key_parity("redsec_medium", 3072, 2024)
+
+
+def test_redsec_params_large_at_a_quarter_of_its_n_on_random_keys():
+    """redsec_params_large (N = 8192) with n = 1536 of 6144: the same comparison; the full n needs 7 GB of host memory for
+    the keyswitch key alone, which a test should not take."""
+    _random_key_parity("redsec_large", 1536, 2025)
