@@ -81,9 +81,9 @@ __global__ __launch_bounds__(KS_TILE_THREADS) void keyswitch_tiled_kernel(Keyswi
   const long ct = (long)blockIdx.x * KS_TILE_THREADS + tid;
   const bool live = ct < a.B;
   const int w0 = blockIdx.y * KS_CH;
-  const int W = a.W;
-  const int32_t* u0 = a.u0 + (live ? ct : 0) * (kN + 1);
-  const int32_t* u1 = a.u1 ? a.u1 + (live ? ct : 0) * (kN + 1) : nullptr;
+  const int W = a.W, N = a.N;   // ring degree of the extracted samples: 1024 ... 8192
+  const int32_t* u0 = a.u0 + (live ? ct : 0) * (size_t)(N + 1);
+  const int32_t* u1 = a.u1 ? a.u1 + (live ? ct : 0) * (size_t)(N + 1) : nullptr;
 
   for (int e = tid; e < 2 * ROWS * KS_CHP; e += KS_TILE_THREADS) (&s_ksk[0][0])[e] = 0;
 
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(KS_TILE_THREADS) void keyswitch_tiled_kernel(Keyswi
   // blockIdx.z selects a slice of the N input coefficients (latency form for small batches: the
   // slices add their partial sums into a zeroed output with integer atomics -- exact and
   // order-independent mod 2^32); gridDim.z == 1 is the plain-store throughput form.
-  const int groups_per_split = (kN / KS_IG) / (int)gridDim.z;
+  const int groups_per_split = (N / KS_IG) / (int)gridDim.z;
   const int g_begin = (int)blockIdx.z * groups_per_split, g_end = g_begin + groups_per_split;
   __syncthreads();
   stage(g_begin & 1, g_begin * KS_IG);
@@ -153,8 +153,8 @@ __global__ __launch_bounds__(KS_TILE_THREADS) void keyswitch_tiled_kernel(Keyswi
   if (!live) return;
   uint32_t bw = 0;
   if (blockIdx.z == 0) {
-    bw = (uint32_t)u0[kN];
-    if (u1) bw += (uint32_t)u1[kN];
+    bw = (uint32_t)u0[N];
+    if (u1) bw += (uint32_t)u1[N];
     bw += (uint32_t)a.bconst;
   }
   int32_t* out = a.out + ct * W + w0;
@@ -381,7 +381,8 @@ __global__ __launch_bounds__(256) void sumpool_kernel(int32_t* __restrict__ out,
 hipError_t launch_keyswitch(const KeyswitchArgs& a, hipStream_t st) {
   if (a.B <= 0) return hipSuccess;
   dim3 grid((unsigned)((a.B + KS_TILE_THREADS - 1) / KS_TILE_THREADS), (unsigned)((a.W + KS_CH - 1) / KS_CH), 1);
-  const bool tiled = a.N == kN && ((a.t == 8 && a.basebit == 2) || (a.t == 9 && a.basebit == 3));
+  // tiled forms: the two shipped shapes and (18, 1) of redsec_params_small / medium / large; any power-of-two ring
+  const bool tiled = (a.t == 8 && a.basebit == 2) || (a.t == 9 && a.basebit == 3) || (a.t == 18 && a.basebit == 1);
   if (tiled) {
     // small batches: slice the input coefficients until ~1024 workgroups exist (latency form)
     unsigned split = 1;
@@ -394,8 +395,10 @@ hipError_t launch_keyswitch(const KeyswitchArgs& a, hipStream_t st) {
   }
   if (tiled && a.t == 8) {
     hipLaunchKernelGGL((keyswitch_tiled_kernel<8, 2, 4>), grid, dim3(KS_TILE_THREADS), 0, st, a);
-  } else if (tiled) {
+  } else if (tiled && a.t == 9) {
     hipLaunchKernelGGL((keyswitch_tiled_kernel<9, 3, 2>), grid, dim3(KS_TILE_THREADS), 0, st, a);
+  } else if (tiled) {
+    hipLaunchKernelGGL((keyswitch_tiled_kernel<18, 1, 4>), grid, dim3(KS_TILE_THREADS), 0, st, a);
   } else {
     // generic gather form: any ring degree, any (t, basebit), any sample width
     const unsigned wy = (unsigned)((a.W + KS_THREADS * KS_MAXR - 1) / (KS_THREADS * KS_MAXR));
