@@ -263,3 +263,16 @@ def test_redsec_params_large_at_a_quarter_of_its_n_on_random_keys():
     """redsec_params_large (N = 8192) with n = 1536 of 6144: the same comparison; the full n needs 7 GB of host memory for
     the keyswitch key alone, which a test should not take."""
     _random_key_parity("redsec_large", 1536, 2025)
+
+
+@pytest.mark.parametrize("toy,name,seed", [("toy_small", "redsec_small", 11), ("toy_medium", "redsec_medium", 13), ("toy_large", "redsec_large", 14)])
+def test_tiled_keyswitch_18_1_on_every_ring(toy, name, seed):
+    """keyswitch_tiled_kernel<18, 1, 4> with the ring degree at run time: a batch that spans several 256-ciphertext
+    workgroups with a ragged last one (plain-store form) and a small one (input-sliced atomic form), both against the oracle."""
+    ks, ctx, be = _setup(toy, name, seed)
+    rng = np.random.default_rng(seed)
+    for B in (5, 700):
+        u = rng.integers(-2**31, 2**31, (B, ks.p.N + 1), dtype=np.int32)
+        got = be.keyswitch(_dev(u)).cpu().numpy()
+        pick = np.arange(B) if B < 32 else np.r_[0:6, 250:262, B - 6:B]
+        assert np.array_equal(got[pick], ctx.keyswitch(u[pick])), B
