@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -833,23 +834,45 @@ namespace redsec_host {
 
 // execute() of a layer or of a single stage: stage the input (or find it resident), free it as the reference's callee
 // does (BinFunc.cpp:327, IntFunc.cpp:698), run, hand back fresh host arrays with the device copy remembered
+// REDSEC_TRACE=1: per-layer host timing on stderr (input staging incl. freeing the caller's arrays, device stages, download +
+// host arrays), for finding out where a driver's wall time goes beside the kernels
+static bool trace_on() { static const bool on = getenv("REDSEC_TRACE") != nullptr; return on; }
+static double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+static void trace(const LayerImpl* L, double t0, double t1, double t2, double t3, size_t rows_out) {
+  fprintf(stderr, "redsec trace: layer in %d -> out %zu ciphertexts: stage %.1f ms, device %.1f ms, publish %.1f ms\n", L->in_count, rows_out,
+          1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2));
+}
 void* execute_bits(LayerImpl* impl, tBit* p_in) {
   assert(impl->prepared);
+  const double t0 = now_s();
   std::vector<const LweSample*> in((size_t)impl->in_count);
   for (size_t i = 0; i < in.size(); ++i) in[i] = &p_in[i];
   DevSlab x = stage_input(impl, p_in, in);
   bit_free((uint32_t)impl->in_count, p_in);
-  return publish(impl, run_layer(impl, x));
+  const double t1 = now_s();
+  DevSlab y = run_layer(impl, x);
+  const double t2 = now_s();
+  const size_t rows = y.rows;
+  void* ret = publish(impl, y);
+  if (trace_on()) trace(impl, t0, t1, t2, now_s(), rows);
+  return ret;
 }
 void* execute_mbits(LayerImpl* impl, tMultiBit* p_in) {
   assert(impl->prepared);
   std::vector<const LweSample*> in((size_t)impl->in_count);
   for (size_t i = 0; i < in.size(); ++i) in[i] = &p_in[i].ctxt[0];
   const bool ours = is_resident(p_in);     // produced by one of these layers (calloc) or by the driver (new[])
+  const double t0 = now_s();
   DevSlab x = stage_input(impl, p_in, in);
   for (int i = 0; i < impl->in_count; ++i) delete_gate_bootstrapping_ciphertext_array((int32_t)p_in[i].size, p_in[i].ctxt);
   if (ours) free(p_in); else delete[] p_in;
-  return publish(impl, run_layer(impl, x));
+  const double t1 = now_s();
+  DevSlab y = run_layer(impl, x);
+  const double t2 = now_s();
+  const size_t rows = y.rows;
+  void* ret = publish(impl, y);
+  if (trace_on()) trace(impl, t0, t1, t2, now_s(), rows);
+  return ret;
 }
 
 // a LayerImpl that is ONE stage (the BinFunc::* / IntFunc::* classes)

@@ -26,6 +26,11 @@ exe = os.path.join(rd.REFNETS, "cifar_%s_enc.out" % net_name)
 t0 = time.time()
 r = subprocess.run([exe], cwd=netdir, env=env, capture_output=True, text=True, timeout=900)
 print("plain run: rc", r.returncode, "wall %.2f s" % (time.time() - t0))
+env_t = dict(env); env_t["REDSEC_TRACE"] = "1"
+t0 = time.time()
+r = subprocess.run([exe], cwd=netdir, env=env_t, capture_output=True, text=True, timeout=900)
+print("traced run: rc", r.returncode, "wall %.2f s" % (time.time() - t0))
+print("".join(l + "\n" for l in r.stderr.splitlines() if "redsec trace" in l), end="")
 t0 = time.time()
 r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", out_dir, "--", exe],
                    cwd=netdir, env=env, capture_output=True, text=True, timeout=1200)
