@@ -1,7 +1,7 @@
 """How far is the FFT mode from ever rounding wrongly? Many 65,536-gate batches (fresh key per round,
 fresh encryptions per batch, random gate type), each run in the FFT mode and again in the exact-NTT
-mode, every output word compared on the device; per batch the rounding certificate (largest
-|x - rint(x)| over all inverse-transform outputs). An error of +-1 needs a distance > 0.5.
+mode and in the split-key mode, every output word compared on the device; per batch the rounding certificate
+(largest |x - rint(x)| over all inverse-transform outputs of the FFT mode). An error of +-1 needs a distance > 0.5.
 
   python tools/certificate_survey.py [params] [keys] [batches_per_key] [gates]
 """
@@ -18,7 +18,7 @@ per_key = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 G = int(sys.argv[4]) if len(sys.argv) > 4 else 65536
 gates = ["NAND", "AND", "OR", "XOR", "XNOR", "NOR"]
 p = redsec_amd.params(params)
-certs, mismatched_words, total = [], 0, 0
+certs, mismatched_words, split_mismatched, total = [], 0, 0, 0
 t0 = time.time()
 for k in range(n_keys):
     sk = client.SecretKeySet(params, seed=1000 + k)
@@ -38,10 +38,13 @@ for k in range(n_keys):
         be.set_mode("exact")
         out_e = be.gate(op, a, c)
         mismatched_words += int((out_f != out_e).sum().item())
+        be.set_mode("split")                                   # the third arithmetic: split-key FFT, exact by an a-priori bound
+        split_mismatched += int((be.gate(op, a, c) != out_e).sum().item())
         total += G
         print("key %d batch %d %-4s certificate %.6f mismatched words so far %d (%.0f s)" % (k, b, op, certs[-1], mismatched_words, time.time() - t0), flush=True)
     del be
 cmux = total * p.n
 print(json.dumps({"params": params, "gates": total, "cmux_steps": cmux, "rounded_values": cmux * 2048,
                   "max_certificate": max(certs), "median_certificate": float(np.median(certs)),
-                  "words_differing_from_exact_ntt_mode": mismatched_words}))
+                  "words_differing_from_exact_ntt_mode": mismatched_words,
+                  "split_mode_words_differing_from_exact_ntt_mode": split_mismatched}))
