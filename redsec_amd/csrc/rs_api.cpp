@@ -81,6 +81,7 @@ struct rs_ctx {
   // general ring path (rs_general.h): every parameter set has it; sets outside the specialised N = 1024 kernels
   // (`general`) have nothing else
   bool general = false;
+  int wgs_cfg = -1;                // gadget id of the lock-step split-key kernel, or -1 (general kernels only)
   int logn = 10;
   double split_bound = 0.0;        // a-priori error bound of the split-key product (< 1/4 or the mode is not offered)
   double* d_tw_gen = nullptr;      // gen_make_twiddles(logn)
@@ -230,11 +231,11 @@ int run_bootstrap(rs_ctx* c, hipStream_t st, int32_t* out, const Combo* combos, 
     // exact by the a-priori bound of rs_general.h: nothing to certify, nothing to recompute
     bool split_wg = false;
     for (int k = 0; k < count; ++k) {
-      if (!c->general && !c->opts.no_wg) {
-        // N = 1024 with a shipped gadget at throughput batch sizes: lock-step workgroups on the split key
+      if (c->wgs_cfg >= 0 && !c->opts.no_wg) {
+        // N = 1024 with one of the reference's gadgets at throughput batch sizes: lock-step workgroups on the split key
         rs::BlindRotateArgs w = br_args(c, ln, 1, cs[k], mu, lut, B);
-        w.bk_x = c->d_bk_gen;
-        const hipError_t e = rs::launch_blind_rotate_split_wg(c->cfg, w, c->num_cus, st, &ln->last);
+        w.bk_x = c->d_bk_gen; w.tw = c->d_tw_fft;
+        const hipError_t e = rs::launch_blind_rotate_split_wg(c->wgs_cfg, w, c->num_cus, st, &ln->last);
         if (e == hipSuccess) { split_wg = true; continue; }
         if (e != hipErrorNotSupported) return fail(RS_ERR_HIP, "split workgroup launch failed: %s", hipGetErrorString(e));
       }
@@ -377,12 +378,19 @@ int rs_create(rs_ctx** out, const rs_params* p, int device) {
     }
   }
   if (special) {
-    const std::vector<double> fft_tw = rs::make_fft_tables();
     if (hipMalloc(&c->d_tw, sizeof(double) * rs::kTwTotal) != hipSuccess ||
-        hipMemcpy(c->d_tw, c->tables.tw.data(), sizeof(double) * rs::kTwTotal, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMalloc(&c->d_tw_fft, sizeof(double) * rs::kFftTwDoubles) != hipSuccess ||
-        hipMemcpy(c->d_tw_fft, fft_tw.data(), sizeof(double) * rs::kFftTwDoubles, hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpy(c->d_tw, c->tables.tw.data(), sizeof(double) * rs::kTwTotal, hipMemcpyHostToDevice) != hipSuccess) {
       destroy_ctx(c);   // releases whatever was allocated
+      return fail(RS_ERR_HIP, "twiddle table upload failed");
+    }
+  }
+  // lock-step split-key kernel (N = 1024): the two shipped gadgets and redsec_params_small's; it runs on rs_fft.h's tables
+  c->wgs_cfg = special ? c->cfg : ((p->N == rs::kN && p->bk_l == 3 && p->bk_Bgbit == 10) ? 2 : -1);
+  if (special || c->wgs_cfg >= 0) {
+    const std::vector<double> fft_tw = rs::make_fft_tables();
+    if (hipMalloc(&c->d_tw_fft, sizeof(double) * rs::kFftTwDoubles) != hipSuccess ||
+        hipMemcpy(c->d_tw_fft, fft_tw.data(), sizeof(double) * rs::kFftTwDoubles, hipMemcpyHostToDevice) != hipSuccess) {
+      destroy_ctx(c);
       return fail(RS_ERR_HIP, "twiddle table upload failed");
     }
   }

@@ -1305,14 +1305,16 @@ hipError_t launch_blind_rotate(int cfg, int mode, const BlindRotateArgs& a, int 
                   : launch_br_xf<XfFft<CfgRedsecV2>>(a, wpb, num_cus, true, opts, st, info);
 }
 
-// Split-key workgroup form (N = 1024, the two shipped gadgets, B >= 8 x #CUs): a.bk_x = the split key of rs_general.h,
+// Split-key workgroup form (N = 1024; cfg 0 / 1 = the two shipped gadgets, 2 = redsec_params_small's l=3 Bgbit=10; B >= 8 x #CUs): a.bk_x = the split key of rs_general.h,
 // a.tw = the FFT tables of rs_fft.h. Returns hipErrorNotSupported when the batch is too small (caller: general kernel).
 hipError_t launch_blind_rotate_split_wg(int cfg, const BlindRotateArgs& a, int num_cus, hipStream_t st, LaunchInfo* info) {
   if (a.B < 8L * num_cus) return hipErrorNotSupported;
   const long groups = (a.B + 7) / 8;
   const long grid = groups < num_cus ? groups : num_cus;
   if (cfg == 0) hipLaunchKernelGGL((blind_rotate_wgs_kernel<CfgDefault128>), dim3((unsigned)grid), dim3(512), 0, st, a);
-  else hipLaunchKernelGGL((blind_rotate_wgs_kernel<CfgRedsecV2>), dim3((unsigned)grid), dim3(512), 0, st, a);
+  else if (cfg == 1) hipLaunchKernelGGL((blind_rotate_wgs_kernel<CfgRedsecV2>), dim3((unsigned)grid), dim3(512), 0, st, a);
+  else if (cfg == 2) hipLaunchKernelGGL((blind_rotate_wgs_kernel<CfgRedsecSmall>), dim3((unsigned)grid), dim3(512), 0, st, a);
+  else return hipErrorNotSupported;
   if (info) { info->form = kFormSplitWorkgroup; info->waves_per_block = 8; info->resident = 8 * grid; }
   return hipGetLastError();
 }

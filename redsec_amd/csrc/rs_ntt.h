@@ -99,6 +99,9 @@ struct Cfg {
 using CfgDefault128 = Cfg<3, 7, (1u << 3) | (1u << 7), (1u << 2) | (1u << 5) | (1u << 8), 1, true>;
 // REDsec redsec_params_small_v2: l=10, Bgbit=3 -> prime 2^48.35 (headroom 25).
 using CfgRedsecV2 = Cfg<10, 3, 0u, (1u << 4), 2, true>;
+// redsec_params_small (client/gen_secure_keyset.cpp:47-68): l=3, Bgbit=10. Only the gadget shape is used (split-key
+// workgroup kernel); its products exceed one FP64-carried prime, so there is no NTT schedule for it.
+using CfgRedsecSmall = Cfg<3, 10, 0u, 0u, 0, false>;
 
 // Table block handed to the kernels: [0,1024) forward twiddles, [1024,2048) inverse twiddles,
 // [2048, 2048+kSmall) constants of the fused stages 0-1:

@@ -276,3 +276,33 @@ def test_tiled_keyswitch_18_1_on_every_ring(toy, name, seed):
         got = be.keyswitch(_dev(u)).cpu().numpy()
         pick = np.arange(B) if B < 32 else np.r_[0:6, 250:262, B - 6:B]
         assert np.array_equal(got[pick], ctx.keyswitch(u[pick])), B
+
+
+def test_split_workgroup_kernel_on_redsec_params_small(monkeypatch):
+    """redsec_params_small (N = 1024, l = 3, Bgbit = 10) takes the lock-step split-key kernel at throughput batch sizes
+    (gadget id 2 of blind_rotate_wgs_kernel): equal word for word to the general kernel (a second context under RS_NO_WG)
+    and, on a sample, to the oracle; ragged last group, identity steps."""
+    import torch
+    import redsec_amd
+    ks, ctx, be = _setup("toy_small", "redsec_small", 11)
+    cus = be.info()["num_cus"]
+    B = 16 * cus + 5
+    rng = np.random.default_rng(5)
+    ct = ks.encrypt(rng.integers(-2**31, 2**31, B), 2.0 ** -25, 77).copy()
+    ct[3, :4] = 0
+    ct[B - 1, : ks.p.n] = 0
+    mu = ol.to_torus(1, 4096)
+    d = _dev(ct)
+    got = be.bootstrap(d, mu)
+    assert be.last_launch()["form"] == "split_workgroup"
+    monkeypatch.setenv("RS_NO_WG", "1")
+    bp = redsec_amd.params("redsec_small", n=ks.p.n)
+    be2 = redsec_amd.Backend(bp, device=0)
+    monkeypatch.delenv("RS_NO_WG")
+    be2.load_keys(ks.bk, ks.ksk)
+    ref = be2.bootstrap(d, mu)
+    assert be2.last_launch()["form"] == "general"
+    assert torch.equal(got, ref)
+    be2.close()
+    sample = np.r_[0:8, 8 * cus:8 * cus + 8, B - 9:B]
+    assert np.array_equal(got.cpu().numpy()[sample], ctx.bootstrap_batch(ct[sample], mu))
