@@ -123,6 +123,24 @@ class EncryptedMnist:
         sign, zero, bias = self.final
         return be.linear_fc(bits, sign, zero, zero_tap_b=0, bias_b=bias)      # Quantize::add_bias, no bootstrap
 
+    def run_many(self, image_cts):
+        """K images at once: int32 CUDA tensor [K][784][W] -> [K][10][W]. Every bootstrap stage is ONE launch over the
+        neurons of all K images (the gates of different images are as independent as the gates of one: the batch moves
+        from the latency forms into the throughput form), the linear stages run per image. Equal word for word to K
+        calls of run()."""
+        import torch
+        be = self.be
+        K = image_cts.shape[0]
+        pre = torch.cat([be.sumpool(image_cts[k].view(28, 28, 1, be.W), self.pool, bias_b=self.bias0).view(196, be.W) for k in range(K)])
+        bits = be.bootstrap(pre, MU_SIGN)
+        for sign, zero, bias in self.fc:
+            width = bits.shape[0] // K
+            pre = torch.cat([be.linear_fc(bits[k * width:(k + 1) * width], sign, zero, zero_tap_b=0, bias_b=bias) for k in range(K)])
+            bits = be.bootstrap(pre, MU_SIGN)
+        sign, zero, bias = self.final
+        width = bits.shape[0] // K
+        return torch.stack([be.linear_fc(bits[k * width:(k + 1) * width], sign, zero, zero_tap_b=0, bias_b=bias) for k in range(K)])
+
 
 # ---- ReLU networks (nets/mnist/relu1024x{1,2,3}) -------------------------------------------------------
 # Quantize::relu_shift (lib/IntFunc.cpp:934-973), corrected semantics -- DESIGN.md "ReLU semantics".

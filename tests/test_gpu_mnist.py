@@ -167,3 +167,22 @@ def test_linear_kernels_against_numpy():
                         if 0 <= ih < H and 0 <= iw < Wd:
                             ref[oh, ow] += x[ih, iw].astype(np.int64)
         assert np.array_equal(got, (ref & 0xFFFFFFFF).astype(np.uint32).view(np.int32)), win
+
+
+def test_run_many_equals_run_word_for_word():
+    """EncryptedMnist.run_many: 5 images through one launch per bootstrap stage == 5 calls of run()."""
+    import torch
+    import redsec_amd
+    from redsec_amd import client, nets
+    import plain_model as pm
+    sk = client.SecretKeySet("redsec_small_v2", seed=9)
+    be = redsec_amd.Backend(redsec_amd.params("redsec_small_v2"), 0)
+    be.load_keys(sk.bk, sk.ksk)
+    enc = nets.EncryptedMnist(be, pm.load_net("sign1024x1"))
+    labels, pixels = pm.load_images()
+    cts = torch.stack([torch.from_numpy(sk.encrypt_image(pixels[k], seed=20 + k)).cuda() for k in range(5)])
+    many = enc.run_many(cts)
+    assert many.shape == (5, 10, be.W)
+    for k in range(5):
+        assert torch.equal(many[k], enc.run(cts[k])), k
+    be.close()

@@ -20,6 +20,12 @@ ts = []
 for _ in range(5):
     t0 = time.perf_counter(); enc.run(ct); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 print("whole image ms:", [round(t * 1e3, 2) for t in ts])
+for K in (8, 32):      # K images per call: every bootstrap stage one launch over all of them
+    cts = torch.stack([torch.from_numpy(sk.encrypt_image(pixels[k % 100], seed=50 + k)).cuda() for k in range(K)])
+    enc.run_many(cts); torch.cuda.synchronize()
+    t0 = time.perf_counter(); many = enc.run_many(cts); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    same = all(torch.equal(many[k], enc.run(cts[k])) for k in (0, K - 1))
+    print("%d images per call: %.2f ms = %.2f ms per image (equal to run() word for word: %s)" % (K, dt * 1e3, dt * 1e3 / K, same))
 be.set_timing(True)
 x = torch.randint(-2**31, 2**31 - 1, (196, be.W), dtype=torch.int64).to(torch.int32).cuda()
 for B in (196, 600, 1024, 2048):
