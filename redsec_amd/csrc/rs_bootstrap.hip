@@ -19,6 +19,7 @@
 // Build-time switches, all OFF in the product build (tools/build_variant.sh passes them for same-box A/B runs):
 //   RS_NO_MAC_STREAM, RS_NO_TW_AHEAD, RS_NO_ACC_AHEAD, RS_NO_SPLIT_STORES   the previous form of one optimisation
 //   RS_ISSUE_FENCE_ON                                   sched_barrier after every exchange burst (measured: -0.5 %)
+//   RS_ADDTID                                           B' <-> C' exchanges stored by ds_write_addtid_b32 rows, read back as 16-byte runs (rs_fft.h): -0.8 % / +0.5 %
 //   RS_WG_SETPRIO=<p>, RS_WG_BAREBAR                    static priority for waves 4-7 (-0.3 %); bare s_barrier instead of __syncthreads (+-0)
 //   RS_WGS_FWD_NOAHEAD, RS_WGS_DRAIN                    split-key workgroup kernel: twiddles fetched stage by stage (-1.9 %); full drain at barriers (+-0)
 //   RS_T_WPB4                                           timing: 4 ciphertexts per workgroup = one wave per SIMD (results correct): 78 % of the rate
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
   constexpr int kChunksPerWave = kChunks / WPB;
   static_assert(kChunks % WPB == 0 && (kChunksPerWave == 1 || kChunksPerWave == 2 || kChunksPerWave == 4), "waves must split a key row evenly");
   __shared__ double s_tw[Xf::kTableDoubles + 1];
-  __shared__ double s_buf[WPB][Xf::kWgBufDoubles];
+  __shared__ __attribute__((aligned(16))) double s_buf[WPB][Xf::kWgBufDoubles];
   __shared__ int32_t s_acc[WPB][2][kN];
   __shared__ __attribute__((aligned(16))) double s_key[2][kRowDoubles];
   __shared__ uint16_t s_bara[WPB][kSmall];
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(512) void blind_rotate_wgs_kernel(BlindRotateArgs a
   constexpr int kSlotDoubles = 2 * kN;   // one key half-row: 2 columns x N doubles = 16 KB
   constexpr int kWin = 64;
   __shared__ double s_tw[Xf::kTableDoubles + 1];
-  __shared__ double s_buf[WPB][Xf::kWgBufDoubles];
+  __shared__ __attribute__((aligned(16))) double s_buf[WPB][Xf::kWgBufDoubles];
   __shared__ int32_t s_acc[WPB][2][kN];
   __shared__ __attribute__((aligned(16))) double s_key[3][kSlotDoubles];
   __shared__ uint16_t s_bara[WPB][kWin];
@@ -905,7 +906,7 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
   constexpr int kRowDoubles = 2 * kN;
   constexpr int kCts = 4;
   __shared__ double s_tw[Xf::kTableDoubles + 1];
-  __shared__ double s_buf[8][Xf::kWgBufDoubles];
+  __shared__ __attribute__((aligned(16))) double s_buf[8][Xf::kWgBufDoubles];
   __shared__ int32_t s_acc[kCts][2][kN];
   __shared__ __attribute__((aligned(16))) double s_key[4][kRowDoubles];   // slot 2 h + k: row k of the pair, component h
   __shared__ uint16_t s_bara[kCts][kSmall];

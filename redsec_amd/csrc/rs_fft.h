@@ -299,8 +299,64 @@ RS_HD int flay_index(int lane, int k) {
 #else
 #define RS_PLANE_STORE(buf, pos, v) ((buf)[pos] = (v))
 #endif
+// ---- row form of the B' <-> C' exchange (T = 2), A/B switch RS_ADDTID ----
+// The exchange between the layouts B' (lane = 8a + c, registers b) and C' (lane = 8a + b, registers c) moves value
+// (a, b, c) from register b of lane 8a + c to register c of lane 8a + b -- in either direction: register k of the
+// writer becomes the low lane bits of the reader. Stored as ROWS (row k = register k of all 64 lanes, lane-major,
+// low and high dwords of the doubles in separate rows), the writer needs no address at all: ds_write_addtid_b32 puts
+// lane L's dword at M0 + offset + 4 L, 2 cycles of the VGPR -> LDS path per dword against 6 per ds_write_b64 (address +
+// 2 data dwords) = 4 instead of 6 per value; the reader's eight values sit in 8 consecutive dwords of row (lane & 7)
+// (low halves) and of its twin (high halves): four 16-byte reads per plane, the cycles of eight ds_read_b64. Row bases
+// (dwords) give every 16-lane group of a ds_read_b128 all 64 banks: residues {0, 4, 32, 36} by k mod 4.
+RS_HD int frow_base(int k, int hi) { const int c = k & 3; return 260 * c + 24 * (c >> 1) + 64 * (k >> 2) + 128 * hi; }   // classes at 0, 260, 544, 804
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RS_ADDTID)
+template <int H>
+__device__ __forceinline__ void frow_store(const double (&x)[kRegs], double* buf) {
+  const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)buf);
+  unsigned lo[8], hi[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const unsigned long long b = (unsigned long long)__builtin_bit_cast(long long, x[k + 8 * H]);
+    lo[k] = (unsigned)b; hi[k] = (unsigned)(b >> 32);
+  }
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+      "ds_write_addtid_b32 %2 offset:0\n\tds_write_addtid_b32 %10 offset:512\n\t"
+      "ds_write_addtid_b32 %3 offset:1040\n\tds_write_addtid_b32 %11 offset:1552\n\t"
+      "ds_write_addtid_b32 %4 offset:2176\n\tds_write_addtid_b32 %12 offset:2688\n\t"
+      "ds_write_addtid_b32 %5 offset:3216\n\tds_write_addtid_b32 %13 offset:3728\n\t"
+      "ds_write_addtid_b32 %6 offset:256\n\tds_write_addtid_b32 %14 offset:768\n\t"
+      "ds_write_addtid_b32 %7 offset:1296\n\tds_write_addtid_b32 %15 offset:1808\n\t"
+      "ds_write_addtid_b32 %8 offset:2432\n\tds_write_addtid_b32 %16 offset:2944\n\t"
+      "ds_write_addtid_b32 %9 offset:3472\n\tds_write_addtid_b32 %17 offset:3984\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(base), "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(lo[4]), "v"(lo[5]), "v"(lo[6]), "v"(lo[7]),
+        "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]), "v"(hi[6]), "v"(hi[7])
+      : "memory");
+}
+template <int H>
+__device__ __forceinline__ void frow_load(int lane, double (&x)[kRegs], const double* buf) {
+  const int q = lane & 7, a8 = 8 * (lane >> 3);
+  const int4* plo = reinterpret_cast<const int4*>(reinterpret_cast<const int*>(buf) + frow_base(q, 0) + a8);
+  const int4* phi = reinterpret_cast<const int4*>(reinterpret_cast<const int*>(buf) + frow_base(q, 1) + a8);
+  const int4 l0 = plo[0], l1 = plo[1], h0 = phi[0], h1 = phi[1];
+  const unsigned lo[8] = {(unsigned)l0.x, (unsigned)l0.y, (unsigned)l0.z, (unsigned)l0.w, (unsigned)l1.x, (unsigned)l1.y, (unsigned)l1.z, (unsigned)l1.w};
+  const unsigned hi[8] = {(unsigned)h0.x, (unsigned)h0.y, (unsigned)h0.z, (unsigned)h0.w, (unsigned)h1.x, (unsigned)h1.y, (unsigned)h1.z, (unsigned)h1.w};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k + 8 * H] = __builtin_bit_cast(double, (long long)(((unsigned long long)hi[k] << 32) | lo[k]));
+}
+#define RS_ROW_FORM 1
+#else
+#define RS_ROW_FORM 0
+#endif
+
 template <int LAY, int T, int H>
 RS_HD void fpl_store(int lane, const double (&x)[kRegs], double* buf) {
+#if RS_ROW_FORM
+  if constexpr (T == 2) { frow_store<H>(x, buf); return; }
+#endif
 #pragma unroll
   for (int k = 0; k < kCRegs; ++k) { const int j = flay_index<LAY>(lane, k); RS_PLANE_STORE(buf, T == 1 ? ppos_t1(j) : ppos_t2(j), x[k + 8 * H]); }
 }
@@ -313,6 +369,9 @@ RS_HD void fpl_store(int lane, const double (&x)[kRegs], double* buf) {
 #endif
 template <int LAY, int T, int H>
 RS_HD void fpl_load(int lane, double (&x)[kRegs], const double* buf) {
+#if RS_ROW_FORM
+  if constexpr (T == 2) { frow_load<H>(lane, x, buf); return; }
+#endif
 #pragma unroll
   for (int k = 0; k < kCRegs; ++k) { const int j = flay_index<LAY>(lane, k); x[k + 8 * H] = RS_PLANE_LOAD(buf, T == 1 ? ppos_t1(j) : ppos_t2(j)); }
 }
