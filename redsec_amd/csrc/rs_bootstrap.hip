@@ -1255,9 +1255,9 @@ static hipError_t launch_br_xf(const BlindRotateArgs& a, int wpb, long num_cus, 
     }
   }
   if constexpr (Xf::kWorkgroupForm) {
-    // throughput form once every CU gets a whole 8-ciphertext group: lock-step workgroups, key rows
-    // shared in LDS. (Groups of 2 or 4 waves were measured for 512 < B < 2048 and do not beat the
-    // per-wave kernel there: with one wave per SIMD the single-wave CMUX latency dominates.)
+    // throughput form: lock-step workgroups of 8 ciphertexts, key rows shared in LDS. Taken as soon as the batch exceeds
+    // FOUR ciphertexts per CU: a partly filled single round of it (10.2 ms for up to 2,048 default-128 ciphertexts) beats two
+    // rounds of the half-size forms (12.8-13.1 ms at 1,536; tools/midsize_rate.py).
 #ifdef RS_T_WPB4   // timing experiment: one wave per SIMD (4 ciphertexts per workgroup, still one workgroup per CU by LDS)
     if (!o.no_wg && a.B >= 8L * num_cus) {
       const long groups = (a.B + 3) / 4;
@@ -1266,11 +1266,22 @@ static hipError_t launch_br_xf(const BlindRotateArgs& a, int wpb, long num_cus, 
       return done(kFormWorkgroup, 4, 4 * grid);
     }
 #endif
-    if (!o.no_wg && a.B >= 8L * num_cus) {
+    if (!o.no_wg && a.B > 4L * num_cus) {
       const long groups = (a.B + 7) / 8;
       const long grid = groups < num_cus ? groups : num_cus;
       hipLaunchKernelGGL((blind_rotate_wg_kernel<Xf, 8>), dim3((unsigned)grid), dim3(512), 0, st, a);
       return done(kFormWorkgroup, 8, 8 * grid);   // the workgroups sweep the key together: 8 x grid ciphertexts per sweep
+    }
+  }
+  if constexpr (Xf::kWorkgroupForm && Xf::Cfg::L % 2 != 0) {
+    // odd l (no duo form), 2 x #CUs < B <= 4 x #CUs: half-size lock-step groups, 4 ciphertexts x 1 wave per workgroup = one
+    // wave per SIMD, which delivers 78 % of the full form's rate per CU and shares the key rows (2-3 % faster than the
+    // per-wave kernel, which streams them per wave)
+    if (!o.no_wg && !o.no_wg4 && a.B > 2L * num_cus) {
+      const long groups = (a.B + 3) / 4;
+      const long grid = groups < num_cus ? groups : num_cus;
+      hipLaunchKernelGGL((blind_rotate_wg_kernel<Xf, 4>), dim3((unsigned)grid), dim3(256), 0, st, a);
+      return done(kFormWorkgroup, 4, 4 * grid);
     }
   }
   if constexpr (Xf::kWorkgroupForm && Xf::Cfg::L % 2 == 0) {

@@ -237,9 +237,9 @@ def test_large_batch_truth_table_property(be_full_default, full_default):
 @pytest.mark.parametrize("size", ["wg8", "duo"])
 @pytest.mark.parametrize("which,fix", [("be_toy_default", "toy_default"), ("be_toy_redsec", "toy_redsec")])
 def test_workgroup_kernel_ragged_groups_and_identity_steps(which, fix, size, request, monkeypatch):
-    """The lock-step workgroup kernels of the FFT mode -- blind_rotate_wg_kernel (B >= 8 x #CUs, 8
-    ciphertexts per group) and blind_rotate_duo_kernel (2 x #CUs < B < 8 x #CUs, even l: 4 ciphertexts
-    x 2 waves) -- on a batch whose last group is ragged AND spills past one group per workgroup, with
+    """The lock-step workgroup kernels of the FFT mode -- blind_rotate_wg_kernel (B > 4 x #CUs, 8
+    ciphertexts per group; odd l also 2 x #CUs < B <= 4 x #CUs with 4 per group) and blind_rotate_duo_kernel
+    (2 x #CUs < B <= 4 x #CUs, even l: 4 ciphertexts x 2 waves) -- on a batch whose last group is ragged AND spills past one group per workgroup, with
     mask words forced to 0 so that some CMUX steps are the identity (tfhe_blindRotate_FFT skips them;
     the lock-step waves must still keep their barriers). Checked word for word against the per-wave
     kernel (RS_NO_WG) and, on a sample, against the oracle."""
@@ -247,7 +247,7 @@ def test_workgroup_kernel_ragged_groups_and_identity_steps(which, fix, size, req
     be = request.getfixturevalue(which)
     ks, ctx = request.getfixturevalue(fix)
     cus = be.info()["num_cus"]
-    B = 8 * cus + 3 if size == "wg8" else 4 * cus + 6
+    B = 8 * cus + 3 if size == "wg8" else 3 * cus + 6
     bits, ct = _bits(ks, B, 4242)
     ct = ct.copy()
     ct[5, :3] = 0            # leading identity steps
@@ -258,7 +258,8 @@ def test_workgroup_kernel_ragged_groups_and_identity_steps(which, fix, size, req
     d = _dev(ct)
     got = be.bootstrap(d, mu)
     if be.mode() == "fft":
-        assert be.last_launch()["form"] == ("workgroup" if size == "wg8" else ("duo" if ks.p.bk_l % 2 == 0 else "per_wave"))
+        launch = be.last_launch()   # odd l has no duo form: half-size lock-step groups (4 waves per workgroup) instead
+        assert (launch["form"], launch["waves_per_block"]) == (("workgroup", 8) if size == "wg8" else (("duo", 8) if ks.p.bk_l % 2 == 0 else ("workgroup", 4)))
     # the launch switches are read once, at context creation: a second context under RS_NO_WG runs the per-wave kernel
     monkeypatch.setenv("RS_NO_WG", "1")
     be2 = _backend(ks, "default128" if ks.p.bk_l == 3 else "redsec_small_v2")
@@ -451,7 +452,7 @@ def test_workgroup_and_duo_kernels_on_full_keys_against_oracle(which, fix, form,
     be = request.getfixturevalue(which)
     ks, ctx = request.getfixturevalue(fix)
     cus = be.info()["num_cus"]
-    B = 8 * cus + 5 if form == "workgroup" else 4 * cus + 2
+    B = 8 * cus + 5 if form == "workgroup" else 3 * cus + 2
     rng = np.random.default_rng(31)
     mu = ol.to_torus(1, 4096)
     sample = np.r_[0:11, B // 2:B // 2 + 10, B - 11:B]
