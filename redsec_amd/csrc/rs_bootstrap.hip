@@ -1267,6 +1267,25 @@ static hipError_t launch_br_xf(const BlindRotateArgs& a, int wpb, long num_cus, 
     }
 #endif
     if (!o.no_wg && a.B > 4L * num_cus) {
+      // The grid walks the batch in rounds of 8 x #CUs ciphertexts. A last round of at most 4 x #CUs of them is cut off
+      // and runs in the form that batch size would take by itself (cooperative / duo / half-size groups: 3.1-8.2 ms against
+      // 14.8 ms for a whole round of the REDsec set, tools/midsize_rate.py); every ciphertext is independent of the split.
+      const long cap = 8L * num_cus, tail = a.B % cap;
+      if (!o.no_tail && a.B > cap && tail > 0 && tail <= 4L * num_cus) {
+        BlindRotateArgs m = a, t = a;
+        m.B = a.B - tail;
+        t.B = tail;
+        t.in0 = a.in0 + m.B * a.W;
+        if (a.in1) t.in1 = a.in1 + m.B * a.W;
+        t.u_out = a.u_out + m.B * (kN + 1);
+        if (a.lut) t.lut_first = (int32_t)((a.lut_first + m.B) % a.lut_count);
+        hipLaunchKernelGGL((blind_rotate_wg_kernel<Xf, 8>), dim3((unsigned)num_cus), dim3(512), 0, st, m);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        e = launch_br_xf<Xf>(t, wpb, num_cus, coop4, o, st, nullptr);
+        if (e != hipSuccess) return e;
+        return done(kFormWorkgroup, 8, 8 * num_cus);
+      }
       const long groups = (a.B + 7) / 8;
       const long grid = groups < num_cus ? groups : num_cus;
       hipLaunchKernelGGL((blind_rotate_wg_kernel<Xf, 8>), dim3((unsigned)grid), dim3(512), 0, st, a);

@@ -462,3 +462,34 @@ def test_workgroup_and_duo_kernels_on_full_keys_against_oracle(which, fix, form,
     if arith_mode == "fft":
         assert be.last_launch()["form"] == form
     assert np.array_equal(got.cpu().numpy()[sample], ctx.bootstrap_batch(ct[sample], mu))
+
+
+@pytest.mark.parametrize("which,fix", [("be_toy_default", "toy_default"), ("be_toy_redsec", "toy_redsec")])
+def test_last_partial_round_runs_in_its_own_form(which, fix, request):
+    """A batch of one full round of the lock-step form plus a remainder of at most 4 x #CUs: the remainder is cut off and
+    launched in the form its size would take by itself (cooperative / duo / half-size groups). Outputs -- also of the
+    programmable bootstrap, whose test polynomial is chosen by the ciphertext's index in the WHOLE batch -- equal the
+    unsplit launch (RS_NO_TAIL context) word for word and the oracle on a sample around the cut."""
+    import os
+    import torch
+    be = request.getfixturevalue(which)
+    ks, ctx = request.getfixturevalue(fix)
+    cus = be.info()["num_cus"]
+    mu = ol.to_torus(1, 8)
+    rng = np.random.default_rng(12)
+    os.environ["RS_NO_TAIL"] = "1"
+    be2 = _backend(ks, "default128" if ks.p.bk_l == 3 else "redsec_small_v2")
+    del os.environ["RS_NO_TAIL"]
+    be2.set_mode(be.mode())
+    luts = _dev(rng.integers(-2**31, 2**31, (7, ks.p.N)).astype(np.int32))
+    for tail in (5, cus + 3, 3 * cus + 1):
+        B = 8 * cus + tail
+        _, ct = _bits(ks, B, 900 + tail)
+        d = _dev(ct)
+        got, ref = be.bootstrap(d, mu), be2.bootstrap(d, mu)
+        assert torch.equal(got, ref), tail
+        assert torch.equal(be.bootstrap_lut(d, luts), be2.bootstrap_lut(d, luts)), tail
+        sample = np.r_[0:4, 8 * cus - 4:8 * cus + 4, B - 4:B]
+        assert np.array_equal(got.cpu().numpy()[sample], ctx.bootstrap_batch(ct[sample], mu)), tail
+    _BACKENDS.remove(be2)
+    be2.close()
