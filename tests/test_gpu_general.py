@@ -182,7 +182,7 @@ def test_split_workgroup_kernel_ragged_groups_and_identity_steps(toy, name, seed
     be.set_mode("split")
 
 
-@pytest.mark.parametrize("toy,name,seed", [("toy_small", "redsec_small", 11), ("toy_medium", "redsec_medium", 13)])
+@pytest.mark.parametrize("toy,name,seed", [("toy_n2048", "default128", 12), ("toy_medium", "redsec_medium", 13)])
 def test_general_kernel_batch_sizes_around_the_resident_grid(toy, name, seed):
     """Persistent workgroups: batches of one ciphertext, just below / at / just above the number of resident workgroups,
     and several rounds with a remainder -- every output equal to the oracle's (full comparison: n is small)."""
@@ -191,6 +191,7 @@ def test_general_kernel_batch_sizes_around_the_resident_grid(toy, name, seed):
     rng = np.random.default_rng(seed + 100)
     mu = ol.to_torus(1, 4096)
     be.bootstrap(_dev(ks.encrypt([mu], 2.0 ** -25, 1)), mu)
+    assert be.last_launch()["form"] == "general"          # rings beyond N = 1024 have no other kernel
     resident = be.last_launch()["resident"]
     assert resident == 1                      # a batch of one occupies one workgroup
     big = _dev(ks.encrypt(rng.integers(-2**31, 2**31, 4096), 2.0 ** -25, 2))
