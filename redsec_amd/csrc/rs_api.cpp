@@ -235,7 +235,7 @@ int run_bootstrap(rs_ctx* c, hipStream_t st, int32_t* out, const Combo* combos, 
         // N = 1024 with one of the reference's gadgets at throughput batch sizes: lock-step workgroups on the split key
         rs::BlindRotateArgs w = br_args(c, ln, 1, cs[k], mu, lut, B);
         w.bk_x = c->d_bk_gen; w.tw = c->d_tw_fft;
-        const hipError_t e = rs::launch_blind_rotate_split_wg(c->wgs_cfg, w, c->num_cus, st, &ln->last);
+        const hipError_t e = rs::launch_blind_rotate_split_wg(c->wgs_cfg, w, c->num_cus, c->opts, st, &ln->last);
         if (e == hipSuccess) { split_wg = true; continue; }
         if (e != hipErrorNotSupported) return fail(RS_ERR_HIP, "split workgroup launch failed: %s", hipGetErrorString(e));
       }

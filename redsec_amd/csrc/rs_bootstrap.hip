@@ -742,10 +742,11 @@ __device__ __forceinline__ void mac_half_stream(double (&s0)[kRegs], double (&s1
   }
 }
 
-template <class C>
-__global__ __launch_bounds__(512) void blind_rotate_wgs_kernel(BlindRotateArgs a) {
+template <class C, int WPB>
+__global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateArgs a) {
   using Xf = XfFft<C>;
-  constexpr int WPB = 8;
+  static_assert(WPB == 8 || WPB == 4, "a 16 KB half-row is fetched as 16 / WPB one-KB chunks per wave");
+  constexpr int kChunks = 16 / WPB;
   constexpr int KPL = 2 * C::L;
   constexpr int kSlotDoubles = 2 * kN;   // one key half-row: 2 columns x N doubles = 16 KB
   constexpr int kWin = 64;
@@ -799,7 +800,7 @@ __global__ __launch_bounds__(512) void blind_rotate_wgs_kernel(BlindRotateArgs a
     int slot_issue = 0;      // its slot, h_issue mod 3
     auto issue_next = [&]() {
       if (h_issue < total_half) {
-        glds_chunks<2>(a.bk_x + (size_t)h_issue * kSlotDoubles + (size_t)(wave * 2) * 128, lane_off, s_key[slot_issue] + (wave * 2) * 128);
+        glds_chunks<kChunks>(a.bk_x + (size_t)h_issue * kSlotDoubles + (size_t)(wave * kChunks) * 128, lane_off, s_key[slot_issue] + (wave * kChunks) * 128);
         ++h_issue;
         slot_issue = slot_issue == 2 ? 0 : slot_issue + 1;
       }
@@ -816,7 +817,7 @@ __global__ __launch_bounds__(512) void blind_rotate_wgs_kernel(BlindRotateArgs a
 #ifdef RS_WGS_DRAIN   // A/B: wait for every outstanding load, as __syncthreads() would
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #else
-      if (h + 1 < total_half) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (h + 1 < total_half) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kChunks) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
       issue_next();
@@ -883,6 +884,159 @@ __global__ __launch_bounds__(512) void blind_rotate_wgs_kernel(BlindRotateArgs a
       }
       if (lane == 0) out[kN] = acc1[0];
     }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Cooperative blind rotation on the SPLIT key (RS_MODE_FFT_SPLIT at latency batch sizes, B <= 2 x #CUs, N = 1024): G waves
+// share ONE ciphertext as in blind_rotate_coop_kernel. Wave g transforms the digit rows [g R, (g+1) R) and multiplies each
+// into FOUR partial sums (low / high key half x two columns; sum index = 2 half + column); every sum has one owner wave
+// that keeps its own partial in registers, adds the other waves' partials from LDS and runs the inverse transform:
+//   G = 4: wave s owns sum s; the rounded low and high results of a column meet in the accumulator by LDS integer
+//          atomics (exact, order-independent);
+//   G = 2: wave w owns both halves of column w -- its two inverse transforms run as a software-pipelined pair.
+// Key half-rows stream from L2 into registers in four chunks per row (the first one requested across the transform).
+// -------------------------------------------------------------------------------------------------
+template <class C, int G>
+__global__ __launch_bounds__(64 * G) void blind_rotate_coops_kernel(BlindRotateArgs a) {
+  using Xf = XfFft<C>;
+  constexpr int KPL = 2 * C::L;
+  constexpr int R = KPL / G;
+  static_assert((G == 2 || G == 4) && KPL % G == 0, "waves split the digit rows evenly within a component");
+  constexpr int OWN = 4 / G;                  // sums per owner wave
+  __shared__ double s_tw[Xf::kTableDoubles + 1];
+  __shared__ __attribute__((aligned(16))) double s_buf[G][kBufDoubles];
+  __shared__ double s_part[G][4 - OWN][kN];   // the sums a wave does NOT own (G = 4: 96 KB, G = 2: 32 KB)
+  __shared__ int32_t s_acc[2][kN];
+  stage_tables(s_tw, a.tw, 64 * G, Xf::kTableDoubles);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const long ct = blockIdx.x;
+  const Field f = a.f;
+  double* buf = s_buf[wave];
+  typename Xf::State tw;
+  Xf::init(tw, lane, s_tw, a.tw);
+  const int32_t* row0 = a.in0 + ct * a.W;
+  const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
+  const int n = a.n;
+  const int comp = wave / (G / 2);
+  const int row_begin = wave * R;
+  auto word = [&](int i) -> int32_t {
+    uint32_t v = (uint32_t)a.c0 * (uint32_t)row0[i];
+    if (row1) v += (uint32_t)a.c1 * (uint32_t)row1[i];
+    return (int32_t)v;
+  };
+  auto owner = [](int sum) { return G == 4 ? sum : (sum & 1); };
+  auto slot = [](int sum, int g) { return G == 4 ? (sum < g ? sum : sum - 1) : (sum >> 1); };   // index among the sums wave g does not own
+  if (wave < 2) {
+    const int32_t barb = modswitch_2N((int32_t)((uint32_t)word(n) + (uint32_t)a.bconst));
+    const int rot = 2 * kN - barb;
+#pragma unroll
+    for (int r = 0; r < kRegs; ++r) {
+      const int j = lane + 64 * r;
+      s_acc[wave][j] = wave == 0 ? 0 : test_vector(a, ct, j, rot);
+    }
+  }
+  __syncthreads();
+  for (int i = 0; i < n; ++i) {
+    const int32_t bara = __builtin_amdgcn_readfirstlane(modswitch_2N(word(i)));
+    if (bara == 0) continue;   // uniform over the workgroup
+    double s[4][kRegs];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int u = 0; u < kRegs; ++u) s[k][u] = 0.0;
+    int32_t d[kRegs];
+#pragma unroll
+    for (int r = 0; r < kRegs; ++r) d[r] = gadget_prepare<C>(rotated_diff(s_acc[comp], lane + 64 * r, bara));
+#pragma unroll 1
+    for (int rr = 0; rr < R; ++rr) {
+      const int row = row_begin + rr;
+      const int q = row - comp * C::L;
+      // half-row (row, half) = [column 0: N doubles][column 1: N doubles], pairs (re, im) of position 8 lane + v at [v][lane]
+      const double2* lo0 = reinterpret_cast<const double2*>(a.bk_x + ((size_t)i * KPL + row) * 4 * kN);
+      const double2* lo1 = lo0 + kN / 2;
+      const double2* hi0 = lo0 + kN;
+      const double2* hi1 = hi0 + kN / 2;
+      auto load4 = [&](const double2* k0, const double2* k1, int v0, double2 (&w0)[4], double2 (&w1)[4]) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { w0[v] = k0[(v0 + v) * 64 + lane]; w1[v] = k1[(v0 + v) * 64 + lane]; }
+      };
+      double2 wa0[4], wa1[4], wb0[4], wb1[4];
+      load4(lo0, lo1, 0, wa0, wa1);
+      double x[kRegs];
+      Xf::fwd_digits(lane, x, d, q, 0u, tw, buf, f);
+      load4(lo0, lo1, 4, wb0, wb1);
+      Xf::mac(s[0], s[1], x, wa0, wa1, 0, f);
+      load4(hi0, hi1, 0, wa0, wa1);
+      Xf::mac(s[0], s[1], x, wb0, wb1, 4, f);
+      load4(hi0, hi1, 4, wb0, wb1);
+      Xf::mac(s[2], s[3], x, wa0, wa1, 0, f);
+      Xf::mac(s[2], s[3], x, wb0, wb1, 4, f);
+    }
+    // partial sums a wave does not own go through LDS (position u*64 + lane is conflict-free)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (owner(k) != wave) {
+        double* dst = s_part[wave][slot(k, wave)];
+#pragma unroll
+        for (int u = 0; u < kRegs; ++u) dst[u * 64 + lane] = s[k][u];
+      }
+    }
+    __syncthreads();   // partials visible; every wave has finished reading the accumulator
+    if constexpr (G == 4) {
+      double x[kRegs];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (wave == k) {
+#pragma unroll
+          for (int u = 0; u < kRegs; ++u) x[u] = s[k][u];
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (g != wave) {
+          const double* src = s_part[g][slot(wave, g)];
+#pragma unroll
+          for (int u = 0; u < kRegs; ++u) x[u] += src[u * 64 + lane];
+        }
+      }
+      Xf::inverse(lane, x, tw, buf, f);
+      const int sh = wave >= 2 ? 16 : 0;
+      int32_t* acc = s_acc[wave & 1];
+#pragma unroll
+      for (int r = 0; r < kRegs; ++r) atomicAdd(reinterpret_cast<unsigned*>(acc) + lane + 64 * r, (uint32_t)f_to_torus32(x[r]) << sh);
+    } else {
+      double xa[kRegs], xb[kRegs];
+      if (wave == 0) {
+#pragma unroll
+        for (int u = 0; u < kRegs; ++u) { xa[u] = s[0][u]; xb[u] = s[2][u]; }
+      } else {
+#pragma unroll
+        for (int u = 0; u < kRegs; ++u) { xa[u] = s[1][u]; xb[u] = s[3][u]; }
+      }
+      const double* pa = s_part[1 - wave][0];
+      const double* pb = s_part[1 - wave][1];
+#pragma unroll
+      for (int u = 0; u < kRegs; ++u) { xa[u] += pa[u * 64 + lane]; xb[u] += pb[u * 64 + lane]; }
+      Xf::inverse2(lane, xa, xb, tw, buf, f);
+      int32_t* acc = s_acc[wave];
+#pragma unroll
+      for (int r = 0; r < kRegs; ++r) {
+        const int j = lane + 64 * r;
+        acc[j] = (int32_t)((uint32_t)acc[j] + (uint32_t)f_to_torus32(xa[r]) + ((uint32_t)f_to_torus32(xb[r]) << 16));
+      }
+    }
+    __syncthreads();   // accumulator updated
+  }
+  int32_t* out = a.u_out + ct * (kN + 1);
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < kRegs; ++r) {
+      const int j = lane + 64 * r;
+      out[j] = (j == 0) ? s_acc[0][0] : (int32_t)(0u - (uint32_t)s_acc[0][kN - j]);
+    }
+    if (lane == 0) out[kN] = s_acc[1][0];
   }
 }
 
@@ -1338,16 +1492,46 @@ hipError_t launch_blind_rotate(int cfg, int mode, const BlindRotateArgs& a, int 
 
 // Split-key workgroup form (N = 1024; cfg 0 / 1 = the two shipped gadgets, 2 = redsec_params_small's l=3 Bgbit=10): a.bk_x = the split key of rs_general.h,
 // a.tw = the FFT tables of rs_fft.h. Returns hipErrorNotSupported for an unknown gadget id (caller: general kernel).
-hipError_t launch_blind_rotate_split_wg(int cfg, const BlindRotateArgs& a, int num_cus, hipStream_t st, LaunchInfo* info) {
+hipError_t launch_blind_rotate_split_wg(int cfg, const BlindRotateArgs& a, int num_cus, const LaunchOpts& o, hipStream_t st, LaunchInfo* info) {
   // any batch size: even a single group of it walks its CMUX chain in 57 us per step (REDsec set) against the 92 us of a lone
-  // wave of the general kernel (sign1024x1 in split mode: 65.7 -> 40 ms)
-  const long groups = (a.B + 7) / 8;
+  // wave of the general kernel (sign1024x1 in split mode: 65.7 -> 40 ms). Up to 4 ciphertexts per CU the groups are 4 waves:
+  // one wave per SIMD on twice the CUs.
+  auto coop = [&](auto c) {
+    using C = decltype(c);
+    LaunchInfo li;
+    li.form = kFormSplitCoop; li.resident = 1;
+    if constexpr ((2 * C::L) % 4 == 0) {
+      if (a.B <= num_cus) {
+        hipLaunchKernelGGL((blind_rotate_coops_kernel<C, 4>), dim3((unsigned)a.B), dim3(256), 0, st, a);
+        li.waves_per_block = 4;
+        if (info) *info = li;
+        return hipGetLastError();
+      }
+    }
+    hipLaunchKernelGGL((blind_rotate_coops_kernel<C, 2>), dim3((unsigned)a.B), dim3(128), 0, st, a);
+    li.waves_per_block = 2;
+    if (info) *info = li;
+    return hipGetLastError();
+  };
+  if (!o.no_coop && a.B <= 2L * num_cus) {   // latency form: several waves per ciphertext, as in the unsplit modes
+    if (cfg == 0) return coop(CfgDefault128{});
+    if (cfg == 1) return coop(CfgRedsecV2{});
+    if (cfg == 2) return coop(CfgRedsecSmall{});
+    return hipErrorNotSupported;
+  }
+  const int wpb = (a.B <= 4L * num_cus && !o.no_wg4) ? 4 : 8;
+  const long groups = (a.B + wpb - 1) / wpb;
   const long grid = groups < num_cus ? groups : num_cus;
-  if (cfg == 0) hipLaunchKernelGGL((blind_rotate_wgs_kernel<CfgDefault128>), dim3((unsigned)grid), dim3(512), 0, st, a);
-  else if (cfg == 1) hipLaunchKernelGGL((blind_rotate_wgs_kernel<CfgRedsecV2>), dim3((unsigned)grid), dim3(512), 0, st, a);
-  else if (cfg == 2) hipLaunchKernelGGL((blind_rotate_wgs_kernel<CfgRedsecSmall>), dim3((unsigned)grid), dim3(512), 0, st, a);
+  auto go = [&](auto c) {
+    using C = decltype(c);
+    if (wpb == 8) hipLaunchKernelGGL((blind_rotate_wgs_kernel<C, 8>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((blind_rotate_wgs_kernel<C, 4>), dim3((unsigned)grid), dim3(256), 0, st, a);
+  };
+  if (cfg == 0) go(CfgDefault128{});
+  else if (cfg == 1) go(CfgRedsecV2{});
+  else if (cfg == 2) go(CfgRedsecSmall{});
   else return hipErrorNotSupported;
-  if (info) { info->form = kFormSplitWorkgroup; info->waves_per_block = 8; info->resident = 8 * grid; }
+  if (info) { info->form = kFormSplitWorkgroup; info->waves_per_block = wpb; info->resident = wpb * grid; }
   return hipGetLastError();
 }
 

@@ -45,7 +45,7 @@ struct LaunchOpts {
 };
 // What a blind-rotate launch actually ran: kernel form and how many ciphertexts share one sweep of the key
 // from L2/HBM (R of SURVEY.md section 8d).
-enum { kFormPerWave = 0, kFormWorkgroup = 1, kFormDuo = 2, kFormCoop2 = 3, kFormCoop4 = 4, kFormGeneral = 5, kFormSplitWorkgroup = 6 };
+enum { kFormPerWave = 0, kFormWorkgroup = 1, kFormDuo = 2, kFormCoop2 = 3, kFormCoop4 = 4, kFormGeneral = 5, kFormSplitWorkgroup = 6, kFormSplitCoop = 7 };
 struct LaunchInfo { int form = -1; int waves_per_block = 0; long resident = 0; };
 
 struct KeyswitchArgs {
@@ -80,7 +80,7 @@ struct PoolShape { int32_t H, Wd, C, win_h, win_w, stride_h, stride_w, off_h, of
 // cfg: 0 = CfgDefault128 (l=3, Bgbit=7), 1 = CfgRedsecV2 (l=10, Bgbit=3); mode: 0 = exact NTT, 1 = FFT
 hipError_t launch_blind_rotate(int cfg, int mode, const BlindRotateArgs& a, int waves_per_block, int num_cus, const LaunchOpts& opts,
                                hipStream_t st, LaunchInfo* info = nullptr);
-hipError_t launch_blind_rotate_split_wg(int cfg, const BlindRotateArgs& a, int num_cus, hipStream_t st, LaunchInfo* info);
+hipError_t launch_blind_rotate_split_wg(int cfg, const BlindRotateArgs& a, int num_cus, const LaunchOpts& opts, hipStream_t st, LaunchInfo* info);
 hipError_t launch_bk_transform(int cfg, int mode, const int32_t* bk, double* bk_x, const double* tw, Field f, double scale,
                                long n_polys, hipStream_t st);
 hipError_t launch_keyswitch(const KeyswitchArgs& a, hipStream_t st);

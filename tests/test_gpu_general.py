@@ -307,3 +307,50 @@ def test_split_workgroup_kernel_on_redsec_params_small(monkeypatch):
     be2.close()
     sample = np.r_[0:8, 8 * cus:8 * cus + 8, B - 9:B]
     assert np.array_equal(got.cpu().numpy()[sample], ctx.bootstrap_batch(ct[sample], mu))
+
+
+@pytest.mark.parametrize("toy,name,seed", SPLIT_ON_SHIPPED + [("toy_small", "redsec_small", 11)])
+def test_split_mode_small_batch_forms(toy, name, seed):
+    """The split-key mode at latency batch sizes (N = 1024 sets): cooperative kernel with 4 waves per ciphertext up to one
+    ciphertext per CU when 2l is a multiple of 4 (REDsec shipped set), 2 waves up to two per CU, then lock-step groups of
+    4 waves up to four per CU, 8 beyond. Every form equal word for word to the oracle on a sample and to the batch pushed
+    through the 8-wave form in one piece (a row's result does not depend on the batch it travels in); gates and the
+    programmable bootstrap through the cooperative form; mask words forced to 0 (identity CMUX steps)."""
+    import torch
+    ks, ctx, be = _setup(toy, name, seed)
+    cus = be.info()["num_cus"]
+    l = ks.p.bk_l if hasattr(ks.p, "bk_l") else ks.p.l
+    rng = np.random.default_rng(123)
+    e8 = ol.to_torus(1, 8)
+    B = 8 * cus + 8
+    ct = ks.encrypt(np.where(rng.integers(0, 2, B) == 1, e8, -e8), 2.0 ** -15, 555).copy()
+    ct[1, :2] = 0
+    ct[2, : ks.p.n] = 0
+    d = _dev(ct)
+    if name != "redsec_small":
+        be.set_mode("split")
+    whole = be.bootstrap(d, e8)
+    assert be.last_launch() == {"form": "split_workgroup", "waves_per_block": 8, "resident": 8 * cus}
+    coop4 = (2 * l) % 4 == 0
+    cases = [(1, "split_coop", 4 if coop4 else 2), (cus, "split_coop", 4 if coop4 else 2), (cus + 1, "split_coop", 2),
+             (2 * cus, "split_coop", 2), (2 * cus + 1, "split_workgroup", 4), (4 * cus, "split_workgroup", 4),
+             (4 * cus + 1, "split_workgroup", 8)]
+    for b, form, waves in cases:
+        got = be.bootstrap(d[:b], e8)
+        ll = be.last_launch()
+        assert (ll["form"], ll["waves_per_block"]) == (form, waves), (b, ll)
+        assert torch.equal(got, whole[:b]), (b, form)
+    sample = np.r_[0:6, cus - 2:cus + 2]
+    assert np.array_equal(whole.cpu().numpy()[sample], ctx.bootstrap_batch(ct[sample], e8))
+    # two-input gates, MUX and the programmable form through the cooperative kernels
+    cb = _dev(ks.encrypt(np.where(rng.integers(0, 2, B) == 1, e8, -e8), 2.0 ** -15, 556))
+    cc = _dev(ks.encrypt(np.where(rng.integers(0, 2, B) == 1, e8, -e8), 2.0 ** -15, 557))
+    luts = _dev(rng.integers(-2**31, 2**31, (3, ks.p.N)).astype(np.int32))
+    g_whole, m_whole, l_whole = be.gate("NAND", d, cb), be.mux(d, cb, cc), be.bootstrap_lut(d, luts)
+    for b in (7, cus + 3):
+        assert torch.equal(be.gate("NAND", d[:b], cb[:b]), g_whole[:b])
+        assert be.last_launch()["form"] == "split_coop"
+        assert torch.equal(be.mux(d[:b], cb[:b], cc[:b]), m_whole[:b])
+        assert torch.equal(be.bootstrap_lut(d[:b], luts), l_whole[:b])
+    if name != "redsec_small":
+        be.set_mode("fft")
