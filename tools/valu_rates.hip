@@ -82,6 +82,26 @@ KERNEL32(k_alignbit, uint32_t, I_ALIGN)
 KERNEL32(k_mov_dpp_quad, uint32_t, I_DPPQ)
 KERNEL32(k_mov_dpp_rowshr, uint32_t, I_DPPROW)
 KERNEL32(k_add_dpp_quad, uint32_t, I_ADDDPP)
+// ---- gfx950 half-wave / row swaps: both operands are written (lane bit 5 / lane bit 4 <-> register transposition)
+#define BODYSWAP(OP) \
+  asm volatile( \
+    OP " %0, %1\n\t" OP " %2, %3\n\t" OP " %4, %5\n\t" OP " %6, %7\n\t" OP " %1, %2\n\t" OP " %3, %4\n\t" OP " %5, %6\n\t" OP " %7, %0\n\t" \
+    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7))
+#define KERNELSWAP(NAME, OP) \
+__global__ void NAME(uint32_t* out, uint32_t b, uint32_t c, unsigned long long* clk) { \
+  uint32_t a0 = threadIdx.x + b, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + c; \
+  unsigned long long t0 = __builtin_amdgcn_s_memtime(); \
+  unsigned long long r0 = __builtin_amdgcn_s_memrealtime(); \
+  for (int it = 0; it < ITERS; ++it) { \
+    BODYSWAP(OP); BODYSWAP(OP); BODYSWAP(OP); BODYSWAP(OP); \
+  } \
+  unsigned long long t1 = __builtin_amdgcn_s_memtime(); \
+  unsigned long long r1 = __builtin_amdgcn_s_memrealtime(); \
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7; \
+  if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; } \
+}
+KERNELSWAP(k_permlane32_swap, "v_permlane32_swap_b32")
+KERNELSWAP(k_permlane16_swap, "v_permlane16_swap_b32")
 // ---- 64-bit integer
 #define I_MAD64(R)  "v_mad_u64_u32 " #R ", vcc, %8, %9, " #R "\n\t"
 #define I_LSHL64(R) "v_lshlrev_b64 " #R ", 5, " #R "\n\t"
@@ -293,6 +313,8 @@ int main() {
     RUN32(k_mov_dpp_quad, uint32_t, 0, 0);
     RUN32(k_mov_dpp_rowshr, uint32_t, 0, 0);
     RUN32(k_add_dpp_quad, uint32_t, 1, 0);
+    RUN32(k_permlane32_swap, uint32_t, 0, 7);
+    RUN32(k_permlane16_swap, uint32_t, 0, 7);
     RUN32(k_lshl_b64, uint64_t, 0, 0);
     run("k_mad_u64_u32", w, n_simple, [&](int g, int b) { hipLaunchKernelGGL(k_mad_u64_u32, dim3(g), dim3(b), 0, 0, (uint64_t*)d_out, 0x9e3779b9u, 0x7f4a7c15u, d_clk); }, d_clk, n_cu);
     run("k_add_u64(2 instr)", w, n_simple, [&](int g, int b) { hipLaunchKernelGGL(k_add_u64, dim3(g), dim3(b), 0, 0, (uint64_t*)d_out, 0x9e3779b97f4a7c15ull, 0ull, d_clk); }, d_clk, n_cu);
