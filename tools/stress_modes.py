@@ -23,7 +23,7 @@ for name, n in (("default128", int(os.environ.get("STRESS_N", 48))), ("redsec_sm
     be = redsec_amd.Backend(redsec_amd.params(name, n=n), 0)
     be.load_keys(sk.bk, sk.ksk)
     cus = be.info()["num_cus"]
-    edges = [1, 2, cus - 1, cus, cus + 1, 2 * cus, 2 * cus + 1, 4 * cus, 8 * cus - 1, 8 * cus, 8 * cus + 1, 16 * cus + 3, 24 * cus]
+    edges = [1, 2, cus - 1, cus, cus + 1, 2 * cus, 2 * cus + 1, 4 * cus, 4 * cus + 1, 8 * cus - 1, 8 * cus, 8 * cus + 1, 12 * cus + 5, 16 * cus + 3, 24 * cus]
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     for r in range(rounds):
         B = int(edges[r % len(edges)] if r < 2 * len(edges) else rng.integers(1, 30 * cus))
