@@ -17,7 +17,8 @@ Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel (blind rotati
 roofline as the contract asks; `roofline_valu` prices it against the FP64 vector-ALU issue rate,
 which is what actually bounds it. `cpu_baseline` is the exact-integer CPU
 oracle (kind "port": TFHE itself is not available) timed on the host cores on a bounded sample of
-the same inputs and keys, and doubles as the in-run parity check.
+the same inputs and keys, and doubles as the in-run parity check. At N = 1 the line also carries the second half of
+BASELINE.json's metric, `mnist_sign1024x1`: the latency of one encrypted MNIST image (configs[2]).
 """
 import argparse
 import json
@@ -81,6 +82,50 @@ def host_cpu_share():
     return n
 
 
+def mnist_image_latency(device_index):
+    """The second half of BASELINE.json's metric (configs[2]): ONE encrypted MNIST sign1024x1 image, device-resident, through
+    the layer chain of redsec_amd/nets.py on the parameter set REDsec ships (1,220 bootstraps in batches of 196 and 1,024;
+    trained weights and a bundled test image from tests/golden). The same image is pushed through the split-key mode as
+    well: the 10 logit ciphertexts must be equal word for word."""
+    import numpy as np
+    import torch
+    import redsec_amd
+    from redsec_amd import client, nets
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import plain_model as pm
+    sk = client.SecretKeySet("redsec_small_v2", seed=7)
+    be = redsec_amd.Backend(redsec_amd.params("redsec_small_v2"), device=device_index)
+    be.load_keys(sk.bk, sk.ksk)
+    enc = nets.EncryptedMnist(be, pm.load_net("sign1024x1"))
+    labels, pixels = pm.load_images()
+    ct = torch.from_numpy(sk.encrypt_image(pixels[1], seed=5)).cuda(device_index)
+
+    def timed(reps):
+        for _ in range(2):
+            out = enc.run(ct)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            out = enc.run(ct)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return out, 1e3 * float(np.median(ts))
+    out_f, ms_f = timed(5)
+    be.set_mode("split")
+    out_s, ms_s = timed(3)
+    be.set_mode("fft")
+    logits = sk.decrypt_ints(out_f.cpu().numpy())
+    res = {"ms_per_image": round(ms_f, 3), "unit": "ms", "images_per_call": 1, "bootstraps_per_image": 196 + 1024,
+           "params": "redsec_small_v2", "mode": "fft", "split_mode_ms_per_image": round(ms_s, 3),
+           "logit_ciphertexts_equal_in_split_mode": bool(torch.equal(out_f, out_s)),
+           "data": "bundled MNIST test image, trained sign1024x1 weights (tests/golden)"}
+    res["encrypted_argmax"] = int(np.argmax(logits))
+    res["label"] = int(labels[1])
+    be.close()
+    return res
+
+
 def relaunch_under_torchrun(args):
     """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process (this process has
     not touched the GPU yet: no torch.cuda call, no HIP call) and leave with its exit code."""
@@ -115,6 +160,7 @@ def main():
                          "a 51-bit prime (exact by construction)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="gates timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-exact-check", action="store_true", help="skip the exact-NTT mode leg (its throughput and the full-batch cross-check)")
+    ap.add_argument("--no-mnist", action="store_true", help="skip the encrypted-MNIST-image latency leg (N = 1 only)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xC0FFEE)
     args = ap.parse_args()
 
@@ -337,7 +383,8 @@ def main():
             except Exception:
                 pass
         kernel_name = {"workgroup": "blind_rotate_wg_kernel", "duo": "blind_rotate_duo_kernel", "per_wave": "blind_rotate_kernel",
-                       "coop2": "blind_rotate_coop_kernel", "coop4": "blind_rotate_coop_kernel", "general": "gen_blind_rotate_kernel", "split_workgroup": "blind_rotate_wgs_kernel"}[launch["form"]]
+                       "coop2": "blind_rotate_coop_kernel", "coop4": "blind_rotate_coop_kernel", "general": "gen_blind_rotate_kernel", "split_workgroup": "blind_rotate_wgs_kernel",
+                       "split_coop": "blind_rotate_coops_kernel"}[launch["form"]]
         roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel_ms": round(last_br, 3), "algorithmic_bytes_per_launch": int(alg_bytes),
@@ -391,6 +438,8 @@ def main():
                                  "the oracle's FP64-FFT product path (exact after rounding, equal to the GPU output word for word); "
                                  "TFHE itself unavailable" % (bsample, cpu_s, cores)}
 
+        mnist = mnist_image_latency(local_rank) if (world == 1 and not args.no_mnist) else None
+
         line = {
             "metric": "gate bootstraps/sec (N=1024)", "value": round(value, 1), "unit": "bootstraps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -401,6 +450,7 @@ def main():
                        "gates_per_gpu": G, "total_gates": total_gates, "params": args.params, "mode": args.mode,
                        "parallelism": "gate-sharded x%d%s" % (world, "" if world == 1 else (", outputs all-gathered over RCCL, overlapped with the next step" if gather else ", no gather"))},
             "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu, "exact_mode": exact_mode, "split_mode": split_mode,
+            "mnist_sign1024x1": mnist,
             "collective": None if not gather else {"op": "all_gather_into_tensor", "bytes_per_rank": int(width_rows * be.W * 4),
                                                    "bytes_received_per_rank": int(world * width_rows * be.W * 4),
                                                    "ms_alone_unoverlapped": round(gather_ms, 3), "inside_timed_region": True,
