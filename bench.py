@@ -433,7 +433,7 @@ def main():
                 ref_fft = octx.gate_batch("NAND", ca_h[:bsample], cb_h[:bsample])
                 cpu_s = time.perf_counter() - t1
                 parity = parity and bool(np.array_equal(ref_fft, got[:bsample]))
-                cpu = {"value": round(bsample / cpu_s, 3), "unit": "bootstraps/s", "cores": int(cores), "kind": "port",
+                cpu = {"value": round(bsample / cpu_s, 3), "unit": "bootstraps/s", "cores": int(cores), "per_core": round(bsample / cpu_s / cores, 2), "kind": "port",
                        "sample": "%d NAND gates of the same batch (same keys, same inputs), %.1f s wall on %d OpenMP threads; "
                                  "the oracle's FP64-FFT product path (exact after rounding, equal to the GPU output word for word); "
                                  "TFHE itself unavailable" % (bsample, cpu_s, cores)}
