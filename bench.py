@@ -82,7 +82,7 @@ def host_cpu_share():
     return n
 
 
-def mnist_image_latency(device_index):
+def redsec_set_legs(device_index, gates):
     """The second half of BASELINE.json's metric (configs[2]): ONE encrypted MNIST sign1024x1 image, device-resident, through
     the layer chain of redsec_amd/nets.py on the parameter set REDsec ships (1,220 bootstraps in batches of 196 and 1,024;
     trained weights and a bundled test image from tests/golden). The same image is pushed through the split-key mode as
@@ -122,8 +122,25 @@ def mnist_image_latency(device_index):
            "data": "bundled MNIST test image, trained sign1024x1 weights (tests/golden)"}
     res["encrypted_argmax"] = int(np.argmax(logits))
     res["label"] = int(labels[1])
+    # "also run the REDsec set" -- the same 65,536-NAND step on the shipped parameters
+    rng = np.random.default_rng(11)
+    ba, bb = rng.integers(0, 2, gates), rng.integers(0, 2, gates)
+    ca = torch.from_numpy(sk.encrypt_bits(ba, seed=21)).cuda(device_index)
+    cb = torch.from_numpy(sk.encrypt_bits(bb, seed=22)).cuda(device_index)
+    out = be.empty(gates, be.W)
+    be.gate("NAND", ca, cb, out=out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        be.gate("NAND", ca, cb, out=out)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 2
+    ok = bool(np.array_equal(sk.decrypt_bits(out.cpu().numpy()), 1 - (ba & bb)))
+    nands = {"value": round(gates / dt, 1), "unit": "bootstraps/s", "ms_per_step": round(1e3 * dt, 3), "steps": 2, "gates": int(gates),
+             "params": "redsec_small_v2 (n=350 N=1024 l=10 Bgbit=3 t=9 basebit=3)", "mode": "fft", "kernel_form": be.last_launch()["form"],
+             "all_outputs_decrypt_to_nand": ok, "fft_rounding_certificate": round(be.rounding_certificate(), 6)}
     be.close()
-    return res
+    return res, nands
 
 
 def relaunch_under_torchrun(args):
@@ -160,7 +177,7 @@ def main():
                          "a 51-bit prime (exact by construction)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="gates timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-exact-check", action="store_true", help="skip the exact-NTT mode leg (its throughput and the full-batch cross-check)")
-    ap.add_argument("--no-mnist", action="store_true", help="skip the encrypted-MNIST-image latency leg (N = 1 only)")
+    ap.add_argument("--no-mnist", action="store_true", help="skip the legs on the parameter set REDsec ships: encrypted-MNIST-image latency and the same NAND step (N = 1 only)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xC0FFEE)
     args = ap.parse_args()
 
@@ -438,7 +455,7 @@ def main():
                                  "the oracle's FP64-FFT product path (exact after rounding, equal to the GPU output word for word); "
                                  "TFHE itself unavailable" % (bsample, cpu_s, cores)}
 
-        mnist = mnist_image_latency(local_rank) if (world == 1 and not args.no_mnist) else None
+        mnist, redsec_nands = redsec_set_legs(local_rank, G) if (world == 1 and not args.no_mnist and args.params == "default128") else (None, None)
 
         line = {
             "metric": "gate bootstraps/sec (N=1024)", "value": round(value, 1), "unit": "bootstraps/s",
@@ -450,7 +467,7 @@ def main():
                        "gates_per_gpu": G, "total_gates": total_gates, "params": args.params, "mode": args.mode,
                        "parallelism": "gate-sharded x%d%s" % (world, "" if world == 1 else (", outputs all-gathered over RCCL, overlapped with the next step" if gather else ", no gather"))},
             "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu, "exact_mode": exact_mode, "split_mode": split_mode,
-            "mnist_sign1024x1": mnist,
+            "mnist_sign1024x1": mnist, "redsec_params_nands": redsec_nands,
             "collective": None if not gather else {"op": "all_gather_into_tensor", "bytes_per_rank": int(width_rows * be.W * 4),
                                                    "bytes_received_per_rank": int(world * width_rows * be.W * 4),
                                                    "ms_alone_unoverlapped": round(gather_ms, 3), "inside_timed_region": True,
