@@ -68,3 +68,34 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".cpp", ".h", ".hip")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "redsec_oracle" not in src and "oracle_lib" not in src, f
+
+
+def test_header_is_plain_c99_and_a_c_program_links(tmp_path):
+    """The drop-in boundary is a C ABI: include/redsec_hip.h must compile under a C compiler (no C++ in the
+    signatures) and a C program must link against libredsec_hip.so. Without a GPU rs_create has to fail with a
+    message, never compute."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "cabi.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <string.h>\n#include "redsec_hip.h"\n'
+        "int main(void) {\n"
+        "  rs_params p; rs_ctx* c = NULL;\n"
+        "  if (rs_params_default128(&p) != 0 || p.N != 1024 || p.n != 630) return 2;\n"
+        "  if (rs_params_redsec_small_v2(&p) != 0 || p.n != 350) return 3;\n"
+        "  if (!rs_version() || strlen(rs_version()) == 0) return 4;\n"
+        "  if (rs_create(&c, &p, 0) == 0) { puts(\"created\"); rs_destroy(c); return 0; }\n"
+        "  printf(\"refused: %s\\n\", rs_last_error());\n"
+        "  return 0;\n}\n")
+    lib_dir = os.path.join(ROOT, "redsec_amd")
+    exe = tmp_path / "cabi"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                    "-L", lib_dir, "-lredsec_hip", "-Wl,-rpath," + lib_dir, "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        assert "refused: " in r.stdout and "no HIP device" in r.stdout, r.stdout
