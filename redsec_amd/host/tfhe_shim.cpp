@@ -48,11 +48,18 @@ struct ParamHeader {
   double lwe_alpha_min, lwe_alpha_max, tlwe_alpha_min, tlwe_alpha_max;
 };
 
+// Parameter objects read from a key file belong to the process, as in TFHE (its readers hand them to the garbage
+// collector, delete_gate_bootstrapping_*_keyset leaves them alone): kept reachable here for the process lifetime.
 TFheGateBootstrappingParameterSet* params_from_header(const ParamHeader& h) {
   LweParams* lp = new_LweParams(h.n, h.lwe_alpha_min, h.lwe_alpha_max);
   TLweParams* tp = new_TLweParams(h.N, h.k, h.tlwe_alpha_min, h.tlwe_alpha_max);
   TGswParams* gp = new_TGswParams(h.l, h.Bgbit, tp);
-  return new TFheGateBootstrappingParameterSet(h.ks_t, h.ks_basebit, lp, gp);
+  TFheGateBootstrappingParameterSet* p = new TFheGateBootstrappingParameterSet(h.ks_t, h.ks_basebit, lp, gp);
+  static std::mutex mu;
+  static std::vector<TFheGateBootstrappingParameterSet*>* const owned = new std::vector<TFheGateBootstrappingParameterSet*>();
+  std::lock_guard<std::mutex> lock(mu);
+  owned->push_back(p);
+  return p;
 }
 
 ParamHeader header_from_params(uint32_t magic, const TFheGateBootstrappingParameterSet* p) {
