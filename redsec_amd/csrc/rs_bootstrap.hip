@@ -24,6 +24,8 @@
 //   RS_WGS_FWD_NOAHEAD, RS_WGS_DRAIN                    split-key workgroup kernel: twiddles fetched stage by stage (-1.9 %); full drain at barriers (+-0)
 //   RS_T_WPB4                                           timing: 4 ciphertexts per workgroup = one wave per SIMD (results correct): 78 % of the rate
 //   RS_NO_CERT, RS_T_NOBAR, RS_T_STAGGER=<n>, RS_T_HALFSTORE, RS_T_HALFLOAD   TIMING PROBES: results are wrong
+//   RS_STAMPS                                           DIAGNOSTIC: s_memtime stamps at the phase boundaries of blind_rotate_wg_kernel, summed per wave into
+//                                                       g_rs_stamps (tools/stamp_profile.py reads the SHARES; the stamps drain LDS reads, so never quote its run time)
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -501,6 +503,26 @@ __device__ __forceinline__ void mac_pair_stream(double (&s0)[kRegs], double (&s1
   }
 }
 
+#ifdef RS_STAMPS
+// Diagnostic build only (cdna_hip_programming.md section 7, in-kernel stamps): phase sums per wave, read back by
+// rs_debug_read_stamps. Phases: 0 step prologue, 1 digits + forward pair, 2 wait for the key rows + barrier, 3 multiply-
+// accumulate, 4 barrier + next rows requested, 5 accumulator pre-read + inverse pair, 6 rounding + accumulator update,
+// 7 group prologue / sample extract.
+constexpr int kStampPhases = 8;
+__device__ unsigned long long g_rs_stamps[256 * 8 * kStampPhases];
+#define RS_STAMP_DECL unsigned long long st_sum_[kStampPhases] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_last_; \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last_) :: "memory")
+#define RS_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+  st_sum_[k] += t_ - st_last_; st_last_ = t_; } while (0)
+#define RS_STAMP_FLUSH(wave) do { if (lane == 0 && blockIdx.x < 256) { for (int k_ = 0; k_ < kStampPhases; ++k_) \
+  g_rs_stamps[((size_t)blockIdx.x * 8 + (wave)) * kStampPhases + k_] = st_sum_[k_]; } } while (0)
+#else
+#define RS_STAMP_DECL ((void)0)
+#define RS_STAMP(k) ((void)0)
+#define RS_STAMP_FLUSH(wave) ((void)0)
+#endif
+
 template <class Xf, int WPB>
 __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateArgs a) {
   using C = typename Xf::Cfg;
@@ -528,6 +550,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
   double dev = 0.0;
   const long n_groups = (a.B + WPB - 1) / WPB;
   const long total_rows = (long)n * KPL;
+  RS_STAMP_DECL;
 #ifdef RS_WG_SETPRIO   // A/B: static priority for the second-dispatched half of the workgroup (the arbitration loser)
   if (wave >= WPB / 2) __builtin_amdgcn_s_setprio(RS_WG_SETPRIO);
 #endif
@@ -576,6 +599,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
     __syncthreads();
     issue_row(0);
     issue_row(1);
+    RS_STAMP(7);
 #ifdef RS_T_STAGGER   // timing experiments only: start the waves RS_T_STAGGER x 64 cycles apart
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int w = 0; w < wave * RS_T_STAGGER; ++w) __builtin_amdgcn_s_sleep(1);
@@ -595,6 +619,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
 #pragma unroll
       for (int u = 0; u < kRegs; ++u) { s0[u] = 0.0; s1[u] = 0.0; }
       int32_t d[kRegs];
+      RS_STAMP(0);
 
       // d holds the PREPARED rotated difference of one component (gadget offset added and field sign bits
       // flipped once per component, not per digit row). Written as straight-line code with a
@@ -618,6 +643,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
           Xf::digits(xb, d, qB);
           Xf::fwd_pair_wg(lane, xa, xb, tw, buf);
         }
+        RS_STAMP(1);
 #ifndef RS_T_NOBAR   // timing experiments only (results are wrong without the barriers)
 #ifdef RS_WG_BAREBAR   // A/B: bare s_barrier behind explicit counts instead of __syncthreads()
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -626,6 +652,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
         __syncthreads();
 #endif
 #endif
+        RS_STAMP(2);
         if (work) {
 #ifdef RS_NO_MAC_STREAM
           mac_row(s0, s1, xa, 0);
@@ -634,6 +661,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
           mac_pair_stream(s0, s1, xa, xb, s_key[0], s_key[1], lane);
 #endif
         }
+        RS_STAMP(3);
 #ifndef RS_T_NOBAR
 #ifdef RS_WG_BAREBAR
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -643,6 +671,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
         R += 2;
         if (R < total_rows) { issue_row(R); issue_row(R + 1); }
 #endif
+        RS_STAMP(4);
       };
       if constexpr (C::L % 2 == 0) {
         if (work) load_d(std::false_type{});
@@ -679,6 +708,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
         for (int r = 0; r < kRegs; ++r) { a0[r] = (uint32_t)acc0[lane + 64 * r]; a1[r] = (uint32_t)acc1[lane + 64 * r]; }
         wave_lds_sync();
         Xf::inverse_pair_wg(lane, s0, s1, tw, buf);
+        RS_STAMP(5);
 #pragma unroll
         for (int r = 0; r < kRegs; ++r) {
           const int j = lane + 64 * r;
@@ -687,6 +717,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
         }
 #endif
         wave_lds_sync();
+        RS_STAMP(6);
       }
     }
 
@@ -700,7 +731,9 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
       }
       if (lane == 0) out[kN] = acc1[0];
     }
+    RS_STAMP(7);
   }
+  RS_STAMP_FLUSH(wave);
   if (Xf::kCertificate) publish_certificate(dev, a.dev_flag, lane);
 }
 
@@ -1564,3 +1597,14 @@ hipError_t launch_polymul(int cfg, int mode, const int32_t* a_small, const int32
 }
 
 }  // namespace rs
+
+#ifdef RS_STAMPS
+// diagnostic builds only (not part of include/redsec_hip.h): copy the per-wave phase sums to the host and clear them
+extern "C" int rs_debug_read_stamps(unsigned long long* host, size_t count) {
+  const size_t all = sizeof(rs::g_rs_stamps) / sizeof(unsigned long long);
+  if (count > all) count = all;
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(rs::g_rs_stamps), count * sizeof(unsigned long long)) != hipSuccess) return 1;
+  static unsigned long long zeros[256 * 8 * rs::kStampPhases];
+  return hipMemcpyToSymbol(HIP_SYMBOL(rs::g_rs_stamps), zeros, sizeof(zeros)) == hipSuccess ? 0 : 1;
+}
+#endif
