@@ -228,6 +228,15 @@ struct XfFft {
   __device__ static __forceinline__ void inverse_pair_wg(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const State& st, double* buf) {
     finv_pair<true>(lane, xa, xb, st, buf, [] { wave_lds_sync(); });
   }
+  // the same with a segment hook (issue-priority toggling in blind_rotate_wg_kernel)
+  template <class Seg>
+  __device__ static __forceinline__ void fwd_pair_wg(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const State& st, double* buf, Seg seg) {
+    ffwd_pair<true>(lane, xa, xb, st, buf, [] { wave_lds_sync(); }, seg);
+  }
+  template <class Seg>
+  __device__ static __forceinline__ void inverse_pair_wg(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const State& st, double* buf, Seg seg) {
+    finv_pair<true>(lane, xa, xb, st, buf, [] { wave_lds_sync(); }, seg);
+  }
 };
 
 // largest rounding distance of the wave -> device flag (positive doubles order like their bit patterns)
@@ -554,6 +563,27 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
 #ifdef RS_WG_SETPRIO   // A/B: static priority for the second-dispatched half of the workgroup (the arbitration loser)
   if (wave >= WPB / 2) __builtin_amdgcn_s_setprio(RS_WG_SETPRIO);
 #endif
+  // Fair share of the SIMD. The two waves of a SIMD (wave w and w + WPB/2) run the same program between the same barriers,
+  // and at equal priority the OLDER one wins vector issue: stamps (tools/stamp_profile.py, profiles/r03/a_stamps_*) show waves
+  // 0-3 parked at the barriers 36 % of their time while waves 4-7 run on alone at a lone wave's lower issue rate. Each wave
+  // therefore raises its priority on alternate segments of a transform pair, the two halves in antiphase.
+#ifdef RS_WG_FAIRPRIO
+#ifndef RS_WG_FAIRMODE
+#define RS_WG_FAIRMODE 2
+#endif
+  const bool younger = WPB == 8 && wave >= WPB / 2;
+  auto seg = [&](int k) {
+    if (WPB == 8) {
+      if (RS_WG_FAIRMODE == 1) {        // both halves toggle, in antiphase
+        if (((k & 1) != 0) == younger) __builtin_amdgcn_s_setprio(RS_WG_FAIRPRIO); else __builtin_amdgcn_s_setprio(0);
+      } else {                          // only the younger half toggles: it wins its odd segments by priority, the older half the even ones by age
+        if (younger) { if (k & 1) __builtin_amdgcn_s_setprio(RS_WG_FAIRPRIO); else __builtin_amdgcn_s_setprio(0); }
+      }
+    }
+  };
+#else
+  auto seg = [](int) {};
+#endif
 
   // my 1/WPB share of key row R -> ring slot R & 1
   const unsigned lane_off = (unsigned)lane * 16u;
@@ -641,7 +671,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
             if (qB == 0) { if (compB) load_d(std::true_type{}); else load_d(std::false_type{}); }
           }
           Xf::digits(xb, d, qB);
-          Xf::fwd_pair_wg(lane, xa, xb, tw, buf);
+          Xf::fwd_pair_wg(lane, xa, xb, tw, buf, seg);
         }
         RS_STAMP(1);
 #ifndef RS_T_NOBAR   // timing experiments only (results are wrong without the barriers)
@@ -692,7 +722,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
 
       if (work) {
 #ifdef RS_NO_ACC_AHEAD
-        Xf::inverse_pair_wg(lane, s0, s1, tw, buf);
+        Xf::inverse_pair_wg(lane, s0, s1, tw, buf, seg);
 #pragma unroll
         for (int r = 0; r < kRegs; ++r) {
           const int j = lane + 64 * r;
@@ -707,7 +737,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
 #pragma unroll
         for (int r = 0; r < kRegs; ++r) { a0[r] = (uint32_t)acc0[lane + 64 * r]; a1[r] = (uint32_t)acc1[lane + 64 * r]; }
         wave_lds_sync();
-        Xf::inverse_pair_wg(lane, s0, s1, tw, buf);
+        Xf::inverse_pair_wg(lane, s0, s1, tw, buf, seg);
         RS_STAMP(5);
 #pragma unroll
         for (int r = 0; r < kRegs; ++r) {

@@ -352,13 +352,53 @@ __device__ __forceinline__ void frow_load(int lane, double (&x)[kRegs], const do
 #define RS_ROW_FORM 0
 #endif
 
+// ---- 8-byte stores, 16-byte loads (the default form) ----
+// What an LDS instruction costs is vector-issue time of its SIMD (tools/lds_issue_bench.hip, profiles/r03/a_lds_issue_costs.jsonl:
+// beside an FP64 stream at two waves per SIMD a ds_read_b64 costs 1.1-1.5 v_fma_f64, a ds_read_b128 1.5, a ds_write_b64 1.8-2.0,
+// a ds_write_b128 3.4), and the blind rotation's time IS the sum of those costs. Moving a plane back
+// with FOUR 16-byte loads instead of eight 8-byte ones takes 4.4 FMA-equivalents off each of the 32 plane exchanges of a CMUX.
+// The reader's registers (2m, 2m+1) must then be adjacent doubles. With the value index written j = 64 a + 8 b + c
+// (A': lane 8b+c, register a; B': lane 8a+c, register b; C': lane 8a+b, register c) the positions (in doubles) are
+//   A' -> B':  16 a + 2 c + 128 (b >> 1) + (b & 1)          B' -> A':  16 b + 2 c + 128 (a >> 1) + (a & 1)
+//   B' -> C':  8 a + c + 72 b + 2 (b & 3)                   C' -> B':  8 a + b + 72 c + 2 (c & 3)
+// Every store instruction (one register of 64 lanes) covers 16 consecutive doubles per 16-lane group, every 16-byte load
+// instruction 16 different 16-byte slots per lane group of ds_read_b128: conflict-free both ways (checked exhaustively on the
+// host against the lane groups of MI355X_MICROARCH.md, tests/test_emulator.py), 574 doubles at most (kPlaneDoubles = 576).
+template <int LAY>
+RS_HD void flay_abc(int lane, int k, int& a, int& b, int& c) {
+  if (LAY == kLayA) { a = k; b = lane >> 3; c = lane & 7; }
+  else if (LAY == kLayB) { a = lane >> 3; b = k; c = lane & 7; }
+  else { a = lane >> 3; b = lane & 7; c = k; }
+}
+template <int FROM, int TO>
+RS_HD int xpos(int a, int b, int c) {
+  if (FROM == kLayA) return 16 * a + 2 * c + 128 * (b >> 1) + (b & 1);                      // A' -> B'
+  if (FROM == kLayB && TO == kLayA) return 16 * b + 2 * c + 128 * (a >> 1) + (a & 1);       // B' -> A'
+  if (FROM == kLayB) return 8 * a + c + 72 * b + 2 * (b & 3);                               // B' -> C'
+  return 8 * a + b + 72 * c + 2 * (c & 3);                                                  // C' -> B'
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef double rs_d2 __attribute__((ext_vector_type(2)));
+#endif
+#if defined(RS_PLANE_B64_LOADS) || RS_ROW_FORM   // A/B: the previous form, eight ds_read_b64 per plane (or the row form of RS_ADDTID)
+#define RS_WIDE_LOADS 0
+#else
+#define RS_WIDE_LOADS 1
+#endif
+
 template <int LAY, int T, int H>
 RS_HD void fpl_store(int lane, const double (&x)[kRegs], double* buf) {
 #if RS_ROW_FORM
   if constexpr (T == 2) { frow_store<H>(x, buf); return; }
 #endif
+#if RS_WIDE_LOADS
+  constexpr int TO = (T == 1) ? (LAY == kLayA ? kLayB : kLayA) : (LAY == kLayB ? kLayC : kLayB);
+#pragma unroll
+  for (int k = 0; k < kCRegs; ++k) { int a, b, c; flay_abc<LAY>(lane, k, a, b, c); RS_PLANE_STORE(buf, (xpos<LAY, TO>(a, b, c)), x[k + 8 * H]); }
+#else
 #pragma unroll
   for (int k = 0; k < kCRegs; ++k) { const int j = flay_index<LAY>(lane, k); RS_PLANE_STORE(buf, T == 1 ? ppos_t1(j) : ppos_t2(j), x[k + 8 * H]); }
+#endif
 }
 // Device: volatile LDS loads stay eight separate ds_read_b64 (2 LDS cycles each); merged into
 // ds_read2_b64 by the compiler they cost 8 cycles per pair (MI355X LDS table), i.e. twice as much.
@@ -372,8 +412,24 @@ RS_HD void fpl_load(int lane, double (&x)[kRegs], const double* buf) {
 #if RS_ROW_FORM
   if constexpr (T == 2) { frow_load<H>(lane, x, buf); return; }
 #endif
+#if RS_WIDE_LOADS
+  constexpr int FROM = (T == 1) ? (LAY == kLayB ? kLayA : kLayB) : (LAY == kLayC ? kLayB : kLayC);
+#pragma unroll
+  for (int m = 0; m < kCRegs / 2; ++m) {
+    int a, b, c;
+    flay_abc<LAY>(lane, 2 * m, a, b, c);
+    const int pos = xpos<FROM, LAY>(a, b, c);   // even, and register 2m + 1 sits at pos + 1
+#if defined(__HIP_DEVICE_COMPILE__)
+    const rs_d2 v = *((const volatile __attribute__((address_space(3))) rs_d2*)(buf + pos));   // one ds_read_b128
+    x[2 * m + 8 * H] = v.x; x[2 * m + 1 + 8 * H] = v.y;
+#else
+    x[2 * m + 8 * H] = buf[pos]; x[2 * m + 1 + 8 * H] = buf[pos + 1];
+#endif
+  }
+#else
 #pragma unroll
   for (int k = 0; k < kCRegs; ++k) { const int j = flay_index<LAY>(lane, k); x[k + 8 * H] = RS_PLANE_LOAD(buf, T == 1 ? ppos_t1(j) : ppos_t2(j)); }
+#endif
 }
 // One exchange FROM layout L0 TO layout L1 through padding T; `sync` orders the wavefront's LDS
 // accesses (on the device a compiler-only fence: DS operations of one wavefront execute in order).
@@ -488,30 +544,45 @@ RS_HD void ffwd_planar(int lane, double (&x)[kRegs], const TW& t, double* buf, S
   fft_fwd3_ahead<2>(x, t);
 #endif
 }
-template <bool PLANAR, class TW, class Sync>
-RS_HD void ffwd_pair(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TW& t, double* buf, Sync sync) {
+// `seg(k)` is called at the start of the k-th of the six segments of a pair (the workgroup kernel toggles the wave's issue
+// priority there, see blind_rotate_wg_kernel; everywhere else it is a no-op).
+struct FftNoSeg { RS_HD void operator()(int) const {} };
+template <bool PLANAR, class TW, class Sync, class Seg = FftNoSeg>
+RS_HD void ffwd_pair(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TW& t, double* buf, Sync sync, Seg seg = Seg()) {
+  seg(0);
   fft_fwd3<0>(xa, t);
+  seg(1);
   fft_exchange_over<PLANAR, kLayA, kLayB, 1, 0, false>(lane, xa, xb, t, buf, sync);
+  seg(2);
   fft_exchange_over<PLANAR, kLayA, kLayB, 1, 1, false>(lane, xb, xa, t, buf, sync);
+  seg(3);
   fft_exchange_over<PLANAR, kLayB, kLayC, 2, 1, false>(lane, xa, xb, t, buf, sync);
+  seg(4);
   fft_exchange_over<PLANAR, kLayB, kLayC, 2, 2, false>(lane, xb, xa, t, buf, sync);
+  seg(5);
 #ifdef RS_NO_TW_AHEAD
   fft_fwd3<2>(xb, t);
 #else
   fft_fwd3_ahead<2>(xb, t);
 #endif
 }
-template <bool PLANAR, class TW, class Sync>
-RS_HD void finv_pair(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TW& t, double* buf, Sync sync) {
+template <bool PLANAR, class TW, class Sync, class Seg = FftNoSeg>
+RS_HD void finv_pair(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TW& t, double* buf, Sync sync, Seg seg = Seg()) {
+  seg(0);
 #ifdef RS_NO_TW_AHEAD
   fft_inv3<2>(xa, t);
 #else
   fft_inv3_ahead<2>(xa, t);
 #endif
+  seg(1);
   fft_exchange_over<PLANAR, kLayC, kLayB, 2, 2, true>(lane, xa, xb, t, buf, sync);
+  seg(2);
   fft_exchange_over<PLANAR, kLayC, kLayB, 2, 1, true>(lane, xb, xa, t, buf, sync);
+  seg(3);
   fft_exchange_over<PLANAR, kLayB, kLayA, 1, 1, true>(lane, xa, xb, t, buf, sync);
+  seg(4);
   fft_exchange_over<PLANAR, kLayB, kLayA, 1, 0, true>(lane, xb, xa, t, buf, sync);
+  seg(5);
   fft_inv3<0>(xb, t);
 }
 

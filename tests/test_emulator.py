@@ -178,6 +178,13 @@ def test_general_path_layouts(logn):
     assert emu_lib.lib().rs_emu_gen_layout_violations(logn) == 0
 
 
+def test_planar_exchange_positions_are_conflict_free():
+    """rs_fft.h, 8-byte stores / 16-byte loads: the device's own position functions, all four exchange directions -- every value
+    comes back in the reader's layout, the reader's register pairs are adjacent and aligned, and every store / load
+    wave-instruction is bank-conflict free in the lane groups MI355X_MICROARCH.md gives for ds_write_b64 / ds_read_b128."""
+    assert emu_lib.lib().rs_emu_plane_layout_violations() == 0
+
+
 @pytest.mark.parametrize("logn,half", [(10, 512), (11, 64), (12, 512), (13, 512)])
 def test_general_path_split_product_is_exact(logn, half):
     N = 1 << logn
