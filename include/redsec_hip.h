@@ -41,7 +41,9 @@ typedef enum rs_status {
   RS_ERR_INVALID = -1,     /* bad argument / unsupported parameter set */
   RS_ERR_NO_DEVICE = -2,   /* no HIP device or device is not gfx950-compatible */
   RS_ERR_HIP = -3,         /* a HIP runtime call failed */
-  RS_ERR_STATE = -4        /* keys not loaded, etc. */
+  RS_ERR_STATE = -4,       /* keys not loaded, etc. */
+  RS_ERR_INEXACT = -5      /* RS_MODE_FFT_SPLIT: the enforced rounding certificate failed (see rs_split_bound); sticky until
+                              rs_certify(..., reset = 1) */
 } rs_status;
 
 /* Mirrors TFheGateBootstrappingParameterSet (ks_t, ks_basebit, in_out_params->n, tgsw_params->l,
@@ -96,18 +98,23 @@ int rs_load_keys(rs_ctx* ctx, const int32_t* bk, const int32_t* ksk);
  *                      2.3x the FP64 operations.
  *   RS_MODE_FFT_SPLIT  the same FP64 FFT with the key split into two signed 16-bit halves (twice the pointwise
  *                      products and inverse transforms). Every half product stays below 2^40, where the FFT's
- *                      WORST-CASE error is orders of magnitude below 1/2 (a-priori bound, rs_split_bound): exact
- *                      by construction, no certificate involved. General kernels: any N in {1024 ... 8192}, any
- *                      gadget; the only mode of the sets outside the specialised N = 1024 kernels.
+ *                      WORST-CASE error is below 1/2 for every parameter set the reference defines (a-priori bound
+ *                      derived in csrc/rs_general.h, rs_split_bound: 3e-4 ... 0.011 for N = 1024, 0.10 for N = 4096,
+ *                      0.30 for N = 8192): rounding is exact for EVERY input. The general kernels (N >= 2048, or any
+ *                      gadget outside the shipped ones) also ENFORCE a rounding certificate: a call that rounds a value
+ *                      1/4 or more away from an integer makes the next call on its stream, rs_sync, rs_certify and the
+ *                      host-pointer calls fail with RS_ERR_INEXACT (never observed: measured distances are 4e-6).
+ *                      General kernels: any N in {1024 ... 8192}, any gadget; the only mode of the sets outside the
+ *                      specialised N = 1024 kernels.
  * Results are identical word for word in all modes (= the CPU oracle).
  * Default RS_MODE_FFT where available (environment REDSEC_MODE=exact | split selects another at context creation;
  * the environment is read ONCE, in rs_create). rs_set_mode must not race with launches of the same context. */
 enum { RS_MODE_EXACT_NTT = 0, RS_MODE_FFT = 1, RS_MODE_FFT_SPLIT = 2 };
 int rs_set_mode(rs_ctx* ctx, int mode);
 int rs_get_mode(rs_ctx* ctx, int* mode);
-/* The a-priori bound on |computed - true coefficient| of a split-key product for this context's parameters
- * (Percival 2003, Thm 5.1 with the operands' 2-norms; derivation in csrc/rs_general.h). The mode is offered when
- * it is below 1/4. */
+/* The a-priori bound on |computed - true coefficient| of a split-key product for this context's parameters (derived in
+ * csrc/rs_general.h from the rounding model of the FP64 butterflies actually used; nothing quoted). The mode is offered
+ * when it is below 1/2, i.e. when rounding to the nearest integer is exact for every input. */
 int rs_split_bound(rs_ctx* ctx, double* bound);
 /* A call whose certificate reaches this limit is recomputed exactly on the device (default 0.25: an error
  * of +-1 needs a distance > 0.5). limit = 0 forces the recomputation of every call (tests). */

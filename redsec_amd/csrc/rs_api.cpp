@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -64,6 +65,9 @@ struct Lane {
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   bool ev_valid = false;
   rs::LaunchInfo last;
+  // enforced split-mode certificate: the lane's running maximum is copied here (pinned host memory) behind every general-kernel
+  // call, and looked at by the next call, rs_certify and rs_sync
+  unsigned long long* h_split_max = nullptr;
 };
 
 struct rs_ctx {
@@ -83,7 +87,9 @@ struct rs_ctx {
   bool general = false;
   int wgs_cfg = -1;                // gadget id of the lock-step split-key kernel, or -1 (general kernels only)
   int logn = 10;
-  double split_bound = 0.0;        // a-priori error bound of the split-key product (< 1/4 or the mode is not offered)
+  double split_bound = 0.0;        // a-priori error bound of the split-key product (rs_general.h; the mode is offered below 1/2)
+  double split_cert_limit = 0.25;    // enforced on the general kernels' rounding distances (REDSEC_SPLIT_CERT_LIMIT lowers it: tests)
+  std::atomic<bool> inexact{false};  // a split-mode call rounded a value 1/4 or more away from an integer: sticky, RS_ERR_INEXACT
   double* d_tw_gen = nullptr;      // gen_make_twiddles(logn)
   double* d_bk_gen = nullptr;      // split key in the FFT domain
   int32_t* d_ksk = nullptr;
@@ -127,6 +133,7 @@ int use_device(rs_ctx* c) {
 }
 
 void free_lane(Lane* ln) {
+  if (ln->h_split_max) (void)hipHostFree(ln->h_split_max);
   (void)hipFree(ln->d_u0); (void)hipFree(ln->d_u1); (void)hipFree(ln->d_counter); (void)hipFree(ln->d_cert);
   (void)hipFree(ln->d_conv_scratch);
   for (auto& e : ln->ev) if (e) (void)hipEventDestroy(e);
@@ -142,10 +149,12 @@ int lane_of(rs_ctx* c, hipStream_t st, Lane** out) {
   ln->sample_words = (size_t)c->p.N + 1;
   const size_t cert_bytes = sizeof(unsigned long long) * (kCertSlots + 2);
   if (hipMalloc(&ln->d_cert, cert_bytes) != hipSuccess || hipMemset(ln->d_cert, 0, cert_bytes) != hipSuccess ||
+      hipHostMalloc((void**)&ln->h_split_max, sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
       (!c->opts.no_persist && hipMalloc(&ln->d_counter, 256) != hipSuccess)) {
     free_lane(ln.get());
     return fail(RS_ERR_HIP, "per-stream state allocation failed");
   }
+  *ln->h_split_max = 0;
   for (auto& e : ln->ev) (void)hipEventCreate(&e);
   *out = ln.get();
   c->lanes[st] = std::move(ln);
@@ -190,6 +199,26 @@ int ready(rs_ctx* c) {
   return RS_OK;
 }
 
+// Enforced certificate of the split-key mode (general kernels). `bits` is a rounding distance as the bit pattern of a
+// non-negative double (ordered like the value). A distance of 1/4 or more cannot be told from an error of the opposite sign
+// around the next integer once the a-priori bound exceeds 1/4, so it poisons the context instead of passing silently.
+bool split_distance_ok(const rs_ctx* c, unsigned long long bits) {
+  double d;
+  memcpy(&d, &bits, sizeof d);
+  return d < c->split_cert_limit;
+}
+int inexact_error(rs_ctx* c) {
+  return fail(RS_ERR_INEXACT, "split-key mode: a rounding distance of 1/4 or more was observed (a-priori bound %.3g): results of this context are not certified; "
+                              "rs_certify(reset = 1) clears the flag", c->split_bound);
+}
+
+// after a synchronisation that covers `ln`'s stream: what its last split-mode call reported is in the pinned word
+int split_check_lane(rs_ctx* c, Lane* ln) {
+  if (c->mode != RS_MODE_FFT_SPLIT) return RS_OK;
+  if (!split_distance_ok(c, *(volatile unsigned long long*)ln->h_split_max)) c->inexact.store(true);
+  return c->inexact.load() ? inexact_error(c) : RS_OK;
+}
+
 struct Combo { const int32_t* in0; const int32_t* in1; int32_t c0, c1, bconst; int32_t* u; };
 
 struct Lut { const int32_t* table = nullptr; size_t count = 0, first = 0; };
@@ -228,7 +257,11 @@ int run_bootstrap(rs_ctx* c, hipStream_t st, int32_t* out, const Combo* combos, 
   for (int k = 0; k < count; ++k) { cs[k] = combos[k]; cs[k].u = k == 0 ? ln->d_u0 : ln->d_u1; }
   if (c->timing) RS_HIP(hipEventRecord(ln->ev[0], st));
   if (mode == RS_MODE_FFT_SPLIT) {
-    // exact by the a-priori bound of rs_general.h: nothing to certify, nothing to recompute
+    // exact by the a-priori bound of rs_general.h (below 1/2 for every set offered): nothing to recompute. The general kernels
+    // also publish the largest rounding distance; it is ENFORCED (see split_distance_ok): what the previous call on this
+    // stream reported is looked at here, without waiting for anything.
+    if (!split_distance_ok(c, *(volatile unsigned long long*)ln->h_split_max)) c->inexact.store(true);
+    if (c->inexact.load()) return inexact_error(c);
     bool split_wg = false;
     for (int k = 0; k < count; ++k) {
       if (c->wgs_cfg >= 0 && !c->opts.no_wg) {
@@ -244,9 +277,10 @@ int run_bootstrap(rs_ctx* c, hipStream_t st, int32_t* out, const Combo* combos, 
       a.bk_x = c->d_bk_gen; a.tw = c->d_tw_gen;
       a.n = c->p.n; a.W = c->p.n + 1; a.l = c->p.bk_l; a.bgbit = c->p.bk_Bgbit; a.B = (long)B; a.u_out = cs[k].u;
       a.lut = lut.table; a.lut_count = (int32_t)lut.count; a.lut_first = (int32_t)lut.first;
-      a.dev_flag = ln->d_cert + kCertSlots;   // running maximum only: a diagnostic against the bound
+      a.dev_flag = ln->d_cert + kCertSlots;   // the stream's running maximum
       RS_HIP(rs::launch_gen_blind_rotate(c->logn, a, c->num_cus, st));
     }
+    if (!split_wg) RS_HIP(hipMemcpyAsync(ln->h_split_max, ln->d_cert + kCertSlots, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     if (!split_wg) {
       ln->last.form = rs::kFormGeneral; ln->last.waves_per_block = (c->p.N / 16) / 64;
       ln->last.resident = std::min<long>((long)B, rs::gen_resident_ciphertexts(c->logn, c->num_cus));
@@ -344,8 +378,8 @@ int rs_create(rs_ctx** out, const rs_params* p, int device) {
   // set runs on the general split-key path alone
   const bool special = p->N == rs::kN && rs::prime_for(p->bk_l, p->bk_Bgbit, &ps);
   const double split_bound = rs::gen_error_bound(logn, p->bk_l, p->bk_Bgbit);
-  if (!special && !(split_bound < 0.25))
-    return fail(RS_ERR_INVALID, "gadget l=%d Bgbit=%d on N=%d: split-key product bound %.3g is not below 1/4", p->bk_l, p->bk_Bgbit, p->N, split_bound);
+  if (!special && !(split_bound < rs::kSplitBoundOffer))
+    return fail(RS_ERR_INVALID, "gadget l=%d Bgbit=%d on N=%d: split-key product bound %.3g is not below 1/2", p->bk_l, p->bk_Bgbit, p->N, split_bound);
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(RS_ERR_NO_DEVICE, "no HIP device visible");
   if (device < 0 || device >= count) return fail(RS_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, count);
@@ -394,7 +428,7 @@ int rs_create(rs_ctx** out, const rs_params* p, int device) {
       return fail(RS_ERR_HIP, "twiddle table upload failed");
     }
   }
-  if (split_bound < 0.25) {
+  if (split_bound < rs::kSplitBoundOffer) {
     std::vector<double> gtw((size_t)p->N);   // M complex entries
     rs::gen_make_twiddles(logn, gtw.data());
     if (hipMalloc(&c->d_tw_gen, sizeof(double) * gtw.size()) != hipSuccess ||
@@ -407,6 +441,7 @@ int rs_create(rs_ctx** out, const rs_params* p, int device) {
   if (const char* m = getenv("REDSEC_MODE")) {
     if (special) c->mode = (strcmp(m, "exact") == 0 || strcmp(m, "ntt") == 0) ? RS_MODE_EXACT_NTT : (strcmp(m, "split") == 0 && c->d_tw_gen ? RS_MODE_FFT_SPLIT : RS_MODE_FFT);
   }
+  if (const char* v = getenv("REDSEC_SPLIT_CERT_LIMIT")) { const double x = atof(v); if (x > 0.0 && x < 0.25) c->split_cert_limit = x; }   // test hook: can only tighten
   c->opts.no_coop = env_on("RS_NO_COOP"); c->opts.no_wg = env_on("RS_NO_WG"); c->opts.no_duo = env_on("RS_NO_DUO");
   c->opts.no_persist = env_on("RS_NO_PERSIST"); c->opts.no_conv_tiled = env_on("RS_NO_CONV_TILED");
   c->opts.no_wg4 = env_on("RS_NO_WG4"); c->opts.no_tail = env_on("RS_NO_TAIL");
@@ -580,6 +615,13 @@ static int host_roundtrip(rs_ctx* c, int32_t* out, const int32_t* const* ins, in
   rc = run(c, c->d_io[3], c->d_io, B, extra);
   if (rc) return rc;
   RS_HIP(hipStreamSynchronize(nullptr));
+  {
+    Lane* ln = nullptr;
+    rc = lane_of(c, nullptr, &ln);
+    if (rc) return rc;
+    rc = split_check_lane(c, ln);   // a host call never hands back an uncertified split-mode result
+    if (rc) return rc;
+  }
   RS_HIP(hipMemcpy(out, c->d_io[3], bytes, hipMemcpyDeviceToHost));
   return RS_OK;
 }
@@ -674,8 +716,16 @@ static int read_lane(Lane* ln, double* dist, int64_t* fallbacks, bool reset) {
   RS_HIP(hipMemcpy(v, ln->d_cert + kCertSlots, sizeof v, hipMemcpyDeviceToHost));
   memcpy(dist, &v[0], sizeof *dist);
   *fallbacks = (int64_t)v[1];
-  if (reset) RS_HIP(hipMemset(ln->d_cert + kCertSlots, 0, sizeof(unsigned long long)));
+  if (reset) { RS_HIP(hipMemset(ln->d_cert + kCertSlots, 0, sizeof(unsigned long long))); *ln->h_split_max = 0; }
   return RS_OK;
+}
+// split mode: the synchronised running maximum against the enforced limit (see split_distance_ok)
+static int split_verdict(rs_ctx* c, double dist, bool reset) {
+  if (c->mode != RS_MODE_FFT_SPLIT) return RS_OK;
+  if (!(dist < c->split_cert_limit)) c->inexact.store(true);
+  const bool bad = c->inexact.load();
+  if (reset) c->inexact.store(false);
+  return bad ? inexact_error(c) : RS_OK;
 }
 
 int rs_certify(rs_ctx* c, void* stream, double* max_distance, int64_t* recomputed_calls, int reset) {
@@ -691,7 +741,7 @@ int rs_certify(rs_ctx* c, void* stream, double* max_distance, int64_t* recompute
   if (rc) return rc;
   if (max_distance) *max_distance = d;
   if (recomputed_calls) *recomputed_calls = n;
-  return RS_OK;
+  return split_verdict(c, d, reset != 0);
 }
 
 int rs_rounding_certificate(rs_ctx* c, double* max_distance, int reset) {
@@ -709,7 +759,7 @@ int rs_rounding_certificate(rs_ctx* c, double* max_distance, int reset) {
     if (d > best) best = d;
   }
   *max_distance = best;
-  return RS_OK;
+  return split_verdict(c, best, reset != 0);
 }
 
 int rs_fft_fallbacks(rs_ctx* c, int64_t* count) {
@@ -835,6 +885,11 @@ int rs_sync(rs_ctx* c) {
   int rc = use_device(c);
   if (rc) return rc;
   RS_HIP(hipDeviceSynchronize());
+  std::lock_guard<std::mutex> g(c->lanes_mu);
+  for (auto& kv : c->lanes) {
+    rc = split_check_lane(c, kv.second.get());
+    if (rc) return rc;
+  }
   return RS_OK;
 }
 

@@ -360,6 +360,64 @@ struct GenEmu {
     if (max_dev) *max_dev = dev;
     return 0;
   }
+  // Measured 2-norm error of one forward and one inverse transform against an 80-bit reference (direct evaluation at the
+  // tree's roots), relative to sqrt(M) ||input||_2: ratios[0] forward, ratios[1] inverse. The a-priori analysis of
+  // rs_general.h bounds them by g_f - 1 and g_i - 1; a sanity check of its per-stage constants, not a proof.
+  void transform_error_ratios(uint64_t seed, int amplitude, double* ratios) {
+    const long double pi = 3.141592653589793238462643383279502884L;
+    std::vector<long double> cr((size_t)2 * G::N), ci((size_t)2 * G::N);
+    for (int e = 0; e < 2 * G::N; ++e) { cr[e] = cosl(pi * e / G::N); ci[e] = sinl(pi * e / G::N); }
+    auto bitrev = [](int p) { int r = 0; for (int b = 0; b < G::LOGM; ++b) r |= ((p >> b) & 1) << (G::LOGM - 1 - b); return r; };
+    uint64_t st = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    // forward: folded value j = t + T r  (registers r, r + 8 = re, im), signs random, magnitudes up to `amplitude`
+    std::vector<long double> zr(G::M), zi(G::M);
+    long double nin = 0;
+    for (int t = 0; t < G::T; ++t)
+      for (int r = 0; r < 8; ++r) {
+        const int j = t + G::T * r;
+        const int a = (int)(rnd() % (2u * (unsigned)amplitude + 1u)) - amplitude, b = (rnd() & 1) ? amplitude : -amplitude;
+        regs(t)[r] = (double)a; regs(t)[r + 8] = (double)b;
+        zr[j] = a; zi[j] = b;
+        nin += (long double)a * a + (long double)b * b;
+      }
+    pass_fwd<0>();
+    std::vector<long double> Xr(G::M), Xi(G::M);
+    long double err = 0;
+    for (int p = 0; p < G::M; ++p) {
+      const long e1 = 1 + 4L * bitrev(p);
+      long double sr = 0, si = 0;
+      for (int j = 0; j < G::M; ++j) {
+        const int e = (int)((e1 * j) % (2L * G::N));
+        sr += zr[j] * cr[e] - zi[j] * ci[e];
+        si += zr[j] * ci[e] + zi[j] * cr[e];
+      }
+      Xr[p] = sr; Xi[p] = si;
+      const long double dr = (long double)regs(p >> 3)[p & 7] - sr, di = (long double)regs(p >> 3)[(p & 7) + 8] - si;
+      err += dr * dr + di * di;
+    }
+    ratios[0] = (double)(sqrtl(err) / (sqrtl((long double)G::M) * sqrtl(nin)));
+    // inverse of the (rounded) forward values: z'_j = sum_p X_p conj(root_p)^j = M z_j
+    long double nX = 0;
+    for (int p = 0; p < G::M; ++p) {
+      Xr[p] = (long double)regs(p >> 3)[p & 7]; Xi[p] = (long double)regs(p >> 3)[(p & 7) + 8];
+      nX += Xr[p] * Xr[p] + Xi[p] * Xi[p];
+    }
+    pass_inv<G::P - 1>();
+    err = 0;
+    for (int j = 0; j < G::M; ++j) {
+      long double sr = 0, si = 0;
+      for (int p = 0; p < G::M; ++p) {
+        const int e = (int)(((1 + 4L * bitrev(p)) * j) % (2L * G::N));
+        sr += Xr[p] * cr[e] + Xi[p] * ci[e];
+        si += Xi[p] * cr[e] - Xr[p] * ci[e];
+      }
+      const int t = j % G::T, r = j / G::T;
+      const long double dr = (long double)regs(t)[r] - sr, di = (long double)regs(t)[r + 8] - si;
+      err += dr * dr + di * di;
+    }
+    ratios[1] = (double)(sqrtl(err) / (sqrtl((long double)G::M) * sqrtl(nX)));
+  }
   // (a) register r sits at register 0's position plus the compile-time offset the device code uses; (b) the 8-byte accesses
   // of every 32-lane group hit 32 different bank pairs on both sides of every exchange. Returns the number of violations.
   template <int XP>
@@ -614,6 +672,19 @@ long rs_emu_plane_layout_violations() {
          plane_violations<rs::kLayB, rs::kLayC, 2>() + plane_violations<rs::kLayC, rs::kLayB, 2>();
 }
 double rs_emu_gen_error_bound(int logn, int l, int bgbit) { return rs::gen_error_bound(logn, l, bgbit); }
+// measured transform errors (see GenEmu::transform_error_ratios) and the analysis' per-transform bounds g_f - 1, g_i - 1
+int rs_emu_gen_transform_errors(int logn, uint64_t seed, int amplitude, double* measured2, double* bounds2) {
+  const double u = std::ldexp(1.0, -53), r2 = std::sqrt(2.0);
+  bounds2[0] = std::pow(1.0 + 8.3 * u / r2, logn - 1) - 1.0;
+  bounds2[1] = std::pow(1.0 + 5.8 * u / r2, logn - 1) - 1.0;
+  switch (logn) {
+    case 10: { GenEmu<10> e; e.transform_error_ratios(seed, amplitude, measured2); return 0; }
+    case 11: { GenEmu<11> e; e.transform_error_ratios(seed, amplitude, measured2); return 0; }
+    case 12: { GenEmu<12> e; e.transform_error_ratios(seed, amplitude, measured2); return 0; }
+    case 13: { GenEmu<13> e; e.transform_error_ratios(seed, amplitude, measured2); return 0; }
+  }
+  return -1;
+}
 // run-time gadget digits of the general path against TFHE's formula
 long rs_emu_gen_digit_mismatches(int l, int bgbit, uint32_t start, uint32_t step, long count) {
   long bad = 0;

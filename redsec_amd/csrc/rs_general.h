@@ -7,7 +7,7 @@
 // twiddles, evaluation-tree form), but with the key split into two signed 16-bit halves K = Khi 2^16 + Klo:
 //     sum_rows d_row * K_row  =  sum d * Klo  +  2^16 sum d * Khi          (mod 2^32)
 // Each half product has coefficients below rows * N * (Bg/2) * 2^15 < 2^40, and the FFT's worst-case error for it is
-// far below 1/2 (gen_error_bound below: Percival's bound with the 2-norms of the operands), so rounding to the
+// below 1/2 (gen_error_bound below, derived in this file for these butterflies), so rounding to the
 // nearest integer returns the exact integer product for EVERY input, not just with overwhelming probability.
 // Cost against the unsplit FFT mode: twice the pointwise products and inverse transforms, forward transforms shared.
 //
@@ -229,31 +229,63 @@ inline void gen_make_twiddles(int logn, double* tw /* 2 * M doubles */) {
     }
 }
 
-// A-priori bound on |computed - true| for one coefficient of  sum_{rows} d_row * Khalf_row  through the FP64 FFT
-// (forward transforms of both operands, pointwise products, inverse), for ANY inputs with |d| <= Bg/2 and
-// |Khalf| <= 2^15. Percival, "Rapid multiplication modulo the sum and difference of highly composite numbers",
-// Math. Comp. 72 (2003), the error theorem for FFT-based convolution (Thm 5.1 there; restated in Brent & Zimmermann,
-// Modern Computer Arithmetic, ch. 3) [recalled: no copy in this image]:
-//     ||z' - z||_inf <= ||x||_2 ||y||_2 ((1+u)^(3n) (1+u sqrt5)^(3n+1) (1+beta)^(3n) - 1)
-// for a length-2^n transform with unit roundoff u = 2^-53 and twiddles within beta of their true values. The merged
-// twist makes every level's twiddle general, which is the case the theorem covers; n is taken one higher than
-// log2(M) to cover the pre-scaled key and the accumulation over rows, and the result is doubled as slack. Products
-// with FMAs round less often than the model assumes. RS_MODE_FFT_SPLIT is offered only when this is below 1/4.
-// A self-contained, cruder bound -- Higham, Accuracy and Stability of Numerical Algorithms, Thm 24.2 (relative 2-norm
-// error of a radix-2 FFT <= log2(M) eta, eta ~ 7u) carried through the product with |X_k| <= sqrt(M) ||x||_2:
-// error <= rows sqrt(M) ||d||_2 ||Khalf||_2 (21 log2(M) + 3) u -- gives 0.006 (default-128), 0.0013 (REDsec shipped set),
-// 0.05 (redsec_params_small), 0.49 (medium) and 1.5 (large): it certifies the three N = 1024 sets by itself; for the
-// two large rings the claim rests on Percival's sharper analysis (and the largest rounding distance measured on
-// operands of the largest norm is 4.3e-6, tests/test_gpu_general.py).
+// -------------------------------------------------------------------------------------------------------------------
+// A-PRIORI bound on |computed - true| for one coefficient of  c = sum_{r < R} d_r * k_r  (negacyclic, R = 2 l rows; |d| <= D
+// = Bg/2; k = one signed 16-bit key half, |k| <= K = 2^15) computed as this file computes it: FP64 forward transforms of
+// both operands, 4-FMA complex multiply-accumulates over the rows, one inverse transform. Derived HERE, for the butterflies
+// of rs_fft.h as written (round 2 quoted Percival's convolution theorem from memory; nothing below is quoted).
+//
+// Model: u = 2^-53; every add, mul and fma returns its exact result times (1 + delta), |delta| <= u (magnitudes stay in
+// [2^-200, 2^60]: no underflow that matters, no overflow). Folding z_j = a_j + i a_{j+M} preserves the 2-norm. The forward
+// transform is F = A_k ... A_1 (k = log2 M stages); stage s applies (x, y) -> (x + w y, x - w y), |w| = 1, to disjoint pairs,
+// so A_s = sqrt2 * (unitary) and ||F v||_2 = sqrt(M) ||v||_2 exactly. Every entry of F and of G = F^H has modulus 1.
+//
+// (1) One forward butterfly, fft_bfly_fwd[_i]:  s = fma(-wi, yi, fma(wr, yr, xr)) etc., y' = fma(2, x, -s). With the rounded
+//     twiddle w^ (each component within u/2 of the true one: the table entries are long-double values rounded once):
+//       |ds_r| <= u (1+u) (2|x_r| + 2|w_r||y_r| + |w_i||y_i|),  likewise ds_i  =>  ||ds|| <= u (1+u) (2|x| + sqrt5 (1+u) |y|)
+//       ||dy'|| <= (1+u) ||ds|| + u (|x| + (1+u)|y|)                    (y' is computed from the ROUNDED s)
+//       twiddle rounding moves both outputs by |w^ - w| |y| <= 0.72 u |y|   (u / sqrt2, plus slack for the table's long double)
+//     together ||(ds, dy')|| <= u (5|x| + 6.5|y|)(1 + 3u) <= 8.3 u ||(x, y)||_2. Pairs are disjoint, so for a whole stage
+//       || fl(A_s v) - A_s v ||_2 <= eps_f ||v||_2,   eps_f = 8.3 u.
+// (2) One inverse butterfly, fft_bfly_inv[_i]:  d = x - y, x' = x + y, y' = fma(+-wi, d_i|r, wr * d_r|i):
+//       ||dx'|| <= u |x + y|;  ||dy'|| <= u |d| (sqrt5 + 1 + 0.72)(1 + 4u) <= 3.96 u |x - y|(1 + 4u)
+//     so ||(dx', dy')|| <= sqrt(1 + 3.96^2) u sqrt(|x+y|^2 + |x-y|^2)(1+4u) <= 5.8 u ||(x, y)||_2:  eps_i = 5.8 u.
+// (3) A whole transform: with e_s = ||v^_s - v_s|| / (2^(s/2) ||v_0||),  1 + e_s <= (1 + eps/sqrt2)(1 + e_(s-1)), hence
+//       ||X^ - X||_2 <= (g_f - 1) sqrt(M) ||x||_2,  ||X^||_2 <= g_f sqrt(M) ||x||_2,  g_f = (1 + eps_f/sqrt2)^k,  g_i likewise.
+//     (digits and key halves convert to FP64 exactly; the key's 1/M is a power of two.)
+// (4) Pointwise sums Z'_t = sum_r X_rt Y'_rt (Y' = Y/M), 2R FMAs per component:  |dZ'_t| <= sqrt2 gamma_2R sum_r |X^_rt||Y'^_rt|,
+//     gamma_n = n u / (1 - n u). With the transform errors of both operands and Cauchy-Schwarz over t:
+//       ||Z'^ - Z'||_1 <= S (g_f^2 - 1 + sqrt2 gamma_2R g_f^2),   S = sum_r ||d_r||_2 ||k_r||_2 <= R D K N.
+// (5) The exact inverse maps that error to at most its 1-norm per entry (unit-modulus entries of G). The inverse transform's
+//     own rounding is bounded in the 2-norm, which bounds every entry:  (g_i - 1) ||G Z'^||_2 = (g_i - 1) sqrt(M) ||Z'^||_2
+//     and ||Z'^||_2 <= ||Z'^||_1 <= S g_f^2 (1 + sqrt2 gamma_2R). Altogether, for EVERY input,
+//       |c^_j - c_j| <= S ( g_f^2 - 1 + sqrt2 gamma_2R g_f^2 + (g_i - 1) sqrt(M) g_f^2 (1 + sqrt2 gamma_2R) ).
+// Values: default-128 0.0014, REDsec shipped set 3.0e-4, redsec_params_small 0.011, medium 0.10, large 0.30 -- all below 1/2,
+// so rounding to the nearest integer returns the exact integer for every input of every set the reference defines
+// (tests/test_emulator.py asserts the five values; the per-stage constants are sanity-checked there against an
+// 80-bit reference transform). Sets whose bound is not below 1/4 (large) additionally run under the ENFORCED rounding
+// certificate (rs_api.cpp): with an a-priori error below 3/4, a largest rounding distance below 1/4 proves the error
+// itself is below 1/4; a call that fails the check poisons its context (RS_ERR_INEXACT) instead of returning silently.
+// The sqrt(M) of term (5) is the price of a 2-norm argument; measured distances are 4e-6 (tests/test_gpu_general.py).
 inline double gen_error_bound(int logn, int l, int bgbit) {
+  const double N = std::ldexp(1.0, logn), M = N / 2.0;
+  const int k = logn - 1;
+  const double u = std::ldexp(1.0, -53), r2 = std::sqrt(2.0);
+  const double gf = std::pow(1.0 + 8.3 * u / r2, k), gi = std::pow(1.0 + 5.8 * u / r2, k);
+  const double rows = 2.0 * l;
+  const double gam = r2 * (2.0 * rows * u) / (1.0 - 2.0 * rows * u);
+  const double S = rows * std::ldexp(1.0, bgbit - 1) * 32768.0 * N;
+  return S * (gf * gf - 1.0 + gam * gf * gf + (gi - 1.0) * std::sqrt(M) * gf * gf * (1.0 + gam));
+}
+// Round 2's figure, for reference only (Percival's convolution theorem as recalled, doubled): nothing depends on it.
+inline double gen_error_bound_recalled(int logn, int l, int bgbit) {
   const double N = std::ldexp(1.0, logn);
-  const int n = logn;   // log2(M) + 1
+  const int n = logn;
   const double u = std::ldexp(1.0, -53), beta = u;
   const double growth = std::pow(1.0 + u, 3.0 * n) * std::pow(1.0 + u * std::sqrt(5.0), 3.0 * n + 1.0) * std::pow(1.0 + beta, 3.0 * n) - 1.0;
-  const double norm_d = std::ldexp(1.0, bgbit - 1) * std::sqrt(N);   // |d| <= Bg/2 on N coefficients
-  const double norm_k = 32768.0 * std::sqrt(N);
-  const double rows = 2.0 * l;
-  return 2.0 * rows * norm_d * norm_k * growth;
+  return 2.0 * (2.0 * l) * std::ldexp(1.0, bgbit - 1) * std::sqrt(N) * 32768.0 * std::sqrt(N) * growth;
 }
+// the split mode is offered below 1/2 (exact for every input) and runs under the enforced certificate from 1/4 upwards
+constexpr double kSplitBoundOffer = 0.5, kSplitBoundEnforce = 0.25;
 
 }  // namespace rs

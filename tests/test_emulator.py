@@ -204,8 +204,25 @@ def test_general_path_split_product_is_exact(logn, half):
 
 
 def test_general_path_bound_covers_every_reference_parameter_set():
-    for logn, l, bgbit in ((10, 3, 7), (10, 10, 3), (10, 3, 10), (12, 3, 10), (13, 3, 10)):
-        assert emu_lib.lib().rs_emu_gen_error_bound(logn, l, bgbit) < 0.02
+    """The split-key bound DERIVED in rs_general.h (no quoted theorem): below 1/2 -- rounding exact for every input -- for all
+    five sets the reference defines (client/gen_secure_keyset.cpp:9-91 and TFHE's default), below 1/4 up to N = 4096."""
+    want = {(10, 3, 7): 0.00135, (10, 10, 3): 0.0003, (10, 3, 10): 0.0108, (12, 3, 10): 0.098, (13, 3, 10): 0.296}
+    for (logn, l, bgbit), v in want.items():
+        b = emu_lib.lib().rs_emu_gen_error_bound(logn, l, bgbit)
+        assert b < 0.5 and abs(b - v) < 0.03 * v + 1e-5, (logn, l, bgbit, b)
+        if logn <= 12:
+            assert b < 0.25
+
+
+@pytest.mark.parametrize("logn", [10, 12, 13])
+def test_general_path_transform_error_constants(logn):
+    """Sanity check of the analysis' per-stage constants: the measured 2-norm error of one forward / one inverse transform
+    (device butterflies, emulated; 80-bit reference) stays below g_f - 1 / g_i - 1, for random and for extreme-magnitude input."""
+    import ctypes as C
+    for seed, amp in ((1, 512), (2, 4), (3, 32768)):
+        got, bound = (C.c_double * 2)(), (C.c_double * 2)()
+        assert emu_lib.lib().rs_emu_gen_transform_errors(logn, seed, amp, got, bound) == 0
+        assert 0 < got[0] < bound[0] and 0 < got[1] < bound[1], (logn, seed, list(got), list(bound))
 
 
 @pytest.mark.parametrize("l,bgbit", [(3, 10), (3, 7), (10, 3), (2, 16), (4, 8)])
