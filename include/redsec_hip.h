@@ -220,7 +220,21 @@ int rs_copy_to_host(rs_ctx* ctx, void* dst_host, const void* src_dev, size_t byt
 /* Device-to-device copy between the devices of two contexts (the same device is fine): the slice exchange of a
  * stage sharded over several GPUs of one process. Synchronous. */
 int rs_copy_dev_to_dev(rs_ctx* dst_ctx, void* dst_dev, rs_ctx* src_ctx, const void* src_dev, size_t bytes);
+/* The slice exchange of a stage sharded over the n contexts of one process (the reference's shape: one host process driving
+ * NUM_GPUS devices, lib/GPU/Layer.cuh:15,22-37, which has no merge step at all). bufs[d] is context d's full replica
+ * int32[rows][row_words]; context d has just computed rows shard(d) = the d-th of n balanced contiguous slices (sizes differ
+ * by at most one, lower ranks first) into it, on ITS default stream. Afterwards every replica holds every slice.
+ * Entirely asynchronous and event-ordered: each context records an event behind its slice; every destination pulls
+ * slice e on a private copy stream as soon as e's event has fired (hipMemcpyPeerAsync over xGMI, peer access enabled once per
+ * device pair; contexts on one device copy device-to-device), so slice e moves while e+1 is still being computed; finally
+ * every context's default stream waits for all copies, so later launches (and buffer reuse) on any of them are ordered
+ * behind the exchange. Nothing blocks the host. */
+int rs_allgather_rows(rs_ctx* const* ctxs, int n_ctx, int32_t* const* bufs, size_t rows, size_t row_words);
 int rs_sync(rs_ctx* ctx);
+/* Drops the private state a context keeps for `stream` (workspace, certificate slots, events; see "Streams" above) after
+ * synchronising it. For callers that create and destroy many streams: a later stream with the same handle value would
+ * otherwise inherit the old one's workspace size and running certificate. The default stream's state cannot be released. */
+int rs_release_stream(rs_ctx* ctx, void* stream);
 
 /* Time (ms) of the kernels enqueued by the last *_dev / host call, by HIP events on the stream the
  * kernels ran on; -1 if not available. Index: 0 blind-rotate, 1 keyswitch. */

@@ -23,6 +23,7 @@ ABI_SYMBOLS = [
     "rs_set_timing", "rs_last_kernel_ms", "rs_info", "rs_set_mode", "rs_get_mode", "rs_rounding_certificate", "rs_fft_fallbacks",
     "rs_bootstrap_lut_dev", "rs_set_certificate_limit", "rs_certify", "rs_reserve_stream", "rs_last_kernel_ms_stream", "rs_last_launch", "rs_copy_dev_to_dev",
     "rs_params_redsec_small", "rs_params_redsec_medium", "rs_params_redsec_large", "rs_split_bound",
+    "rs_allgather_rows", "rs_release_stream",
 ]
 
 GATES = {"NAND": 0, "OR": 1, "AND": 2, "NOR": 3, "XOR": 4, "XNOR": 5, "ANDNY": 6, "ANDYN": 7, "ORNY": 8, "ORYN": 9}
@@ -106,6 +107,8 @@ def load_library(path=None):
     L.rs_fft_fallbacks.argtypes = [vp, C.POINTER(C.c_int64)]
     L.rs_bootstrap_lut_dev.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp]
     L.rs_copy_dev_to_dev.argtypes = [vp, vp, vp, vp, C.c_size_t]
+    L.rs_allgather_rows.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp), C.c_size_t, C.c_size_t]
+    L.rs_release_stream.argtypes = [vp, vp]
     L.rs_set_certificate_limit.argtypes = [vp, C.c_double]
     L.rs_certify.argtypes = [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
     L.rs_reserve_stream.argtypes = [vp, C.c_size_t, vp]

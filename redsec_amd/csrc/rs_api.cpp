@@ -102,6 +102,10 @@ struct rs_ctx {
   std::mutex host_mu;                               // serialises the synchronous host-pointer calls (shared staging buffers)
   int32_t* d_io[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t io_batch = 0;
+  // rs_allgather_rows: private copy stream, "my slice is computed" / "my copies are done" events, peers already enabled
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_slice = nullptr, ev_copied = nullptr;
+  std::vector<int> peers_enabled;
 };
 
 namespace {
@@ -323,6 +327,9 @@ void destroy_ctx(rs_ctx* c) {
   (void)hipFree(c->d_tw_gen); (void)hipFree(c->d_bk_gen);
   for (auto& kv : c->lanes) free_lane(kv.second.get());
   for (auto& p : c->d_io) (void)hipFree(p);
+  if (c->ev_slice) (void)hipEventDestroy(c->ev_slice);
+  if (c->ev_copied) (void)hipEventDestroy(c->ev_copied);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   delete c;
 }
 
@@ -880,6 +887,81 @@ int rs_copy_dev_to_dev(rs_ctx* dc, void* dst, rs_ctx* sc, const void* src, size_
   if (dc->device == sc->device) RS_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
   else RS_HIP(hipMemcpyPeer(dst, dc->device, src, sc->device, bytes));   // staged through the host where peer access is off
   return RS_OK;
+}
+// balanced contiguous slices, lower ranks first (redsec_amd/sharding.py::shard_range, layers.cpp::shard_range)
+static void slice_of(size_t total, int d, int D, size_t* lo, size_t* hi) {
+  const size_t base = total / (size_t)D, rem = total % (size_t)D;
+  *lo = (size_t)d * base + ((size_t)d < rem ? (size_t)d : rem);
+  *hi = *lo + base + ((size_t)d < rem ? 1 : 0);
+}
+static int exchange_state(rs_ctx* c) {
+  RS_HIP(hipSetDevice(c->device));
+  if (!c->copy_stream) RS_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  if (!c->ev_slice) RS_HIP(hipEventCreateWithFlags(&c->ev_slice, hipEventDisableTiming));
+  if (!c->ev_copied) RS_HIP(hipEventCreateWithFlags(&c->ev_copied, hipEventDisableTiming));
+  return RS_OK;
+}
+int rs_allgather_rows(rs_ctx* const* ctxs, int n, int32_t* const* bufs, size_t rows, size_t row_words) {
+  if (!ctxs || !bufs || n < 1) return fail(RS_ERR_INVALID, "null argument");
+  if (n == 1 || rows == 0) return RS_OK;
+  for (int d = 0; d < n; ++d) {
+    if (!ctxs[d] || !bufs[d]) return fail(RS_ERR_INVALID, "null context or buffer %d", d);
+    const int rc = exchange_state(ctxs[d]);
+    if (rc) return rc;
+    RS_HIP(hipEventRecord(ctxs[d]->ev_slice, nullptr));   // behind the kernels that wrote slice d (default stream of device d)
+  }
+  for (int d = 0; d < n; ++d) {
+    rs_ctx* dc = ctxs[d];
+    RS_HIP(hipSetDevice(dc->device));
+    for (int k = 1; k < n; ++k) {
+      const int e = (d + k) % n;                          // staggered: at any moment the n destinations pull from n different sources
+      rs_ctx* sc = ctxs[e];
+      size_t lo, hi;
+      slice_of(rows, e, n, &lo, &hi);
+      if (hi == lo) continue;
+      const size_t off = lo * row_words, bytes = (hi - lo) * row_words * sizeof(int32_t);
+      RS_HIP(hipStreamWaitEvent(dc->copy_stream, sc->ev_slice, 0));
+      if (dc->device == sc->device) {
+        RS_HIP(hipMemcpyAsync(bufs[d] + off, bufs[e] + off, bytes, hipMemcpyDeviceToDevice, dc->copy_stream));
+      } else {
+        if (std::find(dc->peers_enabled.begin(), dc->peers_enabled.end(), sc->device) == dc->peers_enabled.end()) {
+          int can = 0;
+          if (hipDeviceCanAccessPeer(&can, dc->device, sc->device) == hipSuccess && can) {
+            const hipError_t pe = hipDeviceEnablePeerAccess(sc->device, 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return fail(RS_ERR_HIP, "hipDeviceEnablePeerAccess(%d -> %d): %s", dc->device, sc->device, hipGetErrorString(pe));
+            (void)hipGetLastError();
+          }
+          dc->peers_enabled.push_back(sc->device);       // without peer access hipMemcpyPeerAsync stages through the host: slower, still correct
+        }
+        RS_HIP(hipMemcpyPeerAsync(bufs[d] + off, dc->device, bufs[e] + off, sc->device, bytes, dc->copy_stream));
+      }
+    }
+    RS_HIP(hipEventRecord(dc->ev_copied, dc->copy_stream));
+  }
+  // every default stream continues behind ALL copies: its own (it reads the gathered slices next) and the others' (they read
+  // its slice; the caller may reuse or free the buffer in stream order afterwards)
+  for (int d = 0; d < n; ++d) {
+    RS_HIP(hipSetDevice(ctxs[d]->device));
+    for (int e = 0; e < n; ++e) RS_HIP(hipStreamWaitEvent(nullptr, ctxs[e]->ev_copied, 0));
+  }
+  return RS_OK;
+}
+int rs_release_stream(rs_ctx* c, void* stream) {
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (!stream) return fail(RS_ERR_INVALID, "the default stream's state lives as long as the context");
+  RS_HIP(hipStreamSynchronize((hipStream_t)stream));
+  std::unique_ptr<Lane> ln;
+  {
+    std::lock_guard<std::mutex> g(c->lanes_mu);
+    auto it = c->lanes.find((hipStream_t)stream);
+    if (it == c->lanes.end()) return RS_OK;
+    ln = std::move(it->second);
+    c->lanes.erase(it);
+  }
+  rc = split_check_lane(c, ln.get());   // what its last split-mode call reported is not lost with the lane
+  free_lane(ln.get());
+  return rc;
 }
 int rs_sync(rs_ctx* c) {
   int rc = use_device(c);

@@ -18,12 +18,17 @@
 #include <algorithm>
 #include <cassert>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <functional>
+#include <iterator>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "lib/BinLayer.h"
@@ -249,13 +254,84 @@ namespace redsec_host {
 
 // A ciphertext array on the device(s): one full replica int32[rows][W] per context of the fleet (one context =
 // one GPU; a single GPU unless REDSEC_DEVICES lists several).
+// Device buffers come from a per-context cache instead of hipMalloc / hipFree per stage (hipFree waits for the whole device;
+// a layer chain allocates and frees a few hundred MB a dozen times per image, always the same few sizes). Every use of a
+// context's buffers is enqueued on its device's default stream in program order (launches, the synchronous host copies, and
+// rs_allgather_rows, which makes every default stream wait for all peer copies), so handing a block out again in stream order
+// is safe without waiting for anything.
+struct BufPool {
+  std::mutex mu;
+  std::multimap<size_t, void*> idle;     // size -> block
+  std::map<void*, size_t> size_of;       // every block this pool owns
+  size_t idle_bytes = 0;
+};
+std::mutex g_pool_lock;
+std::map<rs_ctx*, std::unique_ptr<BufPool>> g_pools;
+constexpr size_t kPoolIdleCap = size_t(3) << 30;   // idle bytes kept per context before blocks go back to the runtime
+BufPool* pool_of(rs_ctx* c) {
+  std::lock_guard<std::mutex> g(g_pool_lock);
+  auto& p = g_pools[c];
+  if (!p) p.reset(new BufPool);
+  return p.get();
+}
+void* pool_alloc(rs_ctx* c, size_t bytes) {
+  if (bytes == 0) bytes = 4;
+  BufPool* P = pool_of(c);
+  {
+    std::lock_guard<std::mutex> g(P->mu);
+    auto it = P->idle.lower_bound(bytes);
+    if (it != P->idle.end() && it->first <= bytes + bytes / 2 + 4096) {   // close fit: stage sizes recur exactly
+      void* p = it->second;
+      P->idle_bytes -= it->first;
+      P->idle.erase(it);
+      return p;
+    }
+  }
+  void* p = nullptr;
+  if (rs_dev_alloc(c, &p, bytes) != 0) {
+    // out of device memory with blocks idle: give them back and try once more
+    std::vector<void*> drop;
+    { std::lock_guard<std::mutex> g(P->mu); for (auto& kv : P->idle) { drop.push_back(kv.second); P->size_of.erase(kv.second); } P->idle.clear(); P->idle_bytes = 0; }
+    for (void* q : drop) (void)rs_dev_free(c, q);
+    if (rs_dev_alloc(c, &p, bytes) != 0) { fprintf(stderr, "redsec layers: rs_dev_alloc(%zu bytes): %s\n", bytes, rs_last_error()); abort(); }
+  }
+  std::lock_guard<std::mutex> g(P->mu);
+  P->size_of[p] = bytes;
+  return p;
+}
+void pool_free(rs_ctx* c, void* p) {
+  if (!p) return;
+  BufPool* P = pool_of(c);
+  std::vector<void*> drop;
+  {
+    std::lock_guard<std::mutex> g(P->mu);
+    auto it = P->size_of.find(p);
+    if (it == P->size_of.end()) { drop.push_back(p); }          // not ours (should not happen): plain free
+    else {
+      P->idle.emplace(it->second, p);
+      P->idle_bytes += it->second;
+      while (P->idle_bytes > kPoolIdleCap && !P->idle.empty()) { // keep the cache bounded: largest blocks go first
+        auto big = std::prev(P->idle.end());
+        P->idle_bytes -= big->first;
+        P->size_of.erase(big->second);
+        drop.push_back(big->second);
+        P->idle.erase(big);
+      }
+    }
+  }
+  for (void* q : drop) (void)rs_dev_free(c, q);
+}
+
 struct DevSlab {
   std::vector<int32_t*> ptr;     // [device]
   std::vector<rs_ctx*> ctx;      // [device]
   size_t rows = 0;
   uint64_t tag = 0;   // fingerprint of the host copy handed out with it
   uint64_t seq = 0;   // publication order
-  void release() { for (size_t d = 0; d < ptr.size(); ++d) if (ptr[d]) (void)rs_dev_free(ctx[d], ptr[d]); ptr.clear(); ctx.clear(); }
+  bool lazy = false;  // REDSEC_LAZY_HOST: the host arrays handed out with it were never filled (see publish)
+  bool bits = true;   // the host array is tBit[rows] (else tMultiBit[rows] with one sample each)
+  int row_words = 0;  // W of a lazy slab (redsec_materialize)
+  void release() { for (size_t d = 0; d < ptr.size(); ++d) pool_free(ctx[d], ptr[d]); ptr.clear(); ctx.clear(); }
 };
 
 // Device copies of the ciphertext arrays handed back to the caller, keyed by host pointer. A slab is
@@ -318,12 +394,20 @@ constexpr int32_t kUnitRelu = 1 << 18;   // ReLU outputs: 1/16384, so that 1,024
 constexpr int32_t kQuarter = 1 << 30;
 constexpr int kSlopeBitsInt = 8;         // lib/IntFunc.cpp:45
 
-// The unit in which a network's values travel is not part of tDimensions, so it rides beside it: keyed by
-// the tDimensions object the driver threads through every prep() (nets/*/*/net.cpp: p_dim = layerK->prep(f, p_dim)),
-// together with a copy of what that object held when the previous layer returned it -- a driver that starts
-// a new network with the same object is recognised by the contents having changed.
-struct UnitNote { tDimensions seen; int32_t unit; };
-std::map<const tDimensions*, UnitNote> g_units;
+// The unit in which a network's values travel rides INSIDE the tDimensions object the driver threads through every prep()
+// (nets/*/*/net.cpp: p_dim = layerK->prep(f, p_dim)): two private trailing fields of the mirror's struct (lib/Layer.h here;
+// drivers are compiled against it and never touch them). redsec_unit is believed only while redsec_tag equals the
+// fingerprint of the public fields as the previous layer left them: a driver's fresh (uninitialised) object, or one it
+// re-initialises for another network, fails the check and starts at 1/4096. No process-wide table: any number of networks.
+uint32_t dims_tag(const tDimensions* d) {
+  uint32_t h = 2166136261u;
+  auto mix = [&](uint32_t v) { h ^= v; h *= 16777619u; };
+  uint32_t fbits;
+  memcpy(&fbits, &d->scale, sizeof fbits);
+  mix((uint16_t)d->hw.h); mix((uint16_t)d->hw.w); mix(d->in_dep); mix(d->in_bits); mix(d->out_bits); mix(d->filter_bits); mix(d->bias_bits);
+  mix(d->up_bound); mix(fbits);
+  return h ^ 0x52454453u;   // "REDS"
+}
 
 struct LayerImpl {
   bool is_int;
@@ -357,6 +441,7 @@ struct LayerImpl {
   // Encoding: torus32 value of ONE integer step of this layer's input / output (1/4096 = 2^20 for client
   // pixels and sign bits, 1/16384 = 2^18 for ReLU outputs; DESIGN.md "ReLU semantics")
   int32_t unit_in = kUnit4096, unit_out = kUnit4096;
+  int32_t final_rescale = 1;   // see prep_impl
   // IntFunc::Convolution's plaintext branch negates by one's complement (-x - 1): per output channel the
   // number of negative taps, folded into the bias of integer layers (see int_conv_plain)
   std::vector<int32_t> neg_taps;
@@ -411,11 +496,7 @@ tDimensions* prep_impl(LayerImpl* L, FILE* fd, tDimensions* dim, tDimensions* in
   assert(!L->prepared && dim != NULL);
   *in_dim = *dim;
   L->in_count = dim->hw.h * dim->hw.w * (int)dim->in_dep;
-  {
-    std::lock_guard<std::mutex> g(g_lock);
-    auto it = g_units.find(dim);
-    L->unit_in = (it != g_units.end() && memcmp(&it->second.seen, dim, sizeof *dim) == 0) ? it->second.unit : kUnit4096;
-  }
+  L->unit_in = (dim->redsec_tag == dims_tag(dim) && (dim->redsec_unit == kUnit4096 || dim->redsec_unit == kUnitRelu)) ? dim->redsec_unit : kUnit4096;
   if (L->e_conv != E_NO_CONV) {
     if (L->e_conv == E_FC || L->e_conv == E_FC_FINAL) { dim->in_dep *= dim->hw.h * dim->hw.w; dim->hw.h = 1; dim->hw.w = 1; }   // flatten
     const tConvParams& c = L->np.conv;
@@ -531,11 +612,12 @@ tDimensions* prep_impl(LayerImpl* L, FILE* fd, tDimensions* dim, tDimensions* in
         }
     dim->hw.h = (int16_t)g.Ho; dim->hw.w = (int16_t)g.Wo;
   }
+  // a final layer (no activation) hands its logits back in 1/4096 steps whatever unit they were summed in, because that is
+  // what the reference's client decodes with (client/decrypt_image.cpp:52-58, message space 4096): see run_layer
+  L->final_rescale = (L->e_act == E_ACTIVATION_NONE && L->unit_out != kUnit4096 && !getenv("REDSEC_KEEP_UNIT")) ? kUnit4096 / L->unit_out : 1;
+  dim->redsec_unit = L->final_rescale != 1 ? kUnit4096 : L->unit_out;
+  dim->redsec_tag = dims_tag(dim);
   *out_dim = *dim;
-  {
-    std::lock_guard<std::mutex> g(g_lock);
-    g_units[dim] = UnitNote{*dim, L->unit_out};
-  }
   L->prepared = true;
   return dim;
 }
@@ -563,8 +645,7 @@ std::vector<int32_t> relu_luts(const LayerImpl* L) {
 
 template <class T>
 T* to_device(rs_ctx* c, const std::vector<T>& host) {
-  T* p = nullptr;
-  RS_CHECK(rs_dev_alloc(c, (void**)&p, host.size() * sizeof(T)));
+  T* p = (T*)pool_alloc(c, host.size() * sizeof(T));
   RS_CHECK(rs_copy_to_dev(c, p, host.data(), host.size() * sizeof(T)));
   return p;
 }
@@ -601,11 +682,7 @@ void upload_weights(LayerImpl* L) {
   }
 }
 
-int32_t* dev_rows(rs_ctx* c, size_t rows, int W) {
-  int32_t* p = nullptr;
-  RS_CHECK(rs_dev_alloc(c, (void**)&p, rows * (size_t)W * 4));
-  return p;
-}
+int32_t* dev_rows(rs_ctx* c, size_t rows, int W) { return (int32_t*)pool_alloc(c, rows * (size_t)W * 4); }
 
 // contiguous, balanced slice of `total` rows for device d of D (sizes differ by at most one; the same split as
 // redsec_amd/sharding.py::shard_range)
@@ -615,7 +692,60 @@ void shard_range(size_t total, int d, int D, size_t* lo, size_t* hi) {
   *hi = *lo + base + ((size_t)d < rem ? 1 : 0);
 }
 
-// The devices a layer runs on, and the two ways a stage uses them.
+// One host thread per device beyond the first, as the reference drives its GPUs (lib/GPU/BinFunc_gpu.cu:118-137: one
+// thread per enc_segs[g]): the per-device work of a stage (allocation, per-call host preparation, launches) is issued
+// concurrently, device 0's by the calling thread. Threads are started once per process and parked between stages.
+class DeviceWorkers {
+  struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool busy = false, quit = false;
+  };
+  std::vector<std::unique_ptr<Worker>> w_;
+  std::mutex grow_;
+  static void loop(Worker* w) {
+    std::unique_lock<std::mutex> lk(w->mu);
+    for (;;) {
+      w->cv.wait(lk, [&] { return w->busy || w->quit; });
+      if (w->quit) return;
+      std::function<void()> job = std::move(w->job);
+      lk.unlock();
+      job();
+      lk.lock();
+      w->busy = false;
+      w->cv.notify_all();
+    }
+  }
+ public:
+  ~DeviceWorkers() {
+    for (auto& w : w_) { { std::lock_guard<std::mutex> g(w->mu); w->quit = true; } w->cv.notify_all(); w->th.join(); }
+  }
+  // f(d) for d in [0, D): d >= 1 on worker d - 1, d = 0 here; returns when all are done (a host-side join, no device wait)
+  template <class F>
+  void run(int D, F f) {
+    if (D <= 1) { if (D == 1) f(0); return; }
+    std::lock_guard<std::mutex> serial(grow_);   // one stage at a time (layers of one process run one after the other anyway)
+    while ((int)w_.size() < D - 1) { w_.emplace_back(new Worker); Worker* w = w_.back().get(); w->th = std::thread(loop, w); }
+    for (int d = 1; d < D; ++d) {
+      Worker* w = w_[(size_t)d - 1].get();
+      { std::lock_guard<std::mutex> g(w->mu); w->job = [&f, d] { f(d); }; w->busy = true; }
+      w->cv.notify_all();
+    }
+    f(0);
+    for (int d = 1; d < D; ++d) {
+      Worker* w = w_[(size_t)d - 1].get();
+      std::unique_lock<std::mutex> lk(w->mu);
+      w->cv.wait(lk, [&] { return !w->busy; });
+    }
+  }
+};
+DeviceWorkers g_workers;
+
+// The devices a layer runs on, and the two ways a stage uses them. Nothing here waits for a device: stages follow one
+// another in each device's default-stream order, the slice exchange is ordered by events (rs_allgather_rows), and the only
+// synchronisation of a layer chain is the download of what the caller asked for.
 struct Fleet {
   rs_ctx** c;
   int D;
@@ -625,34 +755,26 @@ struct Fleet {
   template <class F>
   std::vector<int32_t*> replicated(size_t rows, F launch) const {
     std::vector<int32_t*> y((size_t)D);
-    for (int d = 0; d < D; ++d) { y[d] = dev_rows(c[d], rows, W); launch(d, c[d], y[d]); }
-    for (int d = 0; d < D; ++d) RS_CHECK(rs_sync(c[d]));
+    g_workers.run(D, [&](int d) { y[d] = dev_rows(c[d], rows, W); launch(d, c[d], y[d]); });
     return y;
   }
   // a stage of independent ciphertexts (every bootstrap: lib/BinFunc.cpp:1056-1071 has no cross-iteration dependence):
-  // device d computes its contiguous slice into its own replica, then every device pulls the other slices, so that the
-  // next linear stage finds the whole vector everywhere. One device: no exchange at all.
+  // device d computes its contiguous slice into its own replica, then every device pulls the other slices as they become
+  // ready, so that the next linear stage finds the whole vector everywhere. One device: no exchange at all.
   template <class F>
   std::vector<int32_t*> sharded(size_t rows, F launch) const {
     std::vector<int32_t*> y((size_t)D);
-    for (int d = 0; d < D; ++d) {
+    g_workers.run(D, [&](int d) {
       y[d] = dev_rows(c[d], rows, W);
       size_t lo, hi;
       shard_range(rows, d, D, &lo, &hi);
       if (hi > lo) launch(d, c[d], y[d] + lo * (size_t)W, lo, hi - lo);
-    }
-    for (int d = 0; d < D; ++d) RS_CHECK(rs_sync(c[d]));
-    for (int d = 0; d < D; ++d)
-      for (int e = 0; e < D; ++e) {
-        if (e == d) continue;
-        size_t lo, hi;
-        shard_range(rows, e, D, &lo, &hi);
-        RS_CHECK(rs_copy_dev_to_dev(c[d], y[d] + lo * (size_t)W, c[e], y[e] + lo * (size_t)W, (hi - lo) * (size_t)W * 4));
-      }
+    });
+    if (D > 1) RS_CHECK(rs_allgather_rows(c, D, y.data(), rows, (size_t)W));
     return y;
   }
   void release(std::vector<int32_t*>& v) const {
-    for (int d = 0; d < D; ++d) if (v[d]) RS_CHECK(rs_dev_free(c[d], v[d]));
+    for (int d = 0; d < D; ++d) pool_free(c[d], v[d]);
     v.clear();
   }
 };
@@ -762,6 +884,12 @@ DevSlab run_layer(LayerImpl* L, DevSlab x) {
       replace(std::move(accv), out);
     }
   }
+  if (L->final_rescale != 1) {
+    // logits summed in the ReLU unit (1/16384) leave in the client's (1/4096): an exact word-wise multiple
+    replace(f.replicated(x.rows, [&](int d, rs_ctx* c, int32_t* y) {
+      RS_CHECK(rs_lincomb_dev(c, y, x.ptr[d], L->final_rescale, nullptr, 0, 0, x.rows, nullptr));
+    }), x.rows);
+  }
   x.ctx.assign(f.c, f.c + f.D);
   return x;
 }
@@ -773,6 +901,10 @@ DevSlab stage_input(LayerImpl* L, const void* key, const std::vector<const LweSa
   rs_ctx** fleet = L->fleet(&D);
   const int W = L->W(), n = W - 1;
   const bool had = take(key, &s);
+  if (had && s.lazy && s.rows == samples.size() && (int)s.ctx.size() == D && std::equal(s.ctx.begin(), s.ctx.end(), fleet)) {
+    s.lazy = false;
+    return s;   // the host arrays are placeholders (REDSEC_LAZY_HOST): the device copy is the only one there is
+  }
   if (had && s.rows == samples.size() && (int)s.ctx.size() == D && std::equal(s.ctx.begin(), s.ctx.end(), fleet)) {
     // same fingerprint as at publication: sampled rows only (packing 131,072 x 351 words per layer just to
     // compare them would cost more than the check is worth)
@@ -808,8 +940,22 @@ std::vector<int32_t> download(const DevSlab& s, int W) {
 }
 
 // Output as the reference returns it: tBit* for sign layers, tMultiBit* (ctxt[0] used) otherwise.
+// REDSEC_LAZY_HOST=1 (opt-in): a layer WITH an activation -- every layer but a network's last -- hands back host arrays of the
+// right shape that are allocated but never filled; the resident device slab is the data. Downloading 131,072 x 351 words and
+// rebuilding the array-of-structs costs ~100 ms per CIFAR layer, and an unmodified driver only ever passes those arrays to
+// the next layer. A layer without activation (the logits) is always downloaded. Code that wants to READ an intermediate
+// array calls redsec_materialize(array) first.
+static bool lazy_host() { static const bool on = [] { const char* v = getenv("REDSEC_LAZY_HOST"); return v && *v && strcmp(v, "0") != 0; }(); return on; }
 void* publish(LayerImpl* L, DevSlab out) {
   const int W = L->W(), n = W - 1;
+  if (lazy_host() && L->e_act != E_ACTIVATION_NONE) {
+    out.lazy = true;
+    out.bits = L->e_act == E_ACTIVATION_SIGN;
+    out.row_words = W;
+    void* ret = L->e_act == E_ACTIVATION_SIGN ? (void*)bit_calloc((uint32_t)out.rows, L->bk) : (void*)mbit_calloc((uint32_t)out.rows, 1, L->bk);
+    remember(ret, out);
+    return ret;
+  }
   std::vector<int32_t> host = download(out, W);
   out.tag = fingerprint(host.data(), out.rows, W);
   void* ret = nullptr;
@@ -827,6 +973,50 @@ void* publish(LayerImpl* L, DevSlab out) {
 }
 
 }  // namespace redsec_host
+
+// Fills a host array that REDSEC_LAZY_HOST left empty (no-op for any other pointer): the slab comes down and is unpacked
+// into the caller's array; the device copy stays resident for the next layer.
+void redsec_materialize(void* host_array) {
+  using namespace redsec_host;
+  DevSlab s;
+  {
+    std::lock_guard<std::mutex> g(g_lock);
+    auto it = g_resident.find(host_array);
+    if (it == g_resident.end() || !it->second.lazy) return;
+    s = it->second;
+  }
+  const size_t rows = s.rows;
+  const int W = s.row_words, n = W - 1;
+  std::vector<int32_t> host(rows * (size_t)W);
+  RS_CHECK(rs_copy_to_host(s.ctx[0], host.data(), s.ptr[0], host.size() * 4));
+  if (s.bits) { tBit* b = (tBit*)host_array; for (size_t i = 0; i < rows; ++i) redsec_unpack(&b[i], &host[i * W], n); }
+  else { tMultiBit* m = (tMultiBit*)host_array; for (size_t i = 0; i < rows; ++i) redsec_unpack(&m[i].ctxt[0], &host[i * W], n); }
+  std::lock_guard<std::mutex> g(g_lock);
+  auto it = g_resident.find(host_array);
+  if (it != g_resident.end() && it->second.seq == s.seq) { it->second.lazy = false; it->second.tag = fingerprint(host.data(), rows, W); }
+}
+// Before a context is destroyed (tfhe_shim.cpp, delete_gate_bootstrapping_*_keyset): resident slabs and cached blocks of it go.
+void redsec_pool_release(rs_ctx* c) {
+  using namespace redsec_host;
+  std::vector<DevSlab> gone;
+  {
+    std::lock_guard<std::mutex> g(g_lock);
+    for (auto it = g_resident.begin(); it != g_resident.end();) {
+      if (std::find(it->second.ctx.begin(), it->second.ctx.end(), c) != it->second.ctx.end()) { gone.push_back(it->second); it = g_resident.erase(it); }
+      else ++it;
+    }
+  }
+  for (DevSlab& sl : gone) sl.release();
+  std::unique_ptr<BufPool> P;
+  {
+    std::lock_guard<std::mutex> g(g_pool_lock);
+    auto it = g_pools.find(c);
+    if (it == g_pools.end()) return;
+    P = std::move(it->second);
+    g_pools.erase(it);
+  }
+  for (auto& kv : P->idle) (void)rs_dev_free(c, kv.second);
+}
 
 using redsec_host::LayerImpl;
 

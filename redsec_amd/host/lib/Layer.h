@@ -34,6 +34,10 @@ typedef struct _DIMS {
   uint8_t in_bits, out_bits, filter_bits, bias_bits;
   uint32_t up_bound;
   float scale;
+  /* mirror-private, behind the reference's fields (lib/Layer.h:31-45): the torus unit of one integer step of the values this
+   * object describes, believed only while redsec_tag matches the fields above (layers.cpp, dims_tag). Drivers never touch them. */
+  uint32_t redsec_tag;
+  int32_t redsec_unit;
 } tDimensions;
 
 typedef struct _CONV_PARAMS { tRectangle window; bool same_pad; float tern_thresh; tRectangle stride; } tConvParams;

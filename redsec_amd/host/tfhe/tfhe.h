@@ -181,6 +181,10 @@ rs_ctx* redsec_ctx_of(const TFheGateBootstrappingCloudKeySet* bk);
 // stage across them (the reference's shape: one host thread per GPU over enc_segs[NUM_GPUS], lib/GPU/BinFunc_gpu.cu:119-137).
 // Unset: the single device REDSEC_DEVICE (default 0). redsec_fleet_of returns the contexts, *count how many.
 rs_ctx** redsec_fleet_of(const TFheGateBootstrappingCloudKeySet* bk, int* count);
+// REDSEC_LAZY_HOST=1 leaves the host arrays of intermediate layers unfilled (layers.cpp, publish): fills one on request.
+void redsec_materialize(void* host_array);
+// resident slabs and cached device blocks of a context, released before the context itself (called by the keyset deleters)
+void redsec_pool_release(rs_ctx* ctx);
 void redsec_pack(int32_t* words, const LweSample* s, int32_t n);
 void redsec_unpack(LweSample* s, const int32_t* words, int32_t n);
 

@@ -323,7 +323,7 @@ TFheGateBootstrappingSecretKeySet* new_random_gate_bootstrapping_secret_keyset(c
 
 static void free_cloud_parts(const TFheGateBootstrappingCloudKeySet* c) {
   if (c->bkFFT) {
-    for (int i = 0; i < c->bkFFT->fleet_size; ++i) rs_destroy(c->bkFFT->fleet[i]);
+    for (int i = 0; i < c->bkFFT->fleet_size; ++i) { redsec_pool_release(c->bkFFT->fleet[i]); rs_destroy(c->bkFFT->fleet[i]); }
     free(c->bkFFT->fleet);
     delete c->bkFFT;
   }

@@ -211,8 +211,13 @@ class MnistReluNet:
         ZERO tap at lib/IntFunc.cpp:268,277, classifies 5 % of relu1024x2's bundled images; this one 100 %)."""
         return ((zero == 0) & (sign == 0)).sum(axis=0).astype(np.int64)
 
+    # what the network hands back: logits in the client's own steps (client/decrypt_image.cpp:52-58 decodes with message
+    # space 4096), whatever unit the last layer summed them in -- an exact word-wise multiple (layers.cpp, final_rescale)
+    LOGIT_UNIT = UNIT_4096
+
     def stages(self):
-        """Per hidden layer: (slope_bits, unit_in, unit_out); the scale chain of IntFunc::*::prep."""
+        """Per hidden layer: (slope_bits, unit_in, unit_out), and the unit the final layer SUMS in; the scale chain of
+        IntFunc::*::prep."""
         out = []
         scale, unit = 4.0, UNIT_4096          # input scale 1 x 2x2 sum-pool (lib/IntFunc.cpp:629)
         for _ in self.fc:
@@ -238,13 +243,14 @@ class EncryptedMnistRelu:
         w32 = lambda a: np.asarray(a, np.int64).astype(np.uint64).astype(np.uint32).view(np.int32)
         self.bias0 = t(w32(net.bias0.astype(np.int64) * UNIT_4096))
         self.pool = dict(H=28, Wd=28, C=1, win_h=2, win_w=2, stride_h=2, stride_w=2, off_h=0, off_w=0, Ho=14, Wo=14)
-        stages, self.logit_unit = net.stages()
+        stages, self.sum_unit = net.stages()
+        self.logit_unit = net.LOGIT_UNIT
         self.fc = []
         for (sign, zero, bias, slope), (sb, u_in, u_out) in zip(net.fc, stages):
             lin_bias = w32(QUARTER - net.neg_taps(sign, zero) * u_in)          # quarter-turn shift + the -1 per negative tap
             self.fc.append((t(sign), t(zero), t(lin_bias), t(relu_luts(slope, bias, sb, net.SHIFT_BITS, u_in, u_out))))
         sign, zero, bias = net.final
-        self.final = (t(sign), t(zero), t(w32((bias.astype(np.int64) - net.neg_taps(sign, zero)) * self.logit_unit)))
+        self.final = (t(sign), t(zero), t(w32((bias.astype(np.int64) - net.neg_taps(sign, zero)) * self.sum_unit)))
 
     def run(self, image_ct, taps=None):
         be = self.be
@@ -257,7 +263,9 @@ class EncryptedMnistRelu:
             if taps is not None:
                 taps["pre%d" % (li + 1)], taps["act%d" % (li + 1)] = pre, v
         sign, zero, bias = self.final
-        return be.linear_fc(v, sign, zero, zero_tap_b=0, bias_b=bias)
+        out = be.linear_fc(v, sign, zero, zero_tap_b=0, bias_b=bias)
+        k = self.logit_unit // self.sum_unit
+        return out if k == 1 else be.lincomb(out, k)      # 1/16384 -> 1/4096 steps: the same integers, exactly
 
 
 class EncryptedCifar:

@@ -63,4 +63,5 @@ def run_relu(ctx, net, image_ct, taps=None):
         if taps is not None:
             taps["pre%d" % (li + 1)], taps["act%d" % (li + 1)] = pre, v
     sign, zero, bias = net.final
-    return _wrap(ol.linear_fc(v, sign, zero).astype(np.int64) + words((bias.astype(np.int64) - net.neg_taps(sign, zero)) * logit_unit))
+    out = _wrap(ol.linear_fc(v, sign, zero).astype(np.int64) + words((bias.astype(np.int64) - net.neg_taps(sign, zero)) * logit_unit))
+    return _wrap(out.astype(np.int64) * (net.LOGIT_UNIT // logit_unit))      # handed back in the client's 1/4096 steps (exact multiple)

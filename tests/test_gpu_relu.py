@@ -91,7 +91,8 @@ def test_relu_nets_decrypt_to_the_reference_plaintext_logits(name):
     enc = nets.EncryptedMnistRelu(be, net)
     gold = json.load(open(os.path.join(pm.GOLD, "mnist_%s.json" % name)))["logits"]
     labels, pixels = pm.load_images()
-    stages, unit = net.stages()
+    stages, _ = net.stages()
+    unit = net.LOGIT_UNIT
     agree, corr = 0, []
     for i in range(12):
         ct = torch.from_numpy(sk.encrypt_image(pixels[i], seed=40 + i, preprocess="relu")).cuda()
@@ -151,9 +152,15 @@ def test_unmodified_relu_driver_equals_python_chain(tmp_path, name):
     be.load_keys(sk.bk, sk.ksk)
     chain = nets.EncryptedMnistRelu(be, net).run(torch.from_numpy(ct).cuda()).cpu().numpy()
     assert np.array_equal(driver, chain)
-    _, unit = net.stages()
+    unit = net.LOGIT_UNIT
     dec = sk.decrypt_ints(driver, msize=(1 << 32) // unit)
     plain = pm.relu_forward(net, pixels[i])
     assert int(np.argmax(dec)) == int(np.argmax(plain)) == labels[i]
     assert np.corrcoef(dec, plain)[0, 1] > 0.95
     be.close()
+    # the reference's own, unmodified client/decrypt_image.cpp (message space 4096) reads the same file: the last layer hands
+    # its logits back in 1/4096 steps whatever unit it summed them in, so the tool's class is the plaintext class
+    import re
+    r = rd.run("client_decrypt_image.out", cdir, "MNIST")
+    m = re.search(r"Classification Result: (\d)", r.stdout)
+    assert r.returncode == 0 and m and int(m.group(1)) == labels[i], r.stdout + r.stderr

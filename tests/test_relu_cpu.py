@@ -88,7 +88,7 @@ def test_relu1024x1_on_the_oracle_decrypts_to_the_plaintext_logits():
     taps, ptaps = {}, {}
     out = oracle_net.run_relu(octx, net, ct, taps)
     plain = pm.relu_forward(net, pixels[0], ptaps)
-    _, unit = net.stages()
+    unit = net.LOGIT_UNIT
     dec = sk.decrypt_ints(out, msize=(1 << 32) // unit)
     assert np.abs(sk.decrypt_ints(taps["pre1"]) - 1024 - ptaps["pre1"]).max() <= 16        # fresh noise of 784 pixels, quarter turn removed
     act = sk.decrypt_ints(taps["act1"], msize=16384)
