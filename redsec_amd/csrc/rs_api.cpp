@@ -888,12 +888,6 @@ int rs_copy_dev_to_dev(rs_ctx* dc, void* dst, rs_ctx* sc, const void* src, size_
   else RS_HIP(hipMemcpyPeer(dst, dc->device, src, sc->device, bytes));   // staged through the host where peer access is off
   return RS_OK;
 }
-// balanced contiguous slices, lower ranks first (redsec_amd/sharding.py::shard_range, layers.cpp::shard_range)
-static void slice_of(size_t total, int d, int D, size_t* lo, size_t* hi) {
-  const size_t base = total / (size_t)D, rem = total % (size_t)D;
-  *lo = (size_t)d * base + ((size_t)d < rem ? (size_t)d : rem);
-  *hi = *lo + base + ((size_t)d < rem ? 1 : 0);
-}
 static int exchange_state(rs_ctx* c) {
   RS_HIP(hipSetDevice(c->device));
   if (!c->copy_stream) RS_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
@@ -910,19 +904,17 @@ int rs_allgather_rows(rs_ctx* const* ctxs, int n, int32_t* const* bufs, size_t r
     if (rc) return rc;
     RS_HIP(hipEventRecord(ctxs[d]->ev_slice, nullptr));   // behind the kernels that wrote slice d (default stream of device d)
   }
+  const std::vector<rs::SliceCopy> plan = rs::exchange_schedule(rows, n);   // destination-major: each destination's copies queue on ITS stream
   for (int d = 0; d < n; ++d) {
     rs_ctx* dc = ctxs[d];
     RS_HIP(hipSetDevice(dc->device));
-    for (int k = 1; k < n; ++k) {
-      const int e = (d + k) % n;                          // staggered: at any moment the n destinations pull from n different sources
-      rs_ctx* sc = ctxs[e];
-      size_t lo, hi;
-      slice_of(rows, e, n, &lo, &hi);
-      if (hi == lo) continue;
-      const size_t off = lo * row_words, bytes = (hi - lo) * row_words * sizeof(int32_t);
+    for (const rs::SliceCopy& cp : plan) {
+      if (cp.dst != d) continue;
+      rs_ctx* sc = ctxs[cp.src];
+      const size_t off = cp.lo * row_words, bytes = (cp.hi - cp.lo) * row_words * sizeof(int32_t);
       RS_HIP(hipStreamWaitEvent(dc->copy_stream, sc->ev_slice, 0));
       if (dc->device == sc->device) {
-        RS_HIP(hipMemcpyAsync(bufs[d] + off, bufs[e] + off, bytes, hipMemcpyDeviceToDevice, dc->copy_stream));
+        RS_HIP(hipMemcpyAsync(bufs[d] + off, bufs[cp.src] + off, bytes, hipMemcpyDeviceToDevice, dc->copy_stream));
       } else {
         if (std::find(dc->peers_enabled.begin(), dc->peers_enabled.end(), sc->device) == dc->peers_enabled.end()) {
           int can = 0;
@@ -933,7 +925,7 @@ int rs_allgather_rows(rs_ctx* const* ctxs, int n, int32_t* const* bufs, size_t r
           }
           dc->peers_enabled.push_back(sc->device);       // without peer access hipMemcpyPeerAsync stages through the host: slower, still correct
         }
-        RS_HIP(hipMemcpyPeerAsync(bufs[d] + off, dc->device, bufs[e] + off, sc->device, bytes, dc->copy_stream));
+        RS_HIP(hipMemcpyPeerAsync(bufs[d] + off, dc->device, bufs[cp.src] + off, sc->device, bytes, dc->copy_stream));
       }
     }
     RS_HIP(hipEventRecord(dc->ev_copied, dc->copy_stream));

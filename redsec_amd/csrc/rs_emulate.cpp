@@ -672,6 +672,14 @@ long rs_emu_plane_layout_violations() {
          plane_violations<rs::kLayB, rs::kLayC, 2>() + plane_violations<rs::kLayC, rs::kLayB, 2>();
 }
 double rs_emu_gen_error_bound(int logn, int l, int bgbit) { return rs::gen_error_bound(logn, l, bgbit); }
+// the copy plan of rs_allgather_rows: rows of (dst, src, round, lo, hi); returns the number of copies (out may be null)
+long rs_emu_exchange_schedule(long rows, int n, long* out) {
+  const std::vector<rs::SliceCopy> plan = rs::exchange_schedule((size_t)rows, n);
+  if (out) for (size_t i = 0; i < plan.size(); ++i) {
+    out[5 * i] = plan[i].dst; out[5 * i + 1] = plan[i].src; out[5 * i + 2] = plan[i].round; out[5 * i + 3] = (long)plan[i].lo; out[5 * i + 4] = (long)plan[i].hi;
+  }
+  return (long)plan.size();
+}
 // measured transform errors (see GenEmu::transform_error_ratios) and the analysis' per-transform bounds g_f - 1, g_i - 1
 int rs_emu_gen_transform_errors(int logn, uint64_t seed, int amplitude, double* measured2, double* bounds2) {
   const double u = std::ldexp(1.0, -53), r2 = std::sqrt(2.0);

@@ -28,6 +28,29 @@ inline bool prime_for(int l, int bgbit, PrimeSpec* out) {
   return false;
 }
 
+// ---- slice exchange of a stage sharded over n contexts (rs_allgather_rows) ----
+// Rank d owns the d-th of n balanced contiguous slices of `rows` (sizes differ by at most one, lower ranks first: the split of
+// redsec_amd/sharding.py::shard_range and layers.cpp::shard_range). Every destination pulls every other slice exactly once;
+// in round k (1 <= k < n) destination d pulls from (d + k) mod n, so the n copies of a round have n different sources and n
+// different destinations: no link is asked for two transfers at a time (xGMI is point to point).
+struct SliceCopy { int dst, src, round; size_t lo, hi; };
+inline void slice_range(size_t total, int d, int D, size_t* lo, size_t* hi) {
+  const size_t base = total / (size_t)D, rem = total % (size_t)D;
+  *lo = (size_t)d * base + ((size_t)d < rem ? (size_t)d : rem);
+  *hi = *lo + base + ((size_t)d < rem ? 1 : 0);
+}
+inline std::vector<SliceCopy> exchange_schedule(size_t rows, int n) {
+  std::vector<SliceCopy> out;
+  for (int d = 0; d < n; ++d)
+    for (int k = 1; k < n; ++k) {
+      const int e = (d + k) % n;
+      SliceCopy c{d, e, k, 0, 0};
+      slice_range(rows, e, n, &c.lo, &c.hi);
+      if (c.hi > c.lo) out.push_back(c);
+    }
+  return out;
+}
+
 inline uint64_t mulmod_u64(uint64_t a, uint64_t b, uint64_t p) { return (uint64_t)((u128_t)a * b % p); }
 inline uint64_t powmod_u64(uint64_t b, uint64_t e, uint64_t p) {
   uint64_t r = 1;

@@ -209,6 +209,78 @@ int main() {
     check("IntFunc::Quantize::relu_shift = clamp((slope x + bias) >> 6, 0, 15) in units of 1/16384", ok);
     fclose(f);
   }
+  // ---- two networks in one process: the value unit travels inside each chain's own tDimensions object ----
+  {
+    // net R: IntLayer(E_FC 6 -> 6, RELU shift_bits 4) -> IntLayer(E_FC 6 -> 3, no activation); net S: BinLayer(E_FC 6 -> 4, SIGN).
+    // R's hidden activations are pinned to 0 / 15 (far inside the clamped regions), so its logits are exact integers.
+    const int D = 6, C = 3, MS = 4;
+    std::vector<int> wid((size_t)D * D, 0), w1((size_t)D * C), ws((size_t)D * MS);
+    for (int i = 0; i < D; ++i) wid[(size_t)i * D + i] = 1;
+    for (auto& x : w1) { const unsigned t = rnd() % 3; x = t == 0 ? 0 : (t == 1 ? 1 : -1); }
+    for (auto& x : ws) x = (rnd() & 1) ? 1 : -1;
+    std::vector<int32_t> b0 = {-3000, 4000, -3000, 4000, 4000, -3000}, sl(D, 4), b1 = {5, -7, 11}, bs(MS, 0);
+    std::vector<int> in = {10, 20, -30, 7, -30, 33};
+    auto make_r = [&](FILE* g) { put_ternary(g, wid); put_ints(g, b0); put_ints(g, sl); put_ternary(g, w1); put_ints(g, b1); rewind(g); };
+    FILE* fr = tmpfile(); make_r(fr);
+    FILE* fs = tmpfile(); put_ternary(fs, ws); put_ints(fs, bs); rewind(fs);
+    tNetParams nq = np; nq.quant.shift_bits = 4;
+    IntLayer r0(E_FC, D, E_NO_POOL, E_ACTIVATION_RELU, &nq, g_bk), r1(E_FC, C, E_NO_POOL, E_ACTIVATION_NONE, &np, g_bk);
+    BinLayer s0(E_FC, MS, E_NO_POOL, E_ACTIVATION_SIGN, &np, g_bk);
+    tDimensions dr = dims(1, 1, D), ds = dims(1, 1, D);
+    dr.scale = 4;
+    tDimensions* pr = &dr; tDimensions* ps = &ds;
+    pr = (tDimensions*)r0.prep(fr, pr);           // interleaved on purpose: R0, S0, R1
+    ps = (tDimensions*)s0.prep(fs, ps);
+    pr = (tDimensions*)r1.prep(fr, pr);
+    check("ReLU layer announces 1/16384 steps, the final layer hands back 1/4096, a sign layer 1/4096 (inside tDimensions)",
+          r0.out_dim.redsec_unit == (1 << 18) && r1.out_dim.redsec_unit == (1 << 20) && s0.out_dim.redsec_unit == (1 << 20));
+    auto enc_in = [&](unsigned seed) {
+      tMultiBit* x = new tMultiBit[D];
+      uint32_t s2[] = {seed, seed, seed};
+      tfhe_random_generator_setSeed(s2, 3);
+      for (int i = 0; i < D; ++i) { x[i].size = 1; x[i].ctxt = new_gate_bootstrapping_ciphertext_array(1, params); lweSymEncrypt(&x[i].ctxt[0], in[i] * u, 1.0 / 65536, g_sk->lwe_key); }
+      return x;
+    };
+    auto enc_sbits = [&]() {
+      tBit* x = new_gate_bootstrapping_ciphertext_array(D, params);
+      for (int i = 0; i < D; ++i) lweSymEncrypt(&x[i], (in[i] > 0 ? 1 : -1) * u, 1.0 / 65536, g_sk->lwe_key);
+      return x;
+    };
+    auto run_r = [&](IntLayer& a, IntLayer& b) { return (tFixedPoint*)b.execute((tFixedPoint*)a.execute(enc_in(31))); };
+    tFixedPoint* y1 = run_r(r0, r1);
+    tBit* ys = (tBit*)s0.execute(enc_sbits());    // the other network in between
+    tFixedPoint* y2 = run_r(r0, r1);
+    bool okr = true, same_r = true, oks = true;
+    for (int c = 0; c < C; ++c) {
+      int want = b1[c];
+      for (int k = 0; k < D; ++k) { const int a = b0[k] > 0 ? 15 : 0; const int w = w1[(size_t)k * C + c]; want += w * a - (w < 0 ? 1 : 0); }
+      const int got = dec_int(&y1[c].ctxt[0], 4096);               // the reference's own message space (client/decrypt_image.cpp:52-58)
+      if (got != want) printf("  relu net logit %d: got %d want %d\n", c, got, want);
+      okr = okr && got == want;
+      same_r = same_r && same(&y1[c].ctxt[0], &y2[c].ctxt[0], n);
+    }
+    for (int m = 0; m < MS; ++m) {
+      int pre = 0;
+      for (int k = 0; k < D; ++k) pre += ws[(size_t)k * MS + m] * (in[k] > 0 ? 1 : -1);
+      if (pre != 0) oks = oks && dec_int(&ys[m], 4096) == (pre > 0 ? 1 : -1);
+    }
+    check("ReLU network: logits decrypt exactly with message space 4096", okr);
+    check("  ... identical words when run again after another network ran in between", same_r);
+    check("sign network constructed beside it decrypts to sign(w.x)", oks);
+    // a driver that re-initialises the SAME tDimensions object for a further network starts again at 1/4096
+    FILE* fr2 = tmpfile(); make_r(fr2);
+    IntLayer q0(E_FC, D, E_NO_POOL, E_ACTIVATION_RELU, &nq, g_bk), q1l(E_FC, C, E_NO_POOL, E_ACTIVATION_NONE, &np, g_bk);
+    dr = dims(1, 1, D); dr.scale = 4;
+    dr.redsec_tag = r1.out_dim.redsec_tag; dr.redsec_unit = 1 << 18;   // stale private fields, as a reused stack object would carry
+    pr = &dr;
+    pr = (tDimensions*)q0.prep(fr2, pr);
+    pr = (tDimensions*)q1l.prep(fr2, pr);
+    tFixedPoint* y3 = run_r(q0, q1l);
+    bool same3 = true;
+    for (int c = 0; c < C; ++c) same3 = same3 && same(&y1[c].ctxt[0], &y3[c].ctxt[0], n);
+    check("a re-initialised tDimensions object with stale private fields starts a network at 1/4096 (same words as the first instance)", same3);
+    fclose(fr); fclose(fs); fclose(fr2);
+  }
   printf("failures: %d\n", g_fail);
   return g_fail;
 }

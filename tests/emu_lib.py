@@ -22,6 +22,8 @@ def lib():
         L.rs_emu_gen_error_bound.restype = C.c_double
         L.rs_emu_gen_error_bound.argtypes = [C.c_int, C.c_int, C.c_int]
         L.rs_emu_gen_transform_errors.argtypes = [C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.rs_emu_exchange_schedule.restype = C.c_long
+        L.rs_emu_exchange_schedule.argtypes = [C.c_long, C.c_int, C.POINTER(C.c_long)]
         L.rs_emu_gen_digit_mismatches.restype = C.c_long
         L.rs_emu_gen_digit_mismatches.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_long]
         L.rs_emu_gen_polymul.argtypes = [C.c_int, _i32p, _i32p, _i32p, C.POINTER(C.c_double)]

@@ -113,13 +113,17 @@ def test_unmodified_cifar_binarynet_full_driver(tmp_path):
     assert np.corrcoef(dec, plain[i])[0, 1] > 0.5
 
 
-@pytest.mark.parametrize("family,net,devices", [("mnist", "sign1024x1", "0,0"), ("mnist", "relu1024x1", "0,0,0"), ("cifar", "binarynet_small", "0,0")])
-def test_driver_sharded_over_several_contexts_equals_single_device(tmp_path, monkeypatch, family, net, devices):
+@pytest.mark.parametrize("family,net,devices,lazy", [("mnist", "sign1024x1", "0,0", False), ("mnist", "relu1024x1", "0,0,0", False),
+                                                     ("mnist", "sign1024x1", "0,0,0,0", True), ("cifar", "binarynet_small", "0,0", False),
+                                                     ("cifar", "binarynet_small", "0,0,0,0", True)])
+def test_driver_sharded_over_several_contexts_equals_single_device(tmp_path, monkeypatch, family, net, devices, lazy):
     """Gate-parallel evaluation of ONE image inside the C++ layer mirror (the reference's shape: enc_segs[NUM_GPUS], one host
     thread per GPU, lib/GPU/BinFunc_gpu.cu:119-137): REDSEC_DEVICES lists the devices, every bootstrapped stage is split
     contiguously across one context per entry and the slices are exchanged device to device before the next linear stage.
     On a one-GPU box the same device is listed several times -- several contexts, the same code path, ragged slices with
-    three -- and the unmodified driver's network_output.ctxt must equal the single-device run BYTE FOR BYTE."""
+    three -- and the unmodified driver's network_output.ctxt must equal the single-device run BYTE FOR BYTE. The exchange is
+    rs_allgather_rows: one host thread per context, event-ordered asynchronous copies, no device-wide waits. `lazy` adds
+    REDSEC_LAZY_HOST=1 to the sharded run: intermediate host arrays stay unfilled, only the logits come down."""
     import shutil
     from redsec_amd import client
     exe = "%s_%s_enc.out" % (family, net)
@@ -147,6 +151,8 @@ def test_driver_sharded_over_several_contexts_equals_single_device(tmp_path, mon
             monkeypatch.delenv("REDSEC_DEVICES", raising=False)
         else:
             monkeypatch.setenv("REDSEC_DEVICES", dev)
+            if lazy:
+                monkeypatch.setenv("REDSEC_LAZY_HOST", "1")
         r = rd.run(exe, netdir)
         assert r.returncode == 0 and "Result ctxts loaded" in r.stdout, r.stdout + r.stderr
         outs.append(open(os.path.join(cdir, "network_output.ctxt"), "rb").read())

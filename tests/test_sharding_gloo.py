@@ -22,6 +22,29 @@ def test_shard_range_is_a_balanced_partition():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_device_to_device_exchange_schedule():
+    """The copy plan of rs_allgather_rows (csrc/rs_host.h::exchange_schedule, the C++ mirror's multi-device slice exchange): every
+    destination pulls every other rank's slice exactly once, the slices are sharding.shard_range's, and the n copies of a
+    round have n different sources and n different destinations (xGMI is point to point: no link carries two at a time)."""
+    import ctypes as C
+    import emu_lib
+    L = emu_lib.lib()
+    for rows in (0, 1, 5, 10, 196, 1024, 131072, 131075):
+        for n in (1, 2, 3, 4, 8):
+            cnt = L.rs_emu_exchange_schedule(rows, n, None)
+            buf = (C.c_long * (5 * max(cnt, 1)))()
+            assert L.rs_emu_exchange_schedule(rows, n, buf) == cnt
+            plan = [tuple(buf[5 * i:5 * i + 5]) for i in range(cnt)]
+            spans = [sharding.shard_range(rows, r, n) for r in range(n)]
+            want = {(d, e) for d in range(n) for e in range(n) if d != e and spans[e][1] > spans[e][0]}
+            assert {(d, e) for d, e, _, _, _ in plan} == want and len(plan) == len(want)
+            for d, e, k, lo, hi in plan:
+                assert (lo, hi) == spans[e] and 1 <= k < n and e == (d + k) % n
+            for k in range(1, n):
+                rnd = [(d, e) for d, e, kk, _, _ in plan if kk == k]
+                assert len({d for d, _ in rnd}) == len(rnd) == len({e for _, e in rnd})
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
