@@ -394,19 +394,20 @@ constexpr int32_t kUnitRelu = 1 << 18;   // ReLU outputs: 1/16384, so that 1,024
 constexpr int32_t kQuarter = 1 << 30;
 constexpr int kSlopeBitsInt = 8;         // lib/IntFunc.cpp:45
 
-// The unit in which a network's values travel rides INSIDE the tDimensions object the driver threads through every prep()
-// (nets/*/*/net.cpp: p_dim = layerK->prep(f, p_dim)): two private trailing fields of the mirror's struct (lib/Layer.h here;
-// drivers are compiled against it and never touch them). redsec_unit is believed only while redsec_tag equals the
-// fingerprint of the public fields as the previous layer left them: a driver's fresh (uninitialised) object, or one it
-// re-initialises for another network, fails the check and starts at 1/4096. No process-wide table: any number of networks.
-uint32_t dims_tag(const tDimensions* d) {
-  uint32_t h = 2166136261u;
-  auto mix = [&](uint32_t v) { h ^= v; h *= 16777619u; };
-  uint32_t fbits;
-  memcpy(&fbits, &d->scale, sizeof fbits);
-  mix((uint16_t)d->hw.h); mix((uint16_t)d->hw.w); mix(d->in_dep); mix(d->in_bits); mix(d->out_bits); mix(d->filter_bits); mix(d->bias_bits);
-  mix(d->up_bound); mix(fbits);
-  return h ^ 0x52454453u;   // "REDS"
+// The unit in which a layer's INPUT values travel (1/4096 for client pixels and sign bits, 1/16384 behind a ReLU) is a function
+// of what produced them, and the tDimensions object the driver threads through every prep() (nets/*/*/net.cpp: p_dim =
+// layerK->prep(f, p_dim)) already says what that was, in the reference's own bookkeeping: Quantize::prep leaves
+//   (in_bits, up_bound, scale) = (1, 1, 0.5 | 1)              behind a sign            (lib/BinFunc.cpp:1000-1010, lib/IntFunc.cpp:823-831)
+//                                (s, 2^(s-1), 2^s - 1)         behind an integer ReLU   (lib/IntFunc.cpp:835-844), s = shift_bits >= 2
+//                                (s + 1, 2^s, 2^s)             behind a binary ReLU     (lib/BinFunc.cpp:1019-1030)
+// and every driver starts its chain with scale = 1. The unit is therefore READ OFF the object at the start of each prep:
+// no table beside the chain, nothing keyed by an address, any number of networks in a process, and the struct keeps the
+// reference's layout (the drivers are compiled against the reference's own lib/Layer.h).
+int32_t unit_of(const tDimensions* d) {
+  const int b = d->in_bits;
+  if (b >= 2 && b <= 8 && d->up_bound == (1u << (b - 1)) && d->scale == (float)((1 << b) - 1)) return kUnitRelu;           // integer ReLU
+  if (b >= 3 && b <= 9 && d->up_bound == (1u << (b - 1)) && d->scale == (float)d->up_bound) return kUnitRelu;              // binary ReLU
+  return kUnit4096;
 }
 
 struct LayerImpl {
@@ -496,7 +497,7 @@ tDimensions* prep_impl(LayerImpl* L, FILE* fd, tDimensions* dim, tDimensions* in
   assert(!L->prepared && dim != NULL);
   *in_dim = *dim;
   L->in_count = dim->hw.h * dim->hw.w * (int)dim->in_dep;
-  L->unit_in = (dim->redsec_tag == dims_tag(dim) && (dim->redsec_unit == kUnit4096 || dim->redsec_unit == kUnitRelu)) ? dim->redsec_unit : kUnit4096;
+  L->unit_in = unit_of(dim);
   if (L->e_conv != E_NO_CONV) {
     if (L->e_conv == E_FC || L->e_conv == E_FC_FINAL) { dim->in_dep *= dim->hw.h * dim->hw.w; dim->hw.h = 1; dim->hw.w = 1; }   // flatten
     const tConvParams& c = L->np.conv;
@@ -615,8 +616,6 @@ tDimensions* prep_impl(LayerImpl* L, FILE* fd, tDimensions* dim, tDimensions* in
   // a final layer (no activation) hands its logits back in 1/4096 steps whatever unit they were summed in, because that is
   // what the reference's client decodes with (client/decrypt_image.cpp:52-58, message space 4096): see run_layer
   L->final_rescale = (L->e_act == E_ACTIVATION_NONE && L->unit_out != kUnit4096 && !getenv("REDSEC_KEEP_UNIT")) ? kUnit4096 / L->unit_out : 1;
-  dim->redsec_unit = L->final_rescale != 1 ? kUnit4096 : L->unit_out;
-  dim->redsec_tag = dims_tag(dim);
   *out_dim = *dim;
   L->prepared = true;
   return dim;

@@ -34,11 +34,7 @@ typedef struct _DIMS {
   uint8_t in_bits, out_bits, filter_bits, bias_bits;
   uint32_t up_bound;
   float scale;
-  /* mirror-private, behind the reference's fields (lib/Layer.h:31-45): the torus unit of one integer step of the values this
-   * object describes, believed only while redsec_tag matches the fields above (layers.cpp, dims_tag). Drivers never touch them. */
-  uint32_t redsec_tag;
-  int32_t redsec_unit;
-} tDimensions;
+} tDimensions;   /* layout as lib/Layer.h:31-45: the reference's drivers are compiled against THEIR header */
 
 typedef struct _CONV_PARAMS { tRectangle window; bool same_pad; float tern_thresh; tRectangle stride; } tConvParams;
 typedef struct _BNORM_PARAMS { bool use_scale; float eps; } tBNormParams;

@@ -218,7 +218,7 @@ int main() {
     for (int i = 0; i < D; ++i) wid[(size_t)i * D + i] = 1;
     for (auto& x : w1) { const unsigned t = rnd() % 3; x = t == 0 ? 0 : (t == 1 ? 1 : -1); }
     for (auto& x : ws) x = (rnd() & 1) ? 1 : -1;
-    std::vector<int32_t> b0 = {-3000, 4000, -3000, 4000, 4000, -3000}, sl(D, 4), b1 = {5, -7, 11}, bs(MS, 0);
+    std::vector<int32_t> b0 = {-3000, 4000, -3000, 4000, 4000, -3000}, sl(D, 4), b1 = {5, -7, 11}, bs = {40, -40, 40, -40};   // sign net: margins far above the mod-switch noise
     std::vector<int> in = {10, 20, -30, 7, -30, 33};
     auto make_r = [&](FILE* g) { put_ternary(g, wid); put_ints(g, b0); put_ints(g, sl); put_ternary(g, w1); put_ints(g, b1); rewind(g); };
     FILE* fr = tmpfile(); make_r(fr);
@@ -232,8 +232,8 @@ int main() {
     pr = (tDimensions*)r0.prep(fr, pr);           // interleaved on purpose: R0, S0, R1
     ps = (tDimensions*)s0.prep(fs, ps);
     pr = (tDimensions*)r1.prep(fr, pr);
-    check("ReLU layer announces 1/16384 steps, the final layer hands back 1/4096, a sign layer 1/4096 (inside tDimensions)",
-          r0.out_dim.redsec_unit == (1 << 18) && r1.out_dim.redsec_unit == (1 << 20) && s0.out_dim.redsec_unit == (1 << 20));
+    check("the dims object keeps the reference's bookkeeping: (4, 8, 15) behind the integer ReLU, (1, 1, .) behind the sign",
+          r0.out_dim.in_bits == 4 && r0.out_dim.up_bound == 8 && r0.out_dim.scale == 15.0f && s0.out_dim.in_bits == 1 && s0.out_dim.up_bound == 1);
     auto enc_in = [&](unsigned seed) {
       tMultiBit* x = new tMultiBit[D];
       uint32_t s2[] = {seed, seed, seed};
@@ -260,9 +260,9 @@ int main() {
       same_r = same_r && same(&y1[c].ctxt[0], &y2[c].ctxt[0], n);
     }
     for (int m = 0; m < MS; ++m) {
-      int pre = 0;
+      int pre = bs[m];
       for (int k = 0; k < D; ++k) pre += ws[(size_t)k * MS + m] * (in[k] > 0 ? 1 : -1);
-      if (pre != 0) oks = oks && dec_int(&ys[m], 4096) == (pre > 0 ? 1 : -1);
+      oks = oks && dec_int(&ys[m], 4096) == (pre > 0 ? 1 : -1);
     }
     check("ReLU network: logits decrypt exactly with message space 4096", okr);
     check("  ... identical words when run again after another network ran in between", same_r);
@@ -270,15 +270,14 @@ int main() {
     // a driver that re-initialises the SAME tDimensions object for a further network starts again at 1/4096
     FILE* fr2 = tmpfile(); make_r(fr2);
     IntLayer q0(E_FC, D, E_NO_POOL, E_ACTIVATION_RELU, &nq, g_bk), q1l(E_FC, C, E_NO_POOL, E_ACTIVATION_NONE, &np, g_bk);
-    dr = dims(1, 1, D); dr.scale = 4;
-    dr.redsec_tag = r1.out_dim.redsec_tag; dr.redsec_unit = 1 << 18;   // stale private fields, as a reused stack object would carry
+    dr = dims(1, 1, D); dr.scale = 4;                                   // the same object, re-initialised as a driver's init() would
     pr = &dr;
     pr = (tDimensions*)q0.prep(fr2, pr);
     pr = (tDimensions*)q1l.prep(fr2, pr);
     tFixedPoint* y3 = run_r(q0, q1l);
     bool same3 = true;
     for (int c = 0; c < C; ++c) same3 = same3 && same(&y1[c].ctxt[0], &y3[c].ctxt[0], n);
-    check("a re-initialised tDimensions object with stale private fields starts a network at 1/4096 (same words as the first instance)", same3);
+    check("a re-initialised tDimensions object starts a further network at 1/4096 (same words as the first instance)", same3);
     fclose(fr); fclose(fs); fclose(fr2);
   }
   printf("failures: %d\n", g_fail);
