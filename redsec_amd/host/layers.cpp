@@ -394,20 +394,20 @@ constexpr int32_t kUnitRelu = 1 << 18;   // ReLU outputs: 1/16384, so that 1,024
 constexpr int32_t kQuarter = 1 << 30;
 constexpr int kSlopeBitsInt = 8;         // lib/IntFunc.cpp:45
 
-// The unit in which a layer's INPUT values travel (1/4096 for client pixels and sign bits, 1/16384 behind a ReLU) is a function
-// of what produced them, and the tDimensions object the driver threads through every prep() (nets/*/*/net.cpp: p_dim =
-// layerK->prep(f, p_dim)) already says what that was, in the reference's own bookkeeping: Quantize::prep leaves
-//   (in_bits, up_bound, scale) = (1, 1, 0.5 | 1)              behind a sign            (lib/BinFunc.cpp:1000-1010, lib/IntFunc.cpp:823-831)
-//                                (s, 2^(s-1), 2^s - 1)         behind an integer ReLU   (lib/IntFunc.cpp:835-844), s = shift_bits >= 2
-//                                (s + 1, 2^s, 2^s)             behind a binary ReLU     (lib/BinFunc.cpp:1019-1030)
-// and every driver starts its chain with scale = 1. The unit is therefore READ OFF the object at the start of each prep:
-// no table beside the chain, nothing keyed by an address, any number of networks in a process, and the struct keeps the
-// reference's layout (the drivers are compiled against the reference's own lib/Layer.h).
+// The unit in which values travel (1/4096 for client pixels and sign bits, 1/16384 behind a ReLU) is a property of the data,
+// so it rides in the object that describes the data: the tDimensions the driver threads through every prep() (nets/*/*/net.cpp:
+// p_dim = layerK->prep(f, p_dim)). Its layout is the reference's (the drivers are compiled against the reference's own
+// lib/Layer.h), so the unit is carried by a MARK on the `scale` field: Quantize::prep's ReLU branch stores the reference's
+// value (2^s - 1 or 2^s, lib/IntFunc.cpp:835-844, lib/BinFunc.cpp:1019-1030) lowered by one part in 2^20. Every other
+// value the chain ever holds there is an integer or a multiple of 1/2 (drivers start at 1, a sign stores 1/2 or 1, pools
+// multiply by their window area), so "just below an integer" can only mean "behind a ReLU"; the mark survives the pools'
+// multiplications, as a unit must, a sign overwrites it, and no consumer of `scale` changes its result (the only one is the
+// ReLU's own ceil(log2(scale)), which a 2^-20 decrease cannot move). No table beside the chain, nothing keyed by an address:
+// any number of networks in a process, stage-wise (BinFunc::* / IntFunc::*) or layer-wise.
+float mark_relu_scale(float v) { return v * (1.0f - 9.5367431640625e-7f); }
 int32_t unit_of(const tDimensions* d) {
-  const int b = d->in_bits;
-  if (b >= 2 && b <= 8 && d->up_bound == (1u << (b - 1)) && d->scale == (float)((1 << b) - 1)) return kUnitRelu;           // integer ReLU
-  if (b >= 3 && b <= 9 && d->up_bound == (1u << (b - 1)) && d->scale == (float)d->up_bound) return kUnitRelu;              // binary ReLU
-  return kUnit4096;
+  const float r = nearbyintf(d->scale), gap = r - d->scale;
+  return (gap > 0.0f && gap <= d->scale * 3.8e-6f) ? kUnitRelu : kUnit4096;
 }
 
 struct LayerImpl {
@@ -577,13 +577,13 @@ tDimensions* prep_impl(LayerImpl* L, FILE* fd, tDimensions* dim, tDimensions* in
       while ((float)(1 << sc_b) < dim->scale) ++sc_b;
       L->relu_shift = kSlopeBitsInt + sc_b - L->shift_bits;
       dim->in_bits = (uint8_t)L->shift_bits;             // :835-844
-      dim->scale = (float)((1 << L->shift_bits) - 1);
+      dim->scale = mark_relu_scale((float)((1 << L->shift_bits) - 1));
       dim->up_bound = 1u << (L->shift_bits - 1);
     } else {
       L->relu_shift = L->shift_bits + 1;                  // BinFunc::Quantize::relu_shift shifts by shift_bits + 1 (lib/BinFunc.cpp:1154)
       dim->in_bits = (uint8_t)(L->shift_bits + 1);        // lib/BinFunc.cpp:1019-1030
       dim->up_bound = 1u << L->shift_bits;
-      dim->scale = (float)dim->up_bound;
+      dim->scale = mark_relu_scale((float)dim->up_bound);
     }
     if (L->relu_shift < 0 || L->relu_shift > 40) { fprintf(stderr, "redsec layers: ReLU shift %d out of range\n", L->relu_shift); abort(); }
     L->unit_out = kUnitRelu;

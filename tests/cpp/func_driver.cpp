@@ -232,8 +232,9 @@ int main() {
     pr = (tDimensions*)r0.prep(fr, pr);           // interleaved on purpose: R0, S0, R1
     ps = (tDimensions*)s0.prep(fs, ps);
     pr = (tDimensions*)r1.prep(fr, pr);
-    check("the dims object keeps the reference's bookkeeping: (4, 8, 15) behind the integer ReLU, (1, 1, .) behind the sign",
-          r0.out_dim.in_bits == 4 && r0.out_dim.up_bound == 8 && r0.out_dim.scale == 15.0f && s0.out_dim.in_bits == 1 && s0.out_dim.up_bound == 1);
+    check("the dims object keeps the reference's bookkeeping: (4, 8, 15 marked) behind the integer ReLU, (1, 1, 1/2) behind the sign",
+          r0.out_dim.in_bits == 4 && r0.out_dim.up_bound == 8 && r0.out_dim.scale < 15.0f && r0.out_dim.scale > 14.9999f &&
+          s0.out_dim.in_bits == 1 && s0.out_dim.up_bound == 1 && s0.out_dim.scale == 0.5f);
     auto enc_in = [&](unsigned seed) {
       tMultiBit* x = new tMultiBit[D];
       uint32_t s2[] = {seed, seed, seed};
