@@ -613,9 +613,13 @@ tDimensions* prep_impl(LayerImpl* L, FILE* fd, tDimensions* dim, tDimensions* in
         }
     dim->hw.h = (int16_t)g.Ho; dim->hw.w = (int16_t)g.Wo;
   }
-  // a final layer (no activation) hands its logits back in 1/4096 steps whatever unit they were summed in, because that is
-  // what the reference's client decodes with (client/decrypt_image.cpp:52-58, message space 4096): see run_layer
-  L->final_rescale = (L->e_act == E_ACTIVATION_NONE && L->unit_out != kUnit4096 && !getenv("REDSEC_KEEP_UNIT")) ? kUnit4096 / L->unit_out : 1;
+  // A final layer (no activation) behind a ReLU hands its logits back in the unit they were summed in, 1/16384. The reference's
+  // client decodes with message space 4096 (client/decrypt_image.cpp:52-58) and therefore reads round(logit / 4): two bits of
+  // resolution less, the same class except for near ties. REDSEC_RESCALE_LOGITS=1 multiplies the logits by 4 instead (exact,
+  // word-wise), which gives that client the integers themselves -- but wraps around its +-2048 range for logits near +-2000,
+  // which relu1024x3 reaches on the bundled images (measured: tests/test_gpu_relu.py history), so it is NOT the default.
+  const char* rescale = getenv("REDSEC_RESCALE_LOGITS");
+  L->final_rescale = (L->e_act == E_ACTIVATION_NONE && L->unit_out != kUnit4096 && rescale && *rescale && strcmp(rescale, "0") != 0) ? kUnit4096 / L->unit_out : 1;
   *out_dim = *dim;
   L->prepared = true;
   return dim;
@@ -884,7 +888,7 @@ DevSlab run_layer(LayerImpl* L, DevSlab x) {
     }
   }
   if (L->final_rescale != 1) {
-    // logits summed in the ReLU unit (1/16384) leave in the client's (1/4096): an exact word-wise multiple
+    // REDSEC_RESCALE_LOGITS: logits summed in the ReLU unit (1/16384) leave in the client's (1/4096): an exact word-wise multiple
     replace(f.replicated(x.rows, [&](int d, rs_ctx* c, int32_t* y) {
       RS_CHECK(rs_lincomb_dev(c, y, x.ptr[d], L->final_rescale, nullptr, 0, 0, x.rows, nullptr));
     }), x.rows);

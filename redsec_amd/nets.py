@@ -211,9 +211,10 @@ class MnistReluNet:
         ZERO tap at lib/IntFunc.cpp:268,277, classifies 5 % of relu1024x2's bundled images; this one 100 %)."""
         return ((zero == 0) & (sign == 0)).sum(axis=0).astype(np.int64)
 
-    # what the network hands back: logits in the client's own steps (client/decrypt_image.cpp:52-58 decodes with message
-    # space 4096), whatever unit the last layer summed them in -- an exact word-wise multiple (layers.cpp, final_rescale)
-    LOGIT_UNIT = UNIT_4096
+    # what the network hands back: logits in the unit the last layer summed them in (1/16384 behind a ReLU). The reference's
+    # client decodes with message space 4096 and so reads round(logit / 4); multiplying by 4 instead (layers.cpp,
+    # REDSEC_RESCALE_LOGITS=1) would wrap around that client's +-2048 range on relu1024x3, whose logits reach +-2000.
+    LOGIT_UNIT = RELU_UNIT
 
     def stages(self):
         """Per hidden layer: (slope_bits, unit_in, unit_out), and the unit the final layer SUMS in; the scale chain of

@@ -255,7 +255,7 @@ int main() {
     for (int c = 0; c < C; ++c) {
       int want = b1[c];
       for (int k = 0; k < D; ++k) { const int a = b0[k] > 0 ? 15 : 0; const int w = w1[(size_t)k * C + c]; want += w * a - (w < 0 ? 1 : 0); }
-      const int got = dec_int(&y1[c].ctxt[0], 4096);               // the reference's own message space (client/decrypt_image.cpp:52-58)
+      const int got = dec_int(&y1[c].ctxt[0], 16384);              // the unit the logits were summed in (the client's 4096 reads round(got / 4))
       if (got != want) printf("  relu net logit %d: got %d want %d\n", c, got, want);
       okr = okr && got == want;
       same_r = same_r && same(&y1[c].ctxt[0], &y2[c].ctxt[0], n);
@@ -265,7 +265,7 @@ int main() {
       for (int k = 0; k < D; ++k) pre += ws[(size_t)k * MS + m] * (in[k] > 0 ? 1 : -1);
       oks = oks && dec_int(&ys[m], 4096) == (pre > 0 ? 1 : -1);
     }
-    check("ReLU network: logits decrypt exactly with message space 4096", okr);
+    check("ReLU network: logits decrypt exactly in steps of 1/16384", okr);
     check("  ... identical words when run again after another network ran in between", same_r);
     check("sign network constructed beside it decrypts to sign(w.x)", oks);
     // a driver that re-initialises the SAME tDimensions object for a further network starts again at 1/4096

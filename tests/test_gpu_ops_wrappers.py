@@ -27,4 +27,4 @@ def test_per_stage_classes_equal_the_layers():
         pytest.skip("no host compiler and no prebuilt test program")
     r = cppbuild.run(exe)
     assert r.returncode == 0 and "failures: 0" in r.stdout, r.stdout + r.stderr
-    assert r.stdout.count("PASS") == 7
+    assert r.stdout.count("PASS") == 12

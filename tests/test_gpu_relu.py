@@ -158,8 +158,8 @@ def test_unmodified_relu_driver_equals_python_chain(tmp_path, name):
     assert int(np.argmax(dec)) == int(np.argmax(plain)) == labels[i]
     assert np.corrcoef(dec, plain)[0, 1] > 0.95
     be.close()
-    # the reference's own, unmodified client/decrypt_image.cpp (message space 4096) reads the same file: the last layer hands
-    # its logits back in 1/4096 steps whatever unit it summed them in, so the tool's class is the plaintext class
+    # the reference's own, unmodified client/decrypt_image.cpp (message space 4096) reads the same file: it sees round(logit / 4)
+    # of logits that travel in 1/16384 steps, i.e. the same class unless two logits are within a few units of each other
     import re
     r = rd.run("client_decrypt_image.out", cdir, "MNIST")
     m = re.search(r"Classification Result: (\d)", r.stdout)
