@@ -58,6 +58,15 @@ def load_library(path=None):
         return _lib
     path = path or os.environ.get("REDSEC_HIP_LIB")   # timing experiments may point at a variant build
     so = path or _build.build_hip()
+    # torch's HIP runtime must be initialised BEFORE this library's code object registers with its own copy of the runtime in the
+    # same process: the other order leaves one of the two without devices ("No HIP GPUs are available" / RS_ERR_NO_DEVICE;
+    # measured on the MI355X boxes, ROCm 7.2 + torch 2.10). Loading is the first thing every user of the package does.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     if not os.path.exists(so):
         raise RedsecHipError("libredsec_hip.so is missing: run `python -m redsec_amd.build`")
     try:
