@@ -115,11 +115,11 @@ def test_toy_all_gates_and_mux(which, fix, request):
 
 def test_batched_ripple_carry_adder(be_full_default, full_default):
     """BinOps::add (lib/BinOps_enc.cpp:55-119: per bit 2 XOR + 2 AND + 1 OR, the full-adder popcount
-    pattern) with every gate level run as ONE batch over all the additions: 96 independent 4-bit sums,
+    pattern) with every gate level run as ONE batch over all the additions: 32 independent 4-bit sums,
     each gate batch equal to the oracle's word for word, the decrypted sums equal to a + b mod 16."""
     be = be_full_default
     ks, ctx = full_default
-    B, bits = 96, 4
+    B, bits = 32, 4
     rng = np.random.default_rng(99)
     xa, xb = rng.integers(0, 16, B), rng.integers(0, 16, B)
     e8 = ol.to_torus(1, 8)
