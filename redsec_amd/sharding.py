@@ -18,11 +18,12 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def all_gather_rows(local, total, group=None):
+def all_gather_rows(local, total, group=None, force=False):
     """Concatenate per-rank row slices (made with shard_range) into the full [total][...] tensor on
-    every rank. Ragged slices are padded to the largest one for the collective."""
+    every rank. Ragged slices are padded to the largest one for the collective. A single rank returns its slice as it
+    is unless `force` asks for the collective anyway (tests: the RCCL path on a one-GPU box)."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return local
     sizes = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
     width = max(sizes)

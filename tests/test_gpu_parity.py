@@ -1,5 +1,6 @@
 """GPU parity: HIP path (through the C ABI) vs the CPU oracle, bit-exact, on identical keys and
 identical seeded inputs. Integer work => the bar is equality of every ciphertext word."""
+import os
 import numpy as np
 import pytest
 
@@ -493,3 +494,16 @@ def test_last_partial_round_runs_in_its_own_form(which, fix, request):
         assert np.array_equal(got.cpu().numpy()[sample], ctx.bootstrap_batch(ct[sample], mu)), tail
     _BACKENDS.remove(be2)
     be2.close()
+
+
+def test_rccl_gather_world_size_one():
+    """backend="nccl" (= RCCL) has to have run once before a multi-GPU scaling run depends on it: one rank on this box, in a
+    clean child process (tests/rccl_world1.py), drives OverlappedGather.launch/wait (async_op on RCCL's stream) and
+    all_gather_rows on device tensors around real gate steps; the gathered blocks equal the oracle word for word."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_world1.py")], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl world-1 ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
