@@ -84,6 +84,11 @@ int rs_destroy(rs_ctx* ctx);
  *   ksk int32[k*N][t][1<<basebit][n+1]   bk->ks->ks[i][j][v] as (a[0..n-1], b)
  * Transforms bk to the transform domain on the device (the bkFFT analogue). */
 int rs_load_keys(rs_ctx* ctx, const int32_t* bk, const int32_t* ksk);
+/* The same with a SYNTHETIC key generated on the device: bk word k = high half of splitmix64(seed + k) (csrc/rs_ntt.h,
+ * synthetic_key_word; redsec_amd/client.py restates it in numpy), ksk word k likewise from seed ^ 0x6b73. Not an encryption of
+ * anything: for benchmarks and parity tests of the large rings, whose real keys are gigabytes on the host (redsec_params_large:
+ * 2.4 GB of bk + 7.2 GB of ksk) -- every kernel does exactly the work it does on a real key, and the oracle is fed the same words. */
+int rs_load_synthetic_keys(rs_ctx* ctx, uint64_t seed);
 
 /* Arithmetic of the external product (both keys are resident after rs_load_keys; switching is free):
  *   RS_MODE_FFT        folded 512-point complex FP64 FFT -- the arithmetic class of TFHE's own

@@ -306,6 +306,21 @@ size_t ro_ksk_words(const ro_params* p) {
   return (size_t)(p->k * p->N) * (size_t)p->ks_t * ((size_t)1 << p->ks_basebit) * (size_t)(p->n + 1);
 }
 
+/* Words [first, first + count) of the SYNTHETIC key the product generates on the device for size tests of the large rings
+ * (include/redsec_hip.h, rs_load_synthetic_keys): word k = high half of splitmix64(seed + k), restated here so that the
+ * oracle is fed the same key words without a multi-gigabyte array crossing from the test into the product. Not a TFHE
+ * routine: a test generator (SplitMix64: Steele, Lea & Flood 2014, the published constants). */
+void ro_synthetic_key_words(uint64_t seed, uint64_t first, uint64_t count, int32_t* out) {
+#pragma omp parallel for schedule(static)
+  for (long long i = 0; i < (long long)count; ++i) {
+    uint64_t z = seed + (first + (uint64_t)i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    out[i] = (int32_t)(uint32_t)(z >> 32);
+  }
+}
+
 /* b += s * a (negacyclic), s binary: torusPolynomialAddMulR with an IntPolynomial key. */
 static void addmul_binary_key(int32_t* b, const int32_t* s, const int32_t* a, int32_t N) {
   for (int32_t i = 0; i < N; ++i) {
@@ -594,6 +609,32 @@ static void cmux_step(const ro_ctx* c, int32_t* acc, int32_t i, int32_t barai, i
   uint64_t* fd = scratch_u64;                         /* [N] one digit transform */
   uint64_t* facc = scratch_u64 + N;                   /* [k+1][N] */
   memset(facc, 0, sizeof(uint64_t) * (size_t)(k + 1) * N);
+#ifdef _OPENMP
+  if (N >= 4096 && !omp_in_parallel() && omp_get_max_threads() > 1) {
+    /* A single ciphertext on a large ring (the full-size parity tests): the kpl row products of a step are independent, so
+     * they go to kpl threads and are summed afterwards -- the same exact values in the same field, any order. */
+    uint64_t* rowprod = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)kpl * (size_t)(k + 2) * N);
+#pragma omp parallel for schedule(static)
+    for (int32_t row = 0; row < kpl; ++row) {
+      uint64_t* f = rowprod + (size_t)row * (size_t)(k + 2) * N;
+      const int32_t* d = digits + (size_t)row * N;
+      for (int32_t j = 0; j < N; ++j) f[j] = gl_from_i64(d[j]);
+      gl_ntt_forward(f, c->tb);
+      for (int32_t col = 0; col <= k; ++col) {
+        const uint64_t* bkp = c->bk_ntt + ((((size_t)i * kpl + row) * (size_t)(k + 1)) + col) * (size_t)N;
+        uint64_t* dst = f + (size_t)(col + 1) * N;
+        for (int32_t j = 0; j < N; ++j) dst[j] = gl_mul(f[j], bkp[j]);
+      }
+    }
+    for (int32_t row = 0; row < kpl; ++row)
+      for (int32_t col = 0; col <= k; ++col) {
+        const uint64_t* src = rowprod + (size_t)row * (size_t)(k + 2) * N + (size_t)(col + 1) * N;
+        uint64_t* dst = facc + (size_t)col * N;
+        for (int32_t j = 0; j < N; ++j) dst[j] = gl_add(dst[j], src[j]);
+      }
+    free(rowprod);
+  } else
+#endif
   for (int32_t row = 0; row < kpl; ++row) {
     const int32_t* d = digits + (size_t)row * N;
     for (int32_t j = 0; j < N; ++j) fd[j] = gl_from_i64(d[j]);

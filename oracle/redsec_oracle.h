@@ -81,6 +81,7 @@ int32_t ro_gaussian32(ro_rng* r, int32_t message, double sigma);
  */
 size_t ro_bk_words(const ro_params* p);
 size_t ro_ksk_words(const ro_params* p);
+void ro_synthetic_key_words(uint64_t seed, uint64_t first, uint64_t count, int32_t* out);   /* test generator, see the .c file */
 void ro_keygen(const ro_params* p, uint64_t seed, int32_t* lwe_key, int32_t* tlwe_key, int32_t* bk, int32_t* ksk);
 
 /* ---- LWE sample ops (lweSymEncrypt / lwePhase / lweSymDecrypt / lweNoiselessTrivial) ---- */

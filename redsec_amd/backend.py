@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "rs_set_timing", "rs_last_kernel_ms", "rs_info", "rs_set_mode", "rs_get_mode", "rs_rounding_certificate", "rs_fft_fallbacks",
     "rs_bootstrap_lut_dev", "rs_set_certificate_limit", "rs_certify", "rs_reserve_stream", "rs_last_kernel_ms_stream", "rs_last_launch", "rs_copy_dev_to_dev",
     "rs_params_redsec_small", "rs_params_redsec_medium", "rs_params_redsec_large", "rs_split_bound",
-    "rs_allgather_rows", "rs_release_stream",
+    "rs_allgather_rows", "rs_release_stream", "rs_load_synthetic_keys",
 ]
 
 GATES = {"NAND": 0, "OR": 1, "AND": 2, "NOR": 3, "XOR": 4, "XNOR": 5, "ANDNY": 6, "ANDYN": 7, "ORNY": 8, "ORYN": 9}
@@ -86,6 +86,7 @@ def load_library(path=None):
     L.rs_create.argtypes = [C.POINTER(vp), P, C.c_int]
     L.rs_destroy.argtypes = [vp]
     L.rs_load_keys.argtypes = [vp, _i32p, _i32p]
+    L.rs_load_synthetic_keys.argtypes = [vp, C.c_uint64]
     L.rs_reserve.argtypes = [vp, C.c_size_t]
     L.rs_bootstrap_dev.argtypes = [vp, vp, vp, C.c_int32, C.c_size_t, vp]
     L.rs_bootstrap.argtypes = [vp, _i32p, _i32p, C.c_int32, C.c_size_t]
@@ -196,6 +197,14 @@ class Backend:
         assert bk.size == p.n * 2 * p.bk_l * 2 * p.N, "bk has the wrong size"
         assert ksk.size == p.N * p.ks_t * (1 << p.ks_basebit) * (p.n + 1), "ksk has the wrong size"
         _check(self.L, self.L.rs_load_keys(self.h, pbk, pksk))
+
+    def load_synthetic_keys(self, seed):
+        """A key of pseudo-random words generated ON THE DEVICE (rs_load_synthetic_keys; client.synthetic_key_words restates the
+        generator): benchmarks and parity tests of the large rings, whose real keys are gigabytes on the host."""
+        _check(self.L, self.L.rs_load_synthetic_keys(self.h, C.c_uint64(int(seed) & (2**64 - 1))))
+
+    def release_stream(self, stream):
+        _check(self.L, self.L.rs_release_stream(self.h, C.c_void_p(int(stream))))
 
     def reserve(self, max_batch):
         """Pre-size the workspace of torch's current stream."""

@@ -241,3 +241,20 @@ def read_ciphertexts(f, n, count):
         assert np.frombuffer(raw[i * rec:i * rec + 4], np.int32)[0] == TFHE_UID["lwe_sample"]
         out[i] = np.frombuffer(raw[i * rec + 4:i * rec + 4 + 4 * (n + 1)], np.int32)
     return out
+
+
+def synthetic_key_words(seed, count, first=0, chunk=1 << 22):
+    """Words [first, first + count) of the synthetic key rs_load_synthetic_keys(seed) generates on the device (csrc/rs_ntt.h,
+    synthetic_key_word: the high half of splitmix64(seed + k)); the keyswitch key uses seed ^ 0x6b73."""
+    out = np.empty(int(count), np.int32)
+    seed = np.uint64(int(seed) & (2**64 - 1))
+    with np.errstate(over="ignore"):
+        for lo in range(0, int(count), chunk):
+            hi = min(int(count), lo + chunk)
+            k = np.arange(first + lo + 1, first + hi + 1, dtype=np.uint64)
+            z = seed + k * np.uint64(0x9E3779B97F4A7C15)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z ^= z >> np.uint64(31)
+            out[lo:hi] = (z >> np.uint64(32)).astype(np.uint32).view(np.int32)
+    return out

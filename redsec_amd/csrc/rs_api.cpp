@@ -466,10 +466,12 @@ int rs_destroy(rs_ctx* c) {
   return RS_OK;
 }
 
-int rs_load_keys(rs_ctx* c, const int32_t* bk, const int32_t* ksk) {
+// bk / ksk: host arrays, or both null for the synthetic key of `seed` generated on the device (rs_load_synthetic_keys)
+static int load_keys_impl(rs_ctx* c, const int32_t* bk, const int32_t* ksk, uint64_t seed) {
   int rc = use_device(c);
   if (rc) return rc;
-  if (!bk || !ksk) return fail(RS_ERR_INVALID, "null key pointer");
+  const bool synthetic = !bk && !ksk;
+  if (!synthetic && (!bk || !ksk)) return fail(RS_ERR_INVALID, "null key pointer");
   const rs_params& p = c->p;
   const size_t n_polys = (size_t)p.n * (size_t)(2 * p.bk_l) * 2;
   const size_t bk_words = n_polys * (size_t)p.N;
@@ -481,7 +483,8 @@ int rs_load_keys(rs_ctx* c, const int32_t* bk, const int32_t* ksk) {
   c->keys = false;
   int32_t* d_bk = nullptr;
   RS_HIP(hipMalloc(&d_bk, bk_words * sizeof(int32_t)));
-  RS_HIP(hipMemcpy(d_bk, bk, bk_words * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (synthetic) RS_HIP(rs::launch_synthetic_words(d_bk, seed, bk_words, nullptr));
+  else RS_HIP(hipMemcpy(d_bk, bk, bk_words * sizeof(int32_t), hipMemcpyHostToDevice));
   c->bk_bytes = 0;
   if (!c->general) {
     // both transform domains are kept resident (62 + 62 MB default-128, 115 + 115 MB REDsec): the FFT mode's
@@ -501,11 +504,18 @@ int rs_load_keys(rs_ctx* c, const int32_t* bk, const int32_t* ksk) {
   RS_HIP(hipDeviceSynchronize());
   RS_HIP(hipFree(d_bk));
   RS_HIP(hipMalloc(&c->d_ksk, ksk_words * sizeof(int32_t)));
-  RS_HIP(hipMemcpy(c->d_ksk, ksk, ksk_words * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (synthetic) { RS_HIP(rs::launch_synthetic_words(c->d_ksk, seed ^ 0x6b73ull, ksk_words, nullptr)); RS_HIP(hipDeviceSynchronize()); }
+  else RS_HIP(hipMemcpy(c->d_ksk, ksk, ksk_words * sizeof(int32_t), hipMemcpyHostToDevice));
   c->ksk_bytes = ksk_words * sizeof(int32_t);
   c->keys = true;
   return RS_OK;
 }
+
+int rs_load_keys(rs_ctx* c, const int32_t* bk, const int32_t* ksk) {
+  if (!bk || !ksk) return fail(RS_ERR_INVALID, "null key pointer");
+  return load_keys_impl(c, bk, ksk, 0);
+}
+int rs_load_synthetic_keys(rs_ctx* c, uint64_t seed) { return load_keys_impl(c, nullptr, nullptr, seed); }
 
 int rs_reserve(rs_ctx* c, size_t max_batch) { return rs_reserve_stream(c, max_batch, nullptr); }
 

@@ -111,64 +111,89 @@ RS_HD void gen_load(double (&x)[kRegs], int t, const double* pre, const double* 
   }
 }
 
-// One exchange = sync (the previous readers of the planes are done), store, sync, load. `sync` is a workgroup
-// barrier (a wave-local fence when the workgroup is a single wavefront, N = 1024).
-template <int LOGN, int XP, bool INV, class Sync>
-RS_HD void gen_exchange(double (&x)[kRegs], int t, double* pre, double* pim, Sync sync) {
-  sync();
-  gen_store<LOGN, INV ? XP + 1 : XP, XP>(x, t, pre, pim);
-  sync();
-  gen_load<LOGN, INV ? XP : XP + 1, XP>(x, t, pre, pim);
+// One exchange = sync (the previous readers of the planes are done), store, sync, load. The exchange between passes XP and XP+1
+// moves values only inside groups of 2^(H(XP) - 3) consecutive threads -- the threads of one block of pass XP, whose 2^H(XP)
+// values occupy a region of the planes of their own (gen_phys pads every block to the same 9/8 of its size for every exchange).
+// Only exchange 0 spans the workgroup; from exchange 1 on a group is at most one wavefront (T/8 threads, T <= 512), so `sync`
+// (a workgroup barrier when the workgroup has several wavefronts) is needed for exchange 0 alone and `wsync` (a wave-local
+// fence: the LDS operations of one wavefront execute in order) orders the others: 2 instead of 6 barriers per transform for
+// N >= 2048. Safe against the other waves: a region is written and read by its own group only, except by exchange 0, which both
+// of whose barriers every wave still passes -- the first one after ITS last read of the previous transform.
+template <int LOGN, int XP>
+constexpr bool gen_exchange_is_wave_local() {
+#ifdef RS_GEN_WG_BARRIERS   // A/B: the previous form, workgroup barriers around every exchange
+  return Gen<LOGN>::T <= 64;
+#else
+  return (1 << (Gen<LOGN>::H(XP) - 3)) <= 64;
+#endif
+}
+template <int LOGN, int XP, bool INV, class Sync, class WSync>
+RS_HD void gen_exchange(double (&x)[kRegs], int t, double* pre, double* pim, Sync sync, WSync wsync) {
+  if constexpr (gen_exchange_is_wave_local<LOGN, XP>()) {
+    wsync();
+    gen_store<LOGN, INV ? XP + 1 : XP, XP>(x, t, pre, pim);
+    wsync();
+    gen_load<LOGN, INV ? XP : XP + 1, XP>(x, t, pre, pim);
+  } else {
+    sync();
+    gen_store<LOGN, INV ? XP + 1 : XP, XP>(x, t, pre, pim);
+    sync();
+    gen_load<LOGN, INV ? XP : XP + 1, XP>(x, t, pre, pim);
+  }
 }
 
 // forward: x[r] + i x[r+8] = folded input value t + T r  ->  transform value 8 t + r (bit-reversed-order tree leaves)
-template <int LOGN, class Sync>
-RS_HD void gen_fft_fwd(double (&x)[kRegs], int t, const double* tw, double* pre, double* pim, Sync sync) {
+template <int LOGN, class Sync, class WSync>
+RS_HD void gen_fft_fwd(double (&x)[kRegs], int t, const double* tw, double* pre, double* pim, Sync sync, WSync wsync) {
   constexpr int P = Gen<LOGN>::P;
   GenPassTw w;
   gen_pass_tw<LOGN, 0>(w, t, tw);
   gen_pass_fwd<LOGN, 0>(x, w);
   if constexpr (P > 1) {
     gen_pass_tw<LOGN, 1>(w, t, tw);
-    gen_exchange<LOGN, 0, false>(x, t, pre, pim, sync);
+    gen_exchange<LOGN, 0, false>(x, t, pre, pim, sync, wsync);
     gen_pass_fwd<LOGN, 1>(x, w);
   }
   if constexpr (P > 2) {
     gen_pass_tw<LOGN, 2>(w, t, tw);
-    gen_exchange<LOGN, 1, false>(x, t, pre, pim, sync);
+    gen_exchange<LOGN, 1, false>(x, t, pre, pim, sync, wsync);
     gen_pass_fwd<LOGN, 2>(x, w);
   }
   if constexpr (P > 3) {
     gen_pass_tw<LOGN, 3>(w, t, tw);
-    gen_exchange<LOGN, 2, false>(x, t, pre, pim, sync);
+    gen_exchange<LOGN, 2, false>(x, t, pre, pim, sync, wsync);
     gen_pass_fwd<LOGN, 3>(x, w);
   }
   static_assert(P <= 4, "at most four passes (N <= 8192)");
 }
 // inverse (unscaled: 1/M lives in the key): transform value 8 t + r -> folded value t + T r
-template <int LOGN, class Sync>
-RS_HD void gen_fft_inv(double (&x)[kRegs], int t, const double* tw, double* pre, double* pim, Sync sync) {
+template <int LOGN, class Sync, class WSync>
+RS_HD void gen_fft_inv(double (&x)[kRegs], int t, const double* tw, double* pre, double* pim, Sync sync, WSync wsync) {
   constexpr int P = Gen<LOGN>::P;
   GenPassTw w;
+  // The inverse STARTS with its wave-local exchanges, whose stores land in block regions that the LAST exchange of a preceding
+  // inverse transform (exchange 0: every wave reads everywhere) may still be reading in another wave: one barrier up front.
+  // (A preceding forward transform ends with a wave-local exchange of the same groups and needs none; it costs little there.)
+  if constexpr (P > 2 && !gen_exchange_is_wave_local<LOGN, 0>()) sync();
   if constexpr (P > 3) {
     gen_pass_tw<LOGN, 3>(w, t, tw);
     gen_pass_inv<LOGN, 3>(x, w);
     gen_pass_tw<LOGN, 2>(w, t, tw);
-    gen_exchange<LOGN, 2, true>(x, t, pre, pim, sync);
+    gen_exchange<LOGN, 2, true>(x, t, pre, pim, sync, wsync);
   } else if constexpr (P > 2) {
     gen_pass_tw<LOGN, 2>(w, t, tw);
   }
   if constexpr (P > 2) {
     gen_pass_inv<LOGN, 2>(x, w);
     gen_pass_tw<LOGN, 1>(w, t, tw);
-    gen_exchange<LOGN, 1, true>(x, t, pre, pim, sync);
+    gen_exchange<LOGN, 1, true>(x, t, pre, pim, sync, wsync);
   } else if constexpr (P > 1) {
     gen_pass_tw<LOGN, 1>(w, t, tw);
   }
   if constexpr (P > 1) {
     gen_pass_inv<LOGN, 1>(x, w);
     gen_pass_tw<LOGN, 0>(w, t, tw);
-    gen_exchange<LOGN, 0, true>(x, t, pre, pim, sync);
+    gen_exchange<LOGN, 0, true>(x, t, pre, pim, sync, wsync);
   } else {
     gen_pass_tw<LOGN, 0>(w, t, tw);
   }

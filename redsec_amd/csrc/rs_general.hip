@@ -50,6 +50,7 @@ __global__ __launch_bounds__(Gen<LOGN>::T) void gen_bk_transform_kernel(const in
   __shared__ double s_re[G::kPlane], s_im[G::kPlane];
   const int t = threadIdx.x;
   auto sync = [] { gen_sync<T>(); };
+  auto wsync = [] { gen_wave_sync(); };
   for (long poly = blockIdx.x; poly < n_polys; poly += gridDim.x) {
     const int32_t* src = bk + poly * N;
 #pragma unroll 1
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(Gen<LOGN>::T) void gen_bk_transform_kernel(const in
         gen_split_key(src[t + T * r + M], lo, hi);
         x[r + 8] = (double)(piece ? hi : lo);
       }
-      gen_fft_fwd<LOGN>(x, t, tw, s_re, s_im, sync);
+      gen_fft_fwd<LOGN>(x, t, tw, s_re, s_im, sync, wsync);
       // [row pair index][piece][column][8][T] complex, scaled by 1/M (a power of two: exact)
       double2* dst = reinterpret_cast<double2*>(bk_x) + ((size_t)(poly >> 1) * 4 + (size_t)piece * 2 + (size_t)(poly & 1)) * M;
 #pragma unroll
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
   __shared__ int32_t s_acc[2][N];
   const int t = threadIdx.x;
   auto sync = [] { gen_sync<T>(); };
+  auto wsync = [] { gen_wave_sync(); };
   const int l = a.l, bgbit = a.bgbit, n = a.n;
   const uint32_t goff = gen_gadget_offset(l, bgbit);
   double dev = 0.0;
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
           double x[kRegs];
 #pragma unroll
           for (int r = 0; r < 16; ++r) x[r] = (double)gen_gadget_digit(v[r], q, bgbit);
-          gen_fft_fwd<LOGN>(x, t, a.tw, s_re, s_im, sync);
+          gen_fft_fwd<LOGN>(x, t, a.tw, s_re, s_im, sync, wsync);
           const double2* kp = reinterpret_cast<const double2*>(a.bk_x) + ((size_t)i * 2 * l + (size_t)comp * l + q) * 4 * M;
 #pragma unroll
           for (int r = 0; r < 8; ++r) {
@@ -154,8 +156,8 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
       // every thread passed at least one barrier since its reads of the accumulator: the update cannot overtake them
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        gen_fft_inv<LOGN>(S[0][c], t, a.tw, s_re, s_im, sync);
-        gen_fft_inv<LOGN>(S[1][c], t, a.tw, s_re, s_im, sync);
+        gen_fft_inv<LOGN>(S[0][c], t, a.tw, s_re, s_im, sync, wsync);
+        gen_fft_inv<LOGN>(S[1][c], t, a.tw, s_re, s_im, sync, wsync);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int j = t + T * (r & 7) + (r >> 3) * M;
@@ -190,6 +192,7 @@ __global__ __launch_bounds__(Gen<LOGN>::T) void gen_polymul_kernel(const int32_t
   __shared__ double s_re[G::kPlane], s_im[G::kPlane];
   const int t = threadIdx.x;
   auto sync = [] { gen_sync<T>(); };
+  auto wsync = [] { gen_wave_sync(); };
   double dev = 0.0;
   for (long idx = blockIdx.x; idx < count; idx += gridDim.x) {
     const int32_t* pa = a_small + idx * N;
@@ -204,14 +207,14 @@ __global__ __launch_bounds__(Gen<LOGN>::T) void gen_polymul_kernel(const int32_t
         gen_split_key(pb[t + T * (r & 7) + (r >> 3) * M], lo, hi);
         x[r] = (double)(piece ? hi : lo);
       }
-      gen_fft_fwd<LOGN>(x, t, tw, s_re, s_im, sync);
+      gen_fft_fwd<LOGN>(x, t, tw, s_re, s_im, sync, wsync);
 #pragma unroll
       for (int r = 0; r < 8; ++r) key[(size_t)piece * M + r * T + t] = make_double2(x[r] * (1.0 / M), x[r + 8] * (1.0 / M));
     }
     double xa[kRegs];
 #pragma unroll
     for (int r = 0; r < 16; ++r) xa[r] = (double)pa[t + T * (r & 7) + (r >> 3) * M];
-    gen_fft_fwd<LOGN>(xa, t, tw, s_re, s_im, sync);
+    gen_fft_fwd<LOGN>(xa, t, tw, s_re, s_im, sync, wsync);
     double S[2][kRegs];
 #pragma unroll
     for (int piece = 0; piece < 2; ++piece) {
@@ -222,8 +225,8 @@ __global__ __launch_bounds__(Gen<LOGN>::T) void gen_polymul_kernel(const int32_t
         fft_cmac(S[piece][r], S[piece][r + 8], xa[r], xa[r + 8], w.x, w.y);
       }
     }
-    gen_fft_inv<LOGN>(S[0], t, tw, s_re, s_im, sync);
-    gen_fft_inv<LOGN>(S[1], t, tw, s_re, s_im, sync);
+    gen_fft_inv<LOGN>(S[0], t, tw, s_re, s_im, sync, wsync);
+    gen_fft_inv<LOGN>(S[1], t, tw, s_re, s_im, sync, wsync);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int j = t + T * (r & 7) + (r >> 3) * M;

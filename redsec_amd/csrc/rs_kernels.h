@@ -93,6 +93,7 @@ hipError_t launch_polymul(int cfg, int mode, const int32_t* a_small, const int32
                           const double* tw, Field f, double scale, long count, unsigned long long* dev_flag, hipStream_t st);
 hipError_t launch_lincomb(int32_t* out, const int32_t* x, int32_t cx, const int32_t* y, int32_t cy, int32_t bconst, int W, long B,
                           hipStream_t st);
+hipError_t launch_synthetic_words(int32_t* out, uint64_t seed, size_t total, hipStream_t st);
 hipError_t launch_gather_rows(int32_t* out, const int32_t* in, const int32_t* idx, int W, long B, hipStream_t st);
 hipError_t launch_linear_fc(int32_t* out, const int32_t* in, const uint8_t* sign, const uint8_t* zero, int K, int M, int W,
                             int32_t zero_tap_b, const int32_t* bias_b, int bias_depth, hipStream_t st);

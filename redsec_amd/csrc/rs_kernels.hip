@@ -186,6 +186,11 @@ __global__ void lincomb_kernel(int32_t* __restrict__ out, const int32_t* __restr
   }
 }
 
+__global__ void synthetic_words_kernel(int32_t* __restrict__ out, uint64_t seed, size_t total) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x)
+    out[e] = (int32_t)synthetic_key_word(seed, (uint64_t)e);
+}
+
 __global__ void gather_rows_kernel(int32_t* __restrict__ out, const int32_t* __restrict__ in, const int32_t* __restrict__ idx, int W,
                                    long total) {
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -414,6 +419,14 @@ hipError_t launch_lincomb(int32_t* out, const int32_t* x, int32_t cx, const int3
   long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out, x, cx, y, cy, bconst, W, total);
+  return hipGetLastError();
+}
+
+hipError_t launch_synthetic_words(int32_t* out, uint64_t seed, size_t total, hipStream_t st) {
+  if (total == 0) return hipSuccess;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(synthetic_words_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out, seed, total);
   return hipGetLastError();
 }
 

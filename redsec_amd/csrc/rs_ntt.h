@@ -373,6 +373,16 @@ RS_HD int32_t rotated_const(int32_t mu, int j, int a) {
   const int neg = (j < aa ? 1 : 0) ^ nb;
   return neg ? (int32_t)(0u - (uint32_t)mu) : mu;
 }
+// Word k of a SYNTHETIC key (rs_load_synthetic_keys: benchmarks and tests of the large rings, whose real keys are gigabytes):
+// the high half of splitmix64(seed + k), the same on the device, in the C++ host code and in numpy (redsec_amd/client.py).
+RS_HD uint32_t synthetic_key_word(uint64_t seed, uint64_t k) {
+  uint64_t z = seed + (k + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 32);
+}
+
 // gadget digit q (0-based) of coefficient d (tGswTorus32PolynomialDecompH).
 template <class C>
 RS_HD int32_t gadget_digit(int32_t d, int q, uint32_t offset) {

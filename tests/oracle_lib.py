@@ -62,6 +62,7 @@ def lib():
     L.ro_bk_words.argtypes = [P]; L.ro_bk_words.restype = C.c_size_t
     L.ro_ksk_words.argtypes = [P]; L.ro_ksk_words.restype = C.c_size_t
     L.ro_keygen.argtypes = [P, C.c_uint64, _i32p, _i32p, _i32p, _i32p]
+    L.ro_synthetic_key_words.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _i32p]
     L.ro_lwe_encrypt.argtypes = [_i32p, C.c_int32, C.c_double, _i32p, C.c_int32, C.POINTER(RoRng)]
     L.ro_lwe_phase.argtypes = [_i32p, _i32p, C.c_int32]; L.ro_lwe_phase.restype = C.c_int32
     L.ro_lwe_decrypt.argtypes = [_i32p, _i32p, C.c_int32, C.c_int32]; L.ro_lwe_decrypt.restype = C.c_int32
@@ -282,4 +283,11 @@ def linear_fc(x, sign, zero, zero_tap_b=0):
     M = sign.shape[1]
     out = np.zeros((M, W), np.int32)
     lib().ro_linear_fc(_p(out), _p(x), _pu8(sign), _pu8(zero), K, M, W, int(zero_tap_b))
+    return out
+
+
+def synthetic_key_words(seed, count, first=0):
+    """Words [first, first + count) of the synthetic key of `seed` (the oracle's restatement of rs_load_synthetic_keys' generator)."""
+    out = np.empty(int(count), np.int32)
+    lib().ro_synthetic_key_words(int(seed) & (2**64 - 1), int(first), int(count), _p(out))
     return out
