@@ -28,11 +28,41 @@ def _abs(paths):
     return [p if os.path.isabs(p) else os.path.join(CSRC, p) for p in paths]
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
+def fingerprint(paths, extra=""):
+    """sha256 over the CONTENTS of `paths` (and `extra`, e.g. the compiler flags): what a built artefact was made from."""
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def is_stale(target, deps, extra=""):
+    """A target is up to date when `<target>.stamp` holds the fingerprint of its present dependencies. Content-based, not
+    mtime-based: a snapshot pushed to another machine (the GPU box) never recompiles what was built from the same sources,
+    whatever the copy did to the timestamps, and an edited source always does."""
+    stamp = target + ".stamp"
+    if not (os.path.exists(target) and os.path.exists(stamp)):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in _abs(deps) + [os.path.abspath(__file__)])
+    try:
+        return open(stamp).read().strip() != fingerprint(deps, extra)
+    except OSError:
+        return True
+
+
+def write_stamp(target, deps, extra=""):
+    with open(target + ".stamp", "w") as f:
+        f.write(fingerprint(deps, extra) + "\n")
+
+
+def _stale(target, deps):
+    return is_stale(target, _abs(deps) + [os.path.abspath(__file__)])
+
+
+def _stamp(target, deps):
+    write_stamp(target, _abs(deps) + [os.path.abspath(__file__)])
 
 
 def find_hipcc():
@@ -55,6 +85,7 @@ def build_hip(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    _stamp(HIP_LIB, HIP_DEPS)
     return HIP_LIB
 
 
@@ -69,6 +100,7 @@ def build_emulator(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    _stamp(EMU_LIB, EMU_DEPS)
     return EMU_LIB
 
 
@@ -91,6 +123,7 @@ def build_layers(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    _stamp(LAYERS_LIB, LAYERS_DEPS)
     return LAYERS_LIB
 
 

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include "rs_general.h"
 #include "rs_kernels.h"
@@ -247,18 +248,25 @@ static long gen_resident(K kernel, int threads, int num_cus) {
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
   return (long)per_cu * num_cus;
 }
+// resident workgroups of the CURRENT device (contexts of a fleet may sit on devices or partitions with different CU counts):
+// cached per (device, ring), filled at first use; a benign race writes the same value twice
 static long gen_grid(int logn, long work, int num_cus) {
-  static long resident[kGenMaxLogN + 1] = {0};
-  if (resident[logn] == 0) {
+  static std::atomic<long> resident[16][kGenMaxLogN + 1];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::atomic<long>& slot = resident[dev & 15][logn];
+  long r = slot.load(std::memory_order_relaxed);
+  if (r == 0 || dev > 15) {
     const int T = (1 << logn) / 16;
     switch (logn) {
-      case 10: resident[logn] = gen_resident(gen_blind_rotate_kernel<10>, T, num_cus); break;
-      case 11: resident[logn] = gen_resident(gen_blind_rotate_kernel<11>, T, num_cus); break;
-      case 12: resident[logn] = gen_resident(gen_blind_rotate_kernel<12>, T, num_cus); break;
-      default: resident[logn] = gen_resident(gen_blind_rotate_kernel<13>, T, num_cus); break;
+      case 10: r = gen_resident(gen_blind_rotate_kernel<10>, T, num_cus); break;
+      case 11: r = gen_resident(gen_blind_rotate_kernel<11>, T, num_cus); break;
+      case 12: r = gen_resident(gen_blind_rotate_kernel<12>, T, num_cus); break;
+      default: r = gen_resident(gen_blind_rotate_kernel<13>, T, num_cus); break;
     }
+    if (dev <= 15) slot.store(r, std::memory_order_relaxed);
   }
-  return work < resident[logn] ? work : resident[logn];
+  return work < r ? work : r;
 }
 long gen_resident_ciphertexts(int logn, int num_cus) { return gen_grid(logn, 1L << 40, num_cus); }
 

@@ -345,7 +345,9 @@ void delete_gate_bootstrapping_parameters(TFheGateBootstrappingParameterSet*) {}
 
 // ---- files ----
 // KEY FILES. Two formats are read, told apart by the first bytes; REDSEC_KEY_FORMAT=rs selects the private one
-// for writing, the default is TFHE's.
+// for writing, the default is TFHE's layout -- EXPERIMENTAL until tools/tfhe_crosscheck.md has been run against a real libtfhe:
+// files round-trip between this shim and redsec_amd/client.py (two restatements of one recollection), nothing more is claimed,
+// and INTEGRATION.md says so. REDSEC_KEY_FORMAT=rs is the verified choice for files that only this backend reads.
 //
 // (1) TFHE v1.1's own (tfhe_io.cpp write_tfheGateBootstrappingCloudKeySet / ...SecretKeySet) [TFHE-recalled:
 //     the library is not in this image, so this is restated from its published source and could not be run

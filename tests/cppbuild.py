@@ -14,8 +14,9 @@ def build(name):
     src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
     exe = os.path.join(OUT, name + ".out")
     os.makedirs(OUT, exist_ok=True)
-    deps = [src, b.LAYERS_LIB]
-    if os.path.exists(exe) and all(os.path.getmtime(d) <= os.path.getmtime(exe) for d in deps):
+    deps = [src, b.LAYERS_LIB] + [os.path.join(ROOT, "redsec_amd", "host", "lib", h) for h in ("Layer.h", "BinLayer.h", "IntLayer.h", "BinFunc.h", "IntFunc.h")] + \
+        [os.path.join(ROOT, "redsec_amd", "host", "tfhe", "tfhe.h")]
+    if not b.is_stale(exe, deps):      # content fingerprints, not mtimes: a pushed snapshot never recompiles (redsec_amd/build.py)
         return exe
     cxx = shutil.which("g++")
     if cxx is None:
@@ -23,6 +24,7 @@ def build(name):
     lib = os.path.join(ROOT, "redsec_amd")
     subprocess.check_call([cxx, "-O1", "-w", "-std=c++17", "-I" + os.path.join(lib, "host"), src, "-L" + lib, "-lredsec_layers",
                            "-lredsec_hip", "-Wl,-rpath," + lib, "-o", exe])
+    b.write_stamp(exe, deps)
     return exe
 
 

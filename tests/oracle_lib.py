@@ -33,10 +33,11 @@ class RoRng(C.Structure):
 def build_oracle(force=False):
     src = os.path.join(ORACLE_DIR, "redsec_oracle.c")
     hdr = os.path.join(ORACLE_DIR, "redsec_oracle.h")
-    stale = (not os.path.exists(_SO)) or any(
-        os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(_SO) for f in (src, hdr))
-    if force or stale:
-        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, os.path.join(ORACLE_DIR, "libredsec_oracle.so")])
+    from redsec_amd import build as _b      # its content-fingerprint helpers only (a pushed snapshot never recompiles)
+    deps = [src, hdr, os.path.join(ORACLE_DIR, "Makefile")]
+    if force or _b.is_stale(_SO, deps):
+        subprocess.check_call(["make", "-s", "-B", "-C", ORACLE_DIR, os.path.join(ORACLE_DIR, "libredsec_oracle.so")])
+        _b.write_stamp(_SO, deps)
     return _SO
 
 
