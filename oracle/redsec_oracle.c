@@ -614,7 +614,8 @@ static void cmux_step(const ro_ctx* c, int32_t* acc, int32_t i, int32_t barai, i
     /* A single ciphertext on a large ring (the full-size parity tests): the kpl row products of a step are independent, so
      * they go to kpl threads and are summed afterwards -- the same exact values in the same field, any order. */
     uint64_t* rowprod = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)kpl * (size_t)(k + 2) * N);
-#pragma omp parallel for schedule(static)
+    const int team = kpl < omp_get_max_threads() ? kpl : omp_get_max_threads();   /* never the whole machine: a team is woken per step */
+#pragma omp parallel for schedule(static) num_threads(team)
     for (int32_t row = 0; row < kpl; ++row) {
       uint64_t* f = rowprod + (size_t)row * (size_t)(k + 2) * N;
       const int32_t* d = digits + (size_t)row * N;

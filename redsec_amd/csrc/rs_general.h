@@ -48,21 +48,28 @@ constexpr RS_HD int gen_phys(int idx, int Hr) { return Hr < 8 ? idx + ((idx >> H
 // the (at most four) EVEN twiddles of one pass: level e of the pass uses blocks (blk << e) | g, g < 2^e; odd g is
 // i times its even sibling and is applied by the _i butterflies (rs_fft.h)
 struct GenPassTw { FftStageTw lv[3]; };
+// Table entries [0, kGenTwLds) -- levels 0..8 of every ring -- are staged in LDS by the kernels (8 KB); `tw_near` serves them,
+// `tw` (global memory) the levels above. Fetched from global memory, every pass of every transform waited for an L1/L2 round
+// trip of its own (10 transforms x 3-4 passes per CMUX step).
+constexpr int kGenTwLds = 512;   // complex entries
 template <int LOGN, int PASS>
-RS_HD void gen_pass_tw(GenPassTw& w, int t, const double* tw) {
+RS_HD void gen_pass_tw(GenPassTw& w, int t, const double* tw, const double* tw_near) {
   using G = Gen<LOGN>;
   constexpr int H = G::H(PASS), E0 = G::first_level(PASS), SB = G::LOGM - H;
   const int blk = t >> (H - 3);
 #pragma unroll
   for (int e = E0; e < 3; ++e) {
     const int base = (1 << (SB + e)) + (blk << e);
+    const double* src = ((2 << (SB + e)) <= kGenTwLds) ? tw_near : tw;   // compile-time choice per level
 #pragma unroll
     for (int g = 0; g < (1 << e); g += 2) {
-      w.lv[e].wr[g >> 1] = tw[2 * (base + g)];
-      w.lv[e].wi[g >> 1] = tw[2 * (base + g) + 1];
+      w.lv[e].wr[g >> 1] = src[2 * (base + g)];
+      w.lv[e].wi[g >> 1] = src[2 * (base + g) + 1];
     }
   }
 }
+template <int LOGN, int PASS>
+RS_HD void gen_pass_tw(GenPassTw& w, int t, const double* tw) { gen_pass_tw<LOGN, PASS>(w, t, tw, tw); }
 template <int LOGN, int PASS>
 RS_HD void gen_pass_fwd(double (&x)[kRegs], const GenPassTw& w) {
   constexpr int E0 = Gen<LOGN>::first_level(PASS);
@@ -144,23 +151,23 @@ RS_HD void gen_exchange(double (&x)[kRegs], int t, double* pre, double* pim, Syn
 
 // forward: x[r] + i x[r+8] = folded input value t + T r  ->  transform value 8 t + r (bit-reversed-order tree leaves)
 template <int LOGN, class Sync, class WSync>
-RS_HD void gen_fft_fwd(double (&x)[kRegs], int t, const double* tw, double* pre, double* pim, Sync sync, WSync wsync) {
+RS_HD void gen_fft_fwd(double (&x)[kRegs], int t, const double* tw, const double* tw_near, double* pre, double* pim, Sync sync, WSync wsync) {
   constexpr int P = Gen<LOGN>::P;
   GenPassTw w;
-  gen_pass_tw<LOGN, 0>(w, t, tw);
+  gen_pass_tw<LOGN, 0>(w, t, tw, tw_near);
   gen_pass_fwd<LOGN, 0>(x, w);
   if constexpr (P > 1) {
-    gen_pass_tw<LOGN, 1>(w, t, tw);
+    gen_pass_tw<LOGN, 1>(w, t, tw, tw_near);
     gen_exchange<LOGN, 0, false>(x, t, pre, pim, sync, wsync);
     gen_pass_fwd<LOGN, 1>(x, w);
   }
   if constexpr (P > 2) {
-    gen_pass_tw<LOGN, 2>(w, t, tw);
+    gen_pass_tw<LOGN, 2>(w, t, tw, tw_near);
     gen_exchange<LOGN, 1, false>(x, t, pre, pim, sync, wsync);
     gen_pass_fwd<LOGN, 2>(x, w);
   }
   if constexpr (P > 3) {
-    gen_pass_tw<LOGN, 3>(w, t, tw);
+    gen_pass_tw<LOGN, 3>(w, t, tw, tw_near);
     gen_exchange<LOGN, 2, false>(x, t, pre, pim, sync, wsync);
     gen_pass_fwd<LOGN, 3>(x, w);
   }
@@ -168,7 +175,7 @@ RS_HD void gen_fft_fwd(double (&x)[kRegs], int t, const double* tw, double* pre,
 }
 // inverse (unscaled: 1/M lives in the key): transform value 8 t + r -> folded value t + T r
 template <int LOGN, class Sync, class WSync>
-RS_HD void gen_fft_inv(double (&x)[kRegs], int t, const double* tw, double* pre, double* pim, Sync sync, WSync wsync) {
+RS_HD void gen_fft_inv(double (&x)[kRegs], int t, const double* tw, const double* tw_near, double* pre, double* pim, Sync sync, WSync wsync) {
   constexpr int P = Gen<LOGN>::P;
   GenPassTw w;
   // The inverse STARTS with its wave-local exchanges, whose stores land in block regions that the LAST exchange of a preceding
@@ -176,26 +183,26 @@ RS_HD void gen_fft_inv(double (&x)[kRegs], int t, const double* tw, double* pre,
   // (A preceding forward transform ends with a wave-local exchange of the same groups and needs none; it costs little there.)
   if constexpr (P > 2 && !gen_exchange_is_wave_local<LOGN, 0>()) sync();
   if constexpr (P > 3) {
-    gen_pass_tw<LOGN, 3>(w, t, tw);
+    gen_pass_tw<LOGN, 3>(w, t, tw, tw_near);
     gen_pass_inv<LOGN, 3>(x, w);
-    gen_pass_tw<LOGN, 2>(w, t, tw);
+    gen_pass_tw<LOGN, 2>(w, t, tw, tw_near);
     gen_exchange<LOGN, 2, true>(x, t, pre, pim, sync, wsync);
   } else if constexpr (P > 2) {
-    gen_pass_tw<LOGN, 2>(w, t, tw);
+    gen_pass_tw<LOGN, 2>(w, t, tw, tw_near);
   }
   if constexpr (P > 2) {
     gen_pass_inv<LOGN, 2>(x, w);
-    gen_pass_tw<LOGN, 1>(w, t, tw);
+    gen_pass_tw<LOGN, 1>(w, t, tw, tw_near);
     gen_exchange<LOGN, 1, true>(x, t, pre, pim, sync, wsync);
   } else if constexpr (P > 1) {
-    gen_pass_tw<LOGN, 1>(w, t, tw);
+    gen_pass_tw<LOGN, 1>(w, t, tw, tw_near);
   }
   if constexpr (P > 1) {
     gen_pass_inv<LOGN, 1>(x, w);
-    gen_pass_tw<LOGN, 0>(w, t, tw);
+    gen_pass_tw<LOGN, 0>(w, t, tw, tw_near);
     gen_exchange<LOGN, 0, true>(x, t, pre, pim, sync, wsync);
   } else {
-    gen_pass_tw<LOGN, 0>(w, t, tw);
+    gen_pass_tw<LOGN, 0>(w, t, tw, tw_near);
   }
   gen_pass_inv<LOGN, 0>(x, w);
 }

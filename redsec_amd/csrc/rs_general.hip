@@ -43,15 +43,34 @@ __device__ __forceinline__ void gen_publish(double dev, unsigned long long* flag
 
 }  // namespace
 
+// Levels 0..8 of the twiddle table staged in LDS (8 KB; rs_general.h, gen_pass_tw). Measured at full size (profiles/r03/
+// f_general_ab.txt): redsec_params_medium +8.9 % (two workgroups per CU, every pass used to wait for an L1/L2 round trip of its
+// own), redsec_params_large -3.9 % (one 512-thread workgroup per CU on 139 KB of LDS already: the extra LDS reads queue behind
+// its exchanges) -- so N = 8192 keeps reading the table from global memory.
+template <int LOGN>
+constexpr bool kGenStageTw = LOGN <= 12;
+template <int LOGN>
+__device__ __forceinline__ const double* gen_stage_twiddles(double* s_twn, const double* tw, int t) {
+  if constexpr (kGenStageTw<LOGN>) {
+    for (int i = t; i < 2 * kGenTwLds; i += Gen<LOGN>::T) s_twn[i] = tw[i];
+    __syncthreads();
+    return s_twn;
+  } else {
+    return tw;
+  }
+}
+
 template <int LOGN>
 __global__ __launch_bounds__(Gen<LOGN>::T) void gen_bk_transform_kernel(const int32_t* __restrict__ bk, double* __restrict__ bk_x,
                                                                          const double* __restrict__ tw, long n_polys) {
   using G = Gen<LOGN>;
   constexpr int N = G::N, M = G::M, T = G::T;
   __shared__ double s_re[G::kPlane], s_im[G::kPlane];
+  __shared__ double s_twn[kGenStageTw<LOGN> ? 2 * kGenTwLds : 2];
   const int t = threadIdx.x;
   auto sync = [] { gen_sync<T>(); };
   auto wsync = [] { gen_wave_sync(); };
+  const double* twn = gen_stage_twiddles<LOGN>(s_twn, tw, t);
   for (long poly = blockIdx.x; poly < n_polys; poly += gridDim.x) {
     const int32_t* src = bk + poly * N;
 #pragma unroll 1
@@ -65,7 +84,7 @@ __global__ __launch_bounds__(Gen<LOGN>::T) void gen_bk_transform_kernel(const in
         gen_split_key(src[t + T * r + M], lo, hi);
         x[r + 8] = (double)(piece ? hi : lo);
       }
-      gen_fft_fwd<LOGN>(x, t, tw, s_re, s_im, sync, wsync);
+      gen_fft_fwd<LOGN>(x, t, tw, twn, s_re, s_im, sync, wsync);
       // [row pair index][piece][column][8][T] complex, scaled by 1/M (a power of two: exact)
       double2* dst = reinterpret_cast<double2*>(bk_x) + ((size_t)(poly >> 1) * 4 + (size_t)piece * 2 + (size_t)(poly & 1)) * M;
 #pragma unroll
@@ -80,9 +99,11 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
   constexpr int N = G::N, M = G::M, T = G::T;
   __shared__ double s_re[G::kPlane], s_im[G::kPlane];
   __shared__ int32_t s_acc[2][N];
+  __shared__ double s_twn[kGenStageTw<LOGN> ? 2 * kGenTwLds : 2];
   const int t = threadIdx.x;
   auto sync = [] { gen_sync<T>(); };
   auto wsync = [] { gen_wave_sync(); };
+  const double* twn = gen_stage_twiddles<LOGN>(s_twn, a.tw, t);
   const int l = a.l, bgbit = a.bgbit, n = a.n;
   const uint32_t goff = gen_gadget_offset(l, bgbit);
   double dev = 0.0;
@@ -131,25 +152,60 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll 1
       for (int comp = 0; comp < 2; ++comp) {
         int32_t v[kRegs];   // prepared rotated difference of this component, shared by its l digit rows
+        {
+          // all 32 accumulator words first, then the arithmetic: left to itself the compiler read them one at a time, each
+          // behind a full s_waitcnt (24 exposed LDS round trips per component; the ISA timeline of profiles/r03 shows it)
+          const int32_t* accc = s_acc[comp];
+          const int aa = bara & (N - 1), nb = (bara >> LOGN) & 1;
+          uint32_t rot[kRegs], own[kRegs];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int j = t + T * (r & 7) + (r >> 3) * M;
-          v[r] = gen_gadget_prepare(gen_rotated_diff(s_acc[comp], j, bara, LOGN), goff);
+          for (int r = 0; r < 16; ++r) {
+            const int j = t + T * (r & 7) + (r >> 3) * M;
+            rot[r] = (uint32_t)accc[(j - aa) & (N - 1)];
+            own[r] = (uint32_t)accc[j];
+          }
+          gen_wave_sync();   // compiler-only: keep the reads together, ahead of their uses
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int j = t + T * (r & 7) + (r >> 3) * M;
+            const int neg = (j < aa ? 1 : 0) ^ nb;
+            v[r] = gen_gadget_prepare((int32_t)((neg ? (0u - rot[r]) : rot[r]) - own[r]), goff);   // gen_rotated_diff, same arithmetic
+          }
         }
 #pragma unroll 1
         for (int q = 0; q < l; ++q) {
           double x[kRegs];
 #pragma unroll
           for (int r = 0; r < 16; ++r) x[r] = (double)gen_gadget_digit(v[r], q, bgbit);
-          gen_fft_fwd<LOGN>(x, t, a.tw, s_re, s_im, sync, wsync);
           const double2* kp = reinterpret_cast<const double2*>(a.bk_x) + ((size_t)i * 2 * l + (size_t)comp * l + q) * 4 * M;
+#ifdef RS_GEN_PREFETCH0   // A/B: the first position's key values requested ahead of the transform
+          double2 w0[4];
+#pragma unroll
+          for (int hc = 0; hc < 4; ++hc) w0[hc] = kp[(size_t)hc * M + t];
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+          gen_fft_fwd<LOGN>(x, t, a.tw, twn, s_re, s_im, sync, wsync);
+          // both halves x both columns of position r: the loads of position r + 1 are issued before the FMAs of position r
+          // (the compiler's own schedule waited for each group of four in full before its 16 FMAs: eight exposed L2 round trips
+          // per row, most of a CMUX step on the large rings)
+          double2 w[2][4];
+#ifdef RS_GEN_PREFETCH0
+#pragma unroll
+          for (int hc = 0; hc < 4; ++hc) w[0][hc] = w0[hc];
+#else
+#pragma unroll
+          for (int hc = 0; hc < 4; ++hc) w[0][hc] = kp[(size_t)hc * M + t];
+#endif
 #pragma unroll
           for (int r = 0; r < 8; ++r) {
-            double2 w[4];   // both halves x both columns of this position
+            if (r + 1 < 8) {
 #pragma unroll
-            for (int hc = 0; hc < 4; ++hc) w[hc] = kp[(size_t)hc * M + r * T + t];
+              for (int hc = 0; hc < 4; ++hc) w[(r + 1) & 1][hc] = kp[(size_t)hc * M + (r + 1) * T + t];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int hc = 0; hc < 4; ++hc) fft_cmac(S[hc >> 1][hc & 1][r], S[hc >> 1][hc & 1][r + 8], x[r], x[r + 8], w[hc].x, w[hc].y);
+            for (int hc = 0; hc < 4; ++hc) fft_cmac(S[hc >> 1][hc & 1][r], S[hc >> 1][hc & 1][r + 8], x[r], x[r + 8], w[r & 1][hc].x, w[r & 1][hc].y);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
@@ -157,8 +213,8 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
       // every thread passed at least one barrier since its reads of the accumulator: the update cannot overtake them
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        gen_fft_inv<LOGN>(S[0][c], t, a.tw, s_re, s_im, sync, wsync);
-        gen_fft_inv<LOGN>(S[1][c], t, a.tw, s_re, s_im, sync, wsync);
+        gen_fft_inv<LOGN>(S[0][c], t, a.tw, twn, s_re, s_im, sync, wsync);
+        gen_fft_inv<LOGN>(S[1][c], t, a.tw, twn, s_re, s_im, sync, wsync);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int j = t + T * (r & 7) + (r >> 3) * M;
@@ -191,9 +247,11 @@ __global__ __launch_bounds__(Gen<LOGN>::T) void gen_polymul_kernel(const int32_t
   using G = Gen<LOGN>;
   constexpr int N = G::N, M = G::M, T = G::T;
   __shared__ double s_re[G::kPlane], s_im[G::kPlane];
+  __shared__ double s_twn[kGenStageTw<LOGN> ? 2 * kGenTwLds : 2];
   const int t = threadIdx.x;
   auto sync = [] { gen_sync<T>(); };
   auto wsync = [] { gen_wave_sync(); };
+  const double* twn = gen_stage_twiddles<LOGN>(s_twn, tw, t);
   double dev = 0.0;
   for (long idx = blockIdx.x; idx < count; idx += gridDim.x) {
     const int32_t* pa = a_small + idx * N;
@@ -208,14 +266,14 @@ __global__ __launch_bounds__(Gen<LOGN>::T) void gen_polymul_kernel(const int32_t
         gen_split_key(pb[t + T * (r & 7) + (r >> 3) * M], lo, hi);
         x[r] = (double)(piece ? hi : lo);
       }
-      gen_fft_fwd<LOGN>(x, t, tw, s_re, s_im, sync, wsync);
+      gen_fft_fwd<LOGN>(x, t, tw, twn, s_re, s_im, sync, wsync);
 #pragma unroll
       for (int r = 0; r < 8; ++r) key[(size_t)piece * M + r * T + t] = make_double2(x[r] * (1.0 / M), x[r + 8] * (1.0 / M));
     }
     double xa[kRegs];
 #pragma unroll
     for (int r = 0; r < 16; ++r) xa[r] = (double)pa[t + T * (r & 7) + (r >> 3) * M];
-    gen_fft_fwd<LOGN>(xa, t, tw, s_re, s_im, sync, wsync);
+    gen_fft_fwd<LOGN>(xa, t, tw, twn, s_re, s_im, sync, wsync);
     double S[2][kRegs];
 #pragma unroll
     for (int piece = 0; piece < 2; ++piece) {
@@ -226,8 +284,8 @@ __global__ __launch_bounds__(Gen<LOGN>::T) void gen_polymul_kernel(const int32_t
         fft_cmac(S[piece][r], S[piece][r + 8], xa[r], xa[r + 8], w.x, w.y);
       }
     }
-    gen_fft_inv<LOGN>(S[0], t, tw, s_re, s_im, sync, wsync);
-    gen_fft_inv<LOGN>(S[1], t, tw, s_re, s_im, sync, wsync);
+    gen_fft_inv<LOGN>(S[0], t, tw, twn, s_re, s_im, sync, wsync);
+    gen_fft_inv<LOGN>(S[1], t, tw, twn, s_re, s_im, sync, wsync);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int j = t + T * (r & 7) + (r >> 3) * M;

@@ -43,6 +43,23 @@ def build_oracle(force=False):
 
 _lib = None
 _i32p = C.POINTER(C.c_int32)
+
+
+def _cpu_share():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except Exception:
+            pass
+    return n
 _u8p = C.POINTER(C.c_uint8)
 
 
@@ -51,6 +68,9 @@ def lib():
     if _lib is not None:
         return _lib
     L = C.CDLL(build_oracle())
+    # OpenMP teams no larger than the CPUs this process may actually use: a GPU box shows 256 hardware threads and grants a
+    # cgroup quota of 16, and a 256-thread team spinning on 16 CPUs makes every parallel region slower than a serial one
+    L.ro_set_threads(C.c_int(_cpu_share()))
     P = C.POINTER(RoParams)
     L.ro_params_default128.argtypes = [P]
     L.ro_params_redsec_small_v2.argtypes = [P]
