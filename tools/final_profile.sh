@@ -18,3 +18,10 @@ python tools/cifar_profile.py binarynet $OUT/cifar_prof > $OUT/${P}_cifar_binary
 find $OUT/cifar_prof -name "*kernel_stats.csv" -exec cp {} $OUT/${P}_cifar_binarynet_driver_kernel_stats.csv \;
 rm -rf $OUT/prof $OUT/cifar_prof
 echo "final profile set done"
+# round 3 additions: general ring kernels at full size (synthetic keys generated on the device), phase stamps if the variant is there
+python tools/general_rate.py > $OUT/${P}_general_path_rates.jsonl 2> $OUT/general_rate.err; cat $OUT/${P}_general_path_rates.jsonl | cut -c1-220
+if [ -f variants/lib_stamps.so ]; then
+  REDSEC_HIP_LIB=$PWD/variants/lib_stamps.so python tools/stamp_profile.py default128 16384 > $OUT/${P}_stamps_wg_default128.json 2>/dev/null
+  REDSEC_HIP_LIB=$PWD/variants/lib_stamps.so python tools/stamp_profile.py redsec_small_v2 16384 > $OUT/${P}_stamps_wg_redsec.json 2>/dev/null
+fi
+echo "round-3 additions done"
