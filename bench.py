@@ -400,7 +400,7 @@ def main():
         # fabric-side traffic of the same launch: rocprofv3 --pmc passes cannot be collected from inside the process, so
         # this is READ FROM THE COMMITTED PROFILE of the same command (tools/pmc_traffic.py), and labelled as such
         traffic, traffic_src = None, None
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             try:
                 path = os.path.join("profiles", rnd, "pmc_traffic.json")
                 pmc = json.load(open(os.path.join(ROOT, path)))
