@@ -184,7 +184,9 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
           for (int hc = 0; hc < 4; ++hc) w0[hc] = kp[(size_t)hc * M + t];
           __builtin_amdgcn_sched_barrier(0);
 #endif
+#ifndef RS_GEN_T_NOFWD   // timing-only probes (wrong results): RS_GEN_T_NOFWD / NOKEY / NOINV drop one phase each
           gen_fft_fwd<LOGN>(x, t, a.tw, twn, s_re, s_im, sync, wsync);
+#endif
           // both halves x both columns of position r: the loads of position r + 1 are issued before the FMAs of position r
           // (the compiler's own schedule waited for each group of four in full before its 16 FMAs: eight exposed L2 round trips
           // per row, most of a CMUX step on the large rings)
@@ -192,6 +194,9 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
 #ifdef RS_GEN_PREFETCH0
 #pragma unroll
           for (int hc = 0; hc < 4; ++hc) w[0][hc] = w0[hc];
+#elif defined(RS_GEN_T_NOKEY)
+#pragma unroll
+          for (int hc = 0; hc < 4; ++hc) w[0][hc] = make_double2(x[hc], x[hc + 8]);
 #else
 #pragma unroll
           for (int hc = 0; hc < 4; ++hc) w[0][hc] = kp[(size_t)hc * M + t];
@@ -199,8 +204,13 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll
           for (int r = 0; r < 8; ++r) {
             if (r + 1 < 8) {
+#ifdef RS_GEN_T_NOKEY
+#pragma unroll
+              for (int hc = 0; hc < 4; ++hc) w[(r + 1) & 1][hc] = make_double2(x[hc + 1], x[hc + 4]);
+#else
 #pragma unroll
               for (int hc = 0; hc < 4; ++hc) w[(r + 1) & 1][hc] = kp[(size_t)hc * M + (r + 1) * T + t];
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -213,8 +223,10 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
       // every thread passed at least one barrier since its reads of the accumulator: the update cannot overtake them
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
+#ifndef RS_GEN_T_NOINV
         gen_fft_inv<LOGN>(S[0][c], t, a.tw, twn, s_re, s_im, sync, wsync);
         gen_fft_inv<LOGN>(S[1][c], t, a.tw, twn, s_re, s_im, sync, wsync);
+#endif
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int j = t + T * (r & 7) + (r >> 3) * M;

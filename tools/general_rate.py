@@ -46,11 +46,15 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
         br, ks = be.last_kernel_ms()
+        try:
+            cert = be.rounding_certificate()
+        except Exception as e:          # timing-only variant builds compute wrong values on purpose
+            cert = "refused: %s" % (str(e)[:60],)
         print(json.dumps({"set": name, "N": p.N, "l": p.bk_l, "Bgbit": p.bk_Bgbit, "n": p.n, "batch": B, "key": "synthetic, generated on the device",
                           "key_load_s": round(load_s, 2), "key_device_GB": round((be.info()["bk_device_bytes"] + be.info()["ksk_device_bytes"]) / 1e9, 2),
                           "launch": be.last_launch(), "blind_rotate_ms": round(br, 3), "keyswitch_ms": round(ks, 3), "wall_ms": round(dt * 1e3, 3),
                           "cmux_steps_per_s": round(B * p.n / (br * 1e-3)), "bootstraps_per_s": round(B / dt, 1),
-                          "split_bound": be.split_bound(), "max_rounding_distance": be.rounding_certificate()}), flush=True)
+                          "split_bound": be.split_bound(), "max_rounding_distance": cert}), flush=True)
         be.close()
         del x, out
         torch.cuda.empty_cache()
