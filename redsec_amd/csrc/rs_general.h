@@ -52,19 +52,50 @@ struct GenPassTw { FftStageTw lv[3]; };
 // `tw` (global memory) the levels above. Fetched from global memory, every pass of every transform waited for an L1/L2 round
 // trip of its own (10 transforms x 3-4 passes per CMUX step).
 constexpr int kGenTwLds = 512;   // complex entries
+// the kernels stage the near levels in LDS for these rings (measured: N = 8192 is faster reading them from the L1-resident table)
+template <int LOGN>
+constexpr bool kGenStageTw = LOGN <= 12;
+// One table entry. On the device a read of the GLOBAL table is written as (uniform base) + (32-bit lane offset), which the
+// compiler turns into one load with a scalar base; indexed as a plain `const double*` it kept a 64-bit address pair per entry
+// (80 pairs live or recomputed per CMUX step at N = 8192, most of that kernel's register spills).
+template <bool GLOBAL>
+RS_HD void gen_tw_fetch(const double* src, unsigned entry, double& wr, double& wi) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RS_GEN_TW_GENERIC)
+  if constexpr (GLOBAL) {
+    typedef double D2 __attribute__((ext_vector_type(2)));
+    typedef const char __attribute__((address_space(1)))* BytePtr;
+    // (An opaque `asm volatile("" : "+v"(offset))` HERE, to stop the hoisting by itself, produced wrong values at N = 8192 with
+    // the full-size key -- all words, deterministically, toy sizes unaffected; not understood, not used. The kernels pass the
+    // thread index through gen_local() once per transform instead, which keeps base + offset in the using block just as well.)
+    const D2 v = *(const D2 __attribute__((address_space(1)))*)((BytePtr)src + entry * 16u);
+    wr = v.x;
+    wi = v.y;
+    return;
+  }
+#endif
+  wr = src[2 * entry];
+  wi = src[2 * entry + 1];
+}
 template <int LOGN, int PASS>
 RS_HD void gen_pass_tw(GenPassTw& w, int t, const double* tw, const double* tw_near) {
   using G = Gen<LOGN>;
   constexpr int H = G::H(PASS), E0 = G::first_level(PASS), SB = G::LOGM - H;
-  const int blk = t >> (H - 3);
+  const unsigned blk = (unsigned)t >> (H - 3);
+#ifdef RS_GEN_TW_FAR_ONLY      // debugging switches: which levels take the scalar-base form
+  constexpr bool kNearGlobal = false, kFarGlobal = true;
+#elif defined(RS_GEN_TW_NEAR_ONLY)
+  constexpr bool kNearGlobal = !kGenStageTw<LOGN>, kFarGlobal = false;
+#else
+  constexpr bool kNearGlobal = !kGenStageTw<LOGN>, kFarGlobal = true;
+#endif
 #pragma unroll
   for (int e = E0; e < 3; ++e) {
-    const int base = (1 << (SB + e)) + (blk << e);
-    const double* src = ((2 << (SB + e)) <= kGenTwLds) ? tw_near : tw;   // compile-time choice per level
+    const unsigned base = (1u << (SB + e)) + (blk << e);
+    const bool staged = (2 << (SB + e)) <= kGenTwLds;   // compile-time per level: from tw_near (LDS where the kernels stage it)
 #pragma unroll
     for (int g = 0; g < (1 << e); g += 2) {
-      w.lv[e].wr[g >> 1] = src[2 * (base + g)];
-      w.lv[e].wi[g >> 1] = src[2 * (base + g) + 1];
+      if (staged) gen_tw_fetch<kNearGlobal>(tw_near, base + g, w.lv[e].wr[g >> 1], w.lv[e].wi[g >> 1]);
+      else gen_tw_fetch<kFarGlobal>(tw, base + g, w.lv[e].wr[g >> 1], w.lv[e].wi[g >> 1]);
     }
   }
 }
@@ -150,28 +181,41 @@ RS_HD void gen_exchange(double (&x)[kRegs], int t, double* pre, double* pim, Syn
 }
 
 // forward: x[r] + i x[r+8] = folded input value t + T r  ->  transform value 8 t + r (bit-reversed-order tree leaves)
-template <int LOGN, class Sync, class WSync>
-RS_HD void gen_fft_fwd(double (&x)[kRegs], int t, const double* tw, const double* tw_near, double* pre, double* pim, Sync sync, WSync wsync) {
+template <int LOGN, bool TAIL_AFTER_EXCHANGE = false, class Sync, class WSync, class Tail>
+RS_HD void gen_fft_fwd(double (&x)[kRegs], int t, const double* tw, const double* tw_near, double* pre, double* pim, Sync sync, WSync wsync,
+                       Tail tail) {
   constexpr int P = Gen<LOGN>::P;
   GenPassTw w;
   gen_pass_tw<LOGN, 0>(w, t, tw, tw_near);
   gen_pass_fwd<LOGN, 0>(x, w);
   if constexpr (P > 1) {
     gen_pass_tw<LOGN, 1>(w, t, tw, tw_near);
+    if constexpr (P == 2 && !TAIL_AFTER_EXCHANGE) tail();
     gen_exchange<LOGN, 0, false>(x, t, pre, pim, sync, wsync);
+    if constexpr (P == 2 && TAIL_AFTER_EXCHANGE) tail();
     gen_pass_fwd<LOGN, 1>(x, w);
   }
   if constexpr (P > 2) {
     gen_pass_tw<LOGN, 2>(w, t, tw, tw_near);
+    if constexpr (P == 3 && !TAIL_AFTER_EXCHANGE) tail();
     gen_exchange<LOGN, 1, false>(x, t, pre, pim, sync, wsync);
+    if constexpr (P == 3 && TAIL_AFTER_EXCHANGE) tail();
     gen_pass_fwd<LOGN, 2>(x, w);
   }
   if constexpr (P > 3) {
     gen_pass_tw<LOGN, 3>(w, t, tw, tw_near);
+    if constexpr (P == 4 && !TAIL_AFTER_EXCHANGE) tail();
     gen_exchange<LOGN, 2, false>(x, t, pre, pim, sync, wsync);
+    if constexpr (P == 4 && TAIL_AFTER_EXCHANGE) tail();
     gen_pass_fwd<LOGN, 3>(x, w);
   }
   static_assert(P <= 4, "at most four passes (N <= 8192)");
+}
+// `tail` runs in front of (or, TAIL_AFTER_EXCHANGE, right behind) the LAST exchange: the caller's chance to request what it consumes right after the transform (key
+// values: their L2 round trip then overlaps the exchange and the last pass instead of following them)
+template <int LOGN, class Sync, class WSync>
+RS_HD void gen_fft_fwd(double (&x)[kRegs], int t, const double* tw, const double* tw_near, double* pre, double* pim, Sync sync, WSync wsync) {
+  gen_fft_fwd<LOGN>(x, t, tw, tw_near, pre, pim, sync, wsync, [] {});
 }
 // inverse (unscaled: 1/M lives in the key): transform value 8 t + r -> folded value t + T r
 template <int LOGN, class Sync, class WSync>

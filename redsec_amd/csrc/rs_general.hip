@@ -31,6 +31,41 @@ __device__ __forceinline__ void gen_sync() {
   if constexpr (T == 64) gen_wave_sync(); else __syncthreads();
 }
 
+// key loads as SGPR base + 32-bit lane offset (global_load ... v_off, s[base:base+1]): the row pointer is the same in every
+// lane, and left as a 64-bit per-lane pointer the compiler kept a VGPR pair and two adds per (half, column, position) stream
+// The thread index as an opaque value: address arithmetic that depends on it is then recomputed where it is used (a few shifts
+// and adds) instead of being hoisted out of the CMUX loop and held -- or spilled -- for the whole kernel.
+__device__ __forceinline__ int gen_local(int t) {
+#ifndef RS_GEN_NO_LOCAL
+  asm volatile("" : "+v"(t));
+#endif
+  return t;
+}
+typedef double GenD2 __attribute__((ext_vector_type(2)));
+typedef const GenD2 __attribute__((address_space(1)))* GenKeyPtr;   // global address space kept through the integer round trip
+__device__ __forceinline__ GenKeyPtr gen_uniform_ptr(const double2* p) {
+  const uint64_t b = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  return (GenKeyPtr)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ GenKeyPtr gen_uniform_ptr(GenKeyPtr p) {   // of an already uniform value: folds to the scalar itself
+  const uint64_t b = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  return (GenKeyPtr)(((uint64_t)hi << 32) | lo);
+}
+// `base` already includes the (half, column, position) displacement; made opaque here so that the optimiser does not move
+// that constant over to the lane offset (which turns every stream back into a 64-bit per-lane pointer)
+__device__ __forceinline__ double2 gen_key_load(GenKeyPtr base, uint32_t lane_bytes) {
+  typedef const char __attribute__((address_space(1)))* BytePtr;
+#ifdef RS_GEN_KEY_GENERIC   // A/B and debugging: the plain per-lane pointer
+  const GenD2 v = *(GenKeyPtr)((BytePtr)base + lane_bytes);
+#else
+  asm volatile("" : "+v"(lane_bytes));   // not hoisted, so that base + offset is selected as ONE load with a scalar base
+  const GenD2 v = *(GenKeyPtr)((BytePtr)gen_uniform_ptr(base) + lane_bytes);
+#endif
+  return make_double2(v.x, v.y);
+}
+
 __device__ __forceinline__ void gen_publish(double dev, unsigned long long* flag) {
   if (!flag) return;
 #pragma unroll
@@ -43,12 +78,10 @@ __device__ __forceinline__ void gen_publish(double dev, unsigned long long* flag
 
 }  // namespace
 
-// Levels 0..8 of the twiddle table staged in LDS (8 KB; rs_general.h, gen_pass_tw). Measured at full size (profiles/r03/
-// f_general_ab.txt): redsec_params_medium +8.9 % (two workgroups per CU, every pass used to wait for an L1/L2 round trip of its
-// own), redsec_params_large -3.9 % (one 512-thread workgroup per CU on 139 KB of LDS already: the extra LDS reads queue behind
-// its exchanges) -- so N = 8192 keeps reading the table from global memory.
-template <int LOGN>
-constexpr bool kGenStageTw = LOGN <= 12;
+// Levels 0..8 of the twiddle table staged in LDS (8 KB; rs_general.h, gen_pass_tw, kGenStageTw). Measured at full size
+// (profiles/r03/f_general_ab_twiddles_in_lds.jsonl): redsec_params_medium +8.9 % (two workgroups per CU, every pass used to wait
+// for an L1/L2 round trip of its own), redsec_params_large -3.9 % (one 512-thread workgroup per CU on 139 KB of LDS already: the
+// extra LDS reads queue behind its exchanges) -- so N = 8192 keeps reading the table from global memory.
 template <int LOGN>
 __device__ __forceinline__ const double* gen_stage_twiddles(double* s_twn, const double* tw, int t) {
   if constexpr (kGenStageTw<LOGN>) {
@@ -93,6 +126,12 @@ __global__ __launch_bounds__(Gen<LOGN>::T) void gen_bk_transform_kernel(const in
   }
 }
 
+#ifndef RS_GEN_LOOKAHEAD
+#define RS_GEN_LOOKAHEAD 2
+#endif
+#ifndef RS_GEN_FIRST_AT
+#define RS_GEN_FIRST_AT 2
+#endif
 template <int LOGN>
 __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2, 2))) void gen_blind_rotate_kernel(GenArgs a) {
   using G = Gen<LOGN>;
@@ -177,44 +216,65 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
           double x[kRegs];
 #pragma unroll
           for (int r = 0; r < 16; ++r) x[r] = (double)gen_gadget_digit(v[r], q, bgbit);
-          const double2* kp = reinterpret_cast<const double2*>(a.bk_x) + ((size_t)i * 2 * l + (size_t)comp * l + q) * 4 * M;
-#ifdef RS_GEN_PREFETCH0   // A/B: the first position's key values requested ahead of the transform
-          double2 w0[4];
+          GenKeyPtr kp = gen_uniform_ptr(reinterpret_cast<const double2*>(a.bk_x) + ((size_t)i * 2 * l + (size_t)comp * l + q) * 4 * M);
+          const uint32_t tb = (uint32_t)t * (uint32_t)sizeof(double2);
+          constexpr int LA = RS_GEN_LOOKAHEAD, NB = LA + 1;   // key positions requested ahead of the one being multiplied
+          double2 w[NB][4];
+          // both halves x both columns of position r; position 0 is requested in front of the transform's last exchange, position
+          // r + LA before the FMAs of position r (the compiler's own schedule waited for each group of four in full before its 16
+          // FMAs: eight exposed L2 round trips per row, most of a CMUX step on the large rings)
+          auto first = [&] {
 #pragma unroll
-          for (int hc = 0; hc < 4; ++hc) w0[hc] = kp[(size_t)hc * M + t];
-          __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifndef RS_GEN_T_NOFWD   // timing-only probes (wrong results): RS_GEN_T_NOFWD / NOKEY / NOINV drop one phase each
-          gen_fft_fwd<LOGN>(x, t, a.tw, twn, s_re, s_im, sync, wsync);
-#endif
-          // both halves x both columns of position r: the loads of position r + 1 are issued before the FMAs of position r
-          // (the compiler's own schedule waited for each group of four in full before its 16 FMAs: eight exposed L2 round trips
-          // per row, most of a CMUX step on the large rings)
-          double2 w[2][4];
-#ifdef RS_GEN_PREFETCH0
-#pragma unroll
-          for (int hc = 0; hc < 4; ++hc) w[0][hc] = w0[hc];
-#elif defined(RS_GEN_T_NOKEY)
-#pragma unroll
-          for (int hc = 0; hc < 4; ++hc) w[0][hc] = make_double2(x[hc], x[hc + 8]);
-#else
-#pragma unroll
-          for (int hc = 0; hc < 4; ++hc) w[0][hc] = kp[(size_t)hc * M + t];
-#endif
-#pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            if (r + 1 < 8) {
+            for (int hc = 0; hc < 4; ++hc) {
 #ifdef RS_GEN_T_NOKEY
-#pragma unroll
-              for (int hc = 0; hc < 4; ++hc) w[(r + 1) & 1][hc] = make_double2(x[hc + 1], x[hc + 4]);
+              w[0][hc] = make_double2(1.0 + hc, 2.0);
 #else
-#pragma unroll
-              for (int hc = 0; hc < 4; ++hc) w[(r + 1) & 1][hc] = kp[(size_t)hc * M + (r + 1) * T + t];
+              w[0][hc] = gen_key_load(kp + (size_t)hc * M, tb);
 #endif
             }
             __builtin_amdgcn_sched_barrier(0);
+          };
+#if RS_GEN_FIRST_AT == 1        // A/B: in front of the whole transform (more spills: measured slower)
+          first();
+#endif
+#ifdef RS_GEN_T_NOFWD           // timing-only probes (wrong results): RS_GEN_T_NOFWD / NOKEY / NOINV drop one phase each
+          first();
+#elif RS_GEN_FIRST_AT == 2
+          gen_fft_fwd<LOGN>(x, gen_local(t), a.tw, twn, s_re, s_im, sync, wsync, first);
+#elif RS_GEN_FIRST_AT == 3    // A/B: behind the last exchange, in front of the last pass's butterflies
+          gen_fft_fwd<LOGN, true>(x, gen_local(t), a.tw, twn, s_re, s_im, sync, wsync, first);
+#else
+          gen_fft_fwd<LOGN>(x, gen_local(t), a.tw, twn, s_re, s_im, sync, wsync);
+#endif
+#if RS_GEN_FIRST_AT == 0        // A/B: behind the transform (the round-3 form before the tail hook)
+          first();
+#endif
 #pragma unroll
-            for (int hc = 0; hc < 4; ++hc) fft_cmac(S[hc >> 1][hc & 1][r], S[hc >> 1][hc & 1][r + 8], x[r], x[r + 8], w[r & 1][hc].x, w[r & 1][hc].y);
+          for (int g = 1; g < LA; ++g) {
+#pragma unroll
+            for (int hc = 0; hc < 4; ++hc) {
+#ifdef RS_GEN_T_NOKEY
+              w[g][hc] = make_double2(x[hc + g], x[hc + 8]);
+#else
+              w[g][hc] = gen_key_load(kp + (size_t)hc * M + g * T, tb);
+#endif
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            if (r + LA < 8) {
+#pragma unroll
+              for (int hc = 0; hc < 4; ++hc) {
+#ifdef RS_GEN_T_NOKEY
+                w[(r + LA) % NB][hc] = make_double2(x[hc + 1], x[hc + 4]);
+#else
+                w[(r + LA) % NB][hc] = gen_key_load(kp + (size_t)hc * M + (r + LA) * T, tb);
+#endif
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int hc = 0; hc < 4; ++hc) fft_cmac(S[hc >> 1][hc & 1][r], S[hc >> 1][hc & 1][r + 8], x[r], x[r + 8], w[r % NB][hc].x, w[r % NB][hc].y);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -224,8 +284,8 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
 #ifndef RS_GEN_T_NOINV
-        gen_fft_inv<LOGN>(S[0][c], t, a.tw, twn, s_re, s_im, sync, wsync);
-        gen_fft_inv<LOGN>(S[1][c], t, a.tw, twn, s_re, s_im, sync, wsync);
+        gen_fft_inv<LOGN>(S[0][c], gen_local(t), a.tw, twn, s_re, s_im, sync, wsync);
+        gen_fft_inv<LOGN>(S[1][c], gen_local(t), a.tw, twn, s_re, s_im, sync, wsync);
 #endif
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
