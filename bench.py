@@ -412,7 +412,7 @@ def main():
                 pass
         kernel_name = {"workgroup": "blind_rotate_wg_kernel", "duo": "blind_rotate_duo_kernel", "per_wave": "blind_rotate_kernel",
                        "coop2": "blind_rotate_coop_kernel", "coop4": "blind_rotate_coop_kernel", "general": "gen_blind_rotate_kernel", "split_workgroup": "blind_rotate_wgs_kernel",
-                       "split_coop": "blind_rotate_coops_kernel"}[launch["form"]]
+                       "split_coop": "blind_rotate_coops_kernel", "split_duo": "blind_rotate_duos_kernel"}[launch["form"]]
         roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel_ms": round(last_br, 3), "algorithmic_bytes_per_launch": int(alg_bytes),

@@ -779,9 +779,8 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
 // Half-row h sits in slot h mod 3 and is requested two half-rows ahead: the barrier that publishes h also says every
 // wave has finished h - 1, whose slot then takes h + 2.
 // -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void mac_half_stream(double (&s0)[kRegs], double (&s1)[kRegs], const double (&x)[kRegs], const double* key, int lane) {
-  const double2* k0 = reinterpret_cast<const double2*>(key);
-  const double2* k1 = k0 + kN / 2;
+// s0 += x * (column at k0), s1 += x * (column at k1): the two columns of one key half-row
+__device__ __forceinline__ void mac_half_stream_cols(double (&s0)[kRegs], double (&s1)[kRegs], const double (&x)[kRegs], const double2* k0, const double2* k1, int lane) {
   double2 u[2][4];
   auto issue = [&](int step, double2 (&w)[4]) {
     const int v = 2 * step;
@@ -803,6 +802,11 @@ __device__ __forceinline__ void mac_half_stream(double (&s0)[kRegs], double (&s1
     fma(step, u[step & 1]);
     RS_MAC_FENCE();
   }
+}
+
+__device__ __forceinline__ void mac_half_stream(double (&s0)[kRegs], double (&s1)[kRegs], const double (&x)[kRegs], const double* key, int lane) {
+  const double2* k0 = reinterpret_cast<const double2*>(key);
+  mac_half_stream_cols(s0, s1, x, k0, k0 + kN / 2, lane);
 }
 
 template <class C, int WPB>
@@ -946,6 +950,185 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
         out[j] = (j == 0) ? acc0[0] : (int32_t)(0u - (uint32_t)acc0[kN - j]);
       }
       if (lane == 0) out[kN] = acc1[0];
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Blind rotation, "duo" form on the SPLIT key (RS_MODE_FFT_SPLIT, 2 x #CUs < B <= 4 x #CUs, N = 1024, any l): a workgroup
+// is 4 ciphertexts x 2 waves, as in blind_rotate_duo_kernel -- wave (c, h) owns accumulator component h of ciphertext c. It
+// transforms the l digit rows of that component (one transform in flight: the four partial sums low / high half x two columns
+// fill 128 registers, as in blind_rotate_wgs_kernel) and multiplies each into all four sums; then it hands the two partials of
+// column 1 - h to its partner, adds the partner's partials of column h to its own, runs the two inverse transforms of column h
+// (low and high half) as one software-pipelined pair and updates component h: acc += round(lo) + (round(hi) << 16).
+// Against the 4-wave lock-step groups that served this batch range (one wave per ciphertext, one wave per SIMD) a wave does
+// half the transforms of a CMUX step and the second wave slot of every SIMD is in use.
+// Key: the 8 waves run in lock step; per (digit row q, key half) a PAIR of 16 KB half-rows -- the one of component 0 and the
+// one of component 1 -- is fetched by direct global->LDS loads, 4 one-KB chunks per wave, into pair slot p & 1 (p numbers the
+// pairs in the order they are consumed). The barrier that publishes pair p also says every wave has finished pair p - 1, whose
+// slot then takes pair p + 1 (an L2-resident half-row lands within one multiply-accumulate phase: measured on the wgs
+// kernel). The partials change hands through the same 64 KB once the last pair of a step has been consumed, low halves first,
+// then high halves (8 waves x 8 KB each time), so the first pair of the next step is requested behind that exchange; it has
+// the inverse transforms, the rotated difference and a forward transform to arrive. Barriers per CMUX step: 2 l + 4.
+// -------------------------------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(512) void blind_rotate_duos_kernel(BlindRotateArgs a) {
+  using Xf = XfFft<C>;
+  constexpr int KPL = 2 * C::L;
+  constexpr int kSlotDoubles = 2 * kN;   // one key half-row: 2 columns x N doubles = 16 KB
+  constexpr int kCts = 4;
+  constexpr int kWin = 64;
+  __shared__ double s_tw[Xf::kTableDoubles + 1];
+  __shared__ __attribute__((aligned(16))) double s_buf[8][Xf::kWgBufDoubles];
+  __shared__ int32_t s_acc[kCts][2][kN];
+  __shared__ __attribute__((aligned(16))) double s_key[4][kSlotDoubles];   // slot 2 (p & 1) + component
+  __shared__ uint16_t s_bara[8][kWin];                                      // one window per wave (the two waves of a ciphertext fill the same values)
+  stage_tables(s_tw, a.tw, 512, Xf::kTableDoubles);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int c = wave >> 1, h = wave & 1;
+  double* buf = s_buf[wave];
+  int32_t* acc = s_acc[c][h];
+  typename Xf::State tw;
+  Xf::init(tw, lane, s_tw, a.tw);
+  const int n = a.n;
+  const long n_groups = (a.B + kCts - 1) / kCts;
+  const long total_pairs = (long)n * C::L * 2;
+  const unsigned lane_off = (unsigned)lane * 16u;
+  auto sync_w = [] { wave_lds_sync(); };
+  // own += x * column h, given += x * column 1 - h of the half-row in `slot`
+  auto mac_cols = [&](double (&own)[kRegs], double (&given)[kRegs], const double (&x)[kRegs], const double* slot) {
+    const double2* k = reinterpret_cast<const double2*>(slot);
+    mac_half_stream_cols(own, given, x, k + h * (kN / 2), k + (1 - h) * (kN / 2), lane);
+  };
+  // pair p = (i L + q) 2 + half holds the half-rows ((i KPL + comp L + q) 2 + half) of comp = 0, 1; this wave fetches chunks
+  // [4 (wave & 3), +4) of component wave >> 2. Consecutive pairs are consecutive half-rows, except across a step (+ 2 l + 1).
+  const int kcomp = wave >> 2;
+  const size_t chunk_off = (size_t)((wave & 3) * 4) * 128;
+  long issued, hrow_next;
+  int within;
+  auto issue_reset = [&] { issued = 0; within = 0; hrow_next = (long)kcomp * C::L * 2; };
+  auto issue_next = [&] {
+    if (issued >= total_pairs) return;
+    glds_chunks<4>(a.bk_x + (size_t)hrow_next * kSlotDoubles + chunk_off, lane_off, s_key[2 * (int)(issued & 1) + kcomp] + chunk_off);
+    ++issued;
+    if (++within == 2 * C::L) { within = 0; hrow_next += 2 * C::L + 1; } else { hrow_next += 1; }
+  };
+
+  for (long group = blockIdx.x; group < n_groups; group += gridDim.x) {
+    const long ct = group * kCts + c;
+    const bool active = ct < a.B;
+    const int32_t* row0 = a.in0 + (active ? ct : 0) * a.W;
+    const int32_t* row1 = a.in1 ? a.in1 + (active ? ct : 0) * a.W : nullptr;
+    auto word = [&](int i) -> int32_t {
+      uint32_t v = (uint32_t)a.c0 * (uint32_t)row0[i];
+      if (row1) v += (uint32_t)a.c1 * (uint32_t)row1[i];
+      return (int32_t)v;
+    };
+    auto fill_window = [&](int i0) {   // bara of steps [i0, i0 + 64): read back by this wave only
+      const int i = i0 + lane;
+      s_bara[wave][lane] = (active && i < n) ? (uint16_t)modswitch_2N(word(i)) : (uint16_t)0;
+    };
+    if (active) {
+      const int32_t barb = modswitch_2N((int32_t)((uint32_t)word(n) + (uint32_t)a.bconst));
+      const int rot = 2 * kN - barb;  // in (0, 2N]
+#pragma unroll
+      for (int r = 0; r < kRegs; ++r) {
+        const int j = lane + 64 * r;
+        acc[j] = h ? test_vector(a, ct, j, rot) : 0;
+      }
+    }
+    fill_window(0);
+    __syncthreads();   // every wave has left the previous group's last exchange and extract before the key buffer is refilled
+    long p = 0;        // pair consumed next; it has been requested, pair p + 1 has not
+    issue_reset();
+    issue_next();
+    // publishes pair p (every wave first waits for its own share; nothing else of this wave is in flight) and requests pair
+    // p + 1 into the other slot unless the step's exchange needs the buffer first (`hold`)
+    auto publish = [&](bool hold) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (!hold) issue_next();
+    };
+
+    for (int i = 0; i < n; ++i) {
+      if ((i & (kWin - 1)) == 0 && i > 0) { wave_lds_sync(); fill_window(i); }
+      wave_lds_sync();
+      const int32_t bara = __builtin_amdgcn_readfirstlane((int)s_bara[wave][i & (kWin - 1)]);
+      const bool work = bara != 0;   // tfhe_blindRotate_FFT skips the identity CMUX (the barriers still run)
+      // partial sums of the column this wave inverts (own = column h) and of the one its partner inverts, low / high key half
+      double lo[kRegs], hi[kRegs], glo[kRegs], ghi[kRegs];
+#pragma unroll
+      for (int u = 0; u < kRegs; ++u) { lo[u] = 0.0; hi[u] = 0.0; glo[u] = 0.0; ghi[u] = 0.0; }
+      int32_t d[kRegs];
+      if (work) {
+#pragma unroll
+        for (int r = 0; r < kRegs; ++r) d[r] = gadget_prepare<C>(rotated_diff(acc, lane + 64 * r, bara));
+      }
+#pragma unroll 1
+      for (int q = 0; q < C::L; ++q) {
+        double x[kRegs];
+        if (work) {
+          Xf::digits(x, d, q);
+          ffwd_planar(lane, x, tw, buf, sync_w);
+        }
+        publish(false);
+        if (work) mac_cols(lo, glo, x, s_key[2 * (int)(p & 1) + h]);
+        ++p;
+        publish(q + 1 == C::L);
+        if (work) mac_cols(hi, ghi, x, s_key[2 * (int)(p & 1) + h]);
+        ++p;
+      }
+      // partial exchange through the key buffer (64 KB = 8 waves x 8 KB), low halves, then high halves: wave (c, h) hands over
+      // its partials of column 1 - h and adds its partner's partials of column h to its own
+      double* mine_xchg = &s_key[0][0] + (size_t)wave * kN;
+      const double* theirs = &s_key[0][0] + (size_t)(wave ^ 1) * kN;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave has consumed the last pair
+      if (work) {
+#pragma unroll
+        for (int u = 0; u < kRegs; ++u) mine_xchg[u * 64 + lane] = glo[u];
+      }
+      __syncthreads();
+      if (work) {
+#pragma unroll
+        for (int u = 0; u < kRegs; ++u) lo[u] += theirs[u * 64 + lane];
+      }
+      __syncthreads();
+      if (work) {
+#pragma unroll
+        for (int u = 0; u < kRegs; ++u) mine_xchg[u * 64 + lane] = ghi[u];
+      }
+      __syncthreads();
+      if (work) {
+#pragma unroll
+        for (int u = 0; u < kRegs; ++u) hi[u] += theirs[u * 64 + lane];
+      }
+      __syncthreads();                             // partials consumed: the key buffer may be refilled
+      issue_next();
+      if (work) {
+        uint32_t a0[kRegs];   // accumulator words read ahead of the inverse transforms (see the workgroup kernel)
+#pragma unroll
+        for (int r = 0; r < kRegs; ++r) a0[r] = (uint32_t)acc[lane + 64 * r];
+        wave_lds_sync();
+        Xf::inverse_pair_wg(lane, lo, hi, tw, buf);
+#pragma unroll
+        for (int r = 0; r < kRegs; ++r)
+          acc[lane + 64 * r] = (int32_t)(a0[r] + (uint32_t)f_to_torus32(lo[r]) + ((uint32_t)f_to_torus32(hi[r]) << 16));
+        wave_lds_sync();
+      }
+    }
+
+    if (active) {
+      // tLweExtractLweSampleIndex(index 0): a'[0] = acc_a[0], a'[j] = -acc_a[N-j], b' = acc_b[0]
+      int32_t* out = a.u_out + ct * (kN + 1);
+      if (h == 0) {
+#pragma unroll
+        for (int r = 0; r < kRegs; ++r) {
+          const int j = lane + 64 * r;
+          out[j] = (j == 0) ? acc[0] : (int32_t)(0u - (uint32_t)acc[kN - j]);
+        }
+      } else if (lane == 0) {
+        out[kN] = acc[0];
+      }
     }
   }
 }
@@ -1581,6 +1764,15 @@ hipError_t launch_blind_rotate_split_wg(int cfg, const BlindRotateArgs& a, int n
     if (cfg == 1) return coop(CfgRedsecV2{});
     if (cfg == 2) return coop(CfgRedsecSmall{});
     return hipErrorNotSupported;
+  }
+  if (!o.no_duo && a.B <= 4L * num_cus) {   // mid-size batches: 4 ciphertexts x 2 waves per workgroup (no_duo: the 4-wave lock-step groups)
+    const long grid = std::min<long>((a.B + 3) / 4, num_cus);
+    if (cfg == 0) hipLaunchKernelGGL((blind_rotate_duos_kernel<CfgDefault128>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    else if (cfg == 1) hipLaunchKernelGGL((blind_rotate_duos_kernel<CfgRedsecV2>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    else if (cfg == 2) hipLaunchKernelGGL((blind_rotate_duos_kernel<CfgRedsecSmall>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    else return hipErrorNotSupported;
+    if (info) { info->form = kFormSplitDuo; info->waves_per_block = 8; info->resident = 4 * grid; }
+    return hipGetLastError();
   }
   const int wpb = (a.B <= 4L * num_cus && !o.no_wg4) ? 4 : 8;
   const long groups = (a.B + wpb - 1) / wpb;

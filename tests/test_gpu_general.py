@@ -385,7 +385,7 @@ def test_split_mode_small_batch_forms(toy, name, seed):
     assert be.last_launch() == {"form": "split_workgroup", "waves_per_block": 8, "resident": 8 * cus}
     coop4 = (2 * l) % 4 == 0
     cases = [(1, "split_coop", 4 if coop4 else 2), (cus, "split_coop", 4 if coop4 else 2), (cus + 1, "split_coop", 2),
-             (2 * cus, "split_coop", 2), (2 * cus + 1, "split_workgroup", 4), (4 * cus, "split_workgroup", 4),
+             (2 * cus, "split_coop", 2), (2 * cus + 1, "split_duo", 8), (3 * cus + 2, "split_duo", 8), (4 * cus, "split_duo", 8),
              (4 * cus + 1, "split_workgroup", 8)]
     for b, form, waves in cases:
         got = be.bootstrap(d[:b], e8)
@@ -399,9 +399,9 @@ def test_split_mode_small_batch_forms(toy, name, seed):
     cc = _dev(ks.encrypt(np.where(rng.integers(0, 2, B) == 1, e8, -e8), 2.0 ** -15, 557))
     luts = _dev(rng.integers(-2**31, 2**31, (3, ks.p.N)).astype(np.int32))
     g_whole, m_whole, l_whole = be.gate("NAND", d, cb), be.mux(d, cb, cc), be.bootstrap_lut(d, luts)
-    for b in (7, cus + 3):
+    for b in (7, cus + 3, 2 * cus + 5):     # the last one through blind_rotate_duos_kernel (4 ciphertexts x 2 waves, ragged last group)
         assert torch.equal(be.gate("NAND", d[:b], cb[:b]), g_whole[:b])
-        assert be.last_launch()["form"] == "split_coop"
+        assert be.last_launch()["form"] == ("split_coop" if b <= 2 * cus else "split_duo")
         assert torch.equal(be.mux(d[:b], cb[:b], cc[:b]), m_whole[:b])
         assert torch.equal(be.bootstrap_lut(d[:b], luts), l_whole[:b])
     if name != "redsec_small":
