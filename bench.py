@@ -82,6 +82,43 @@ def host_cpu_share():
     return n
 
 
+def live_traffic(args, kernel_prefix):
+    """Fabric-side bytes of ONE launch of the dominant kernel, measured now: rocprofv3 --pmc cannot be collected from inside a
+    process, so two child runs (FETCH_SIZE, WRITE_SIZE: separate passes, counters only, as MI355X_MICROARCH.md prescribes) execute
+    one step of the same workload on the same GPU; FETCH_SIZE (KiB) is doubled (the guide's gfx950 correction for wide coalesced
+    reads), WRITE_SIZE is in KiB. Returns None (and says why on stderr) when rocprofv3 is missing or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        print("bench.py: rocprofv3 not on PATH, roofline.traffic falls back to the committed profile", file=sys.stderr)
+        return None
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="redsec_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--no-exact-check", "--no-mnist", "--no-live-traffic",
+               "--params", args.params, "--mode", args.mode, "--gates", str(args.gates), "--seed", str(args.seed)]
+        env = dict(os.environ, TMPDIR="/tmp", REDSEC_BENCH_PMC_CHILD="1")
+        try:
+            r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+            rows = [row for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True) for row in csv.DictReader(open(f))]
+            hit = [float(row["Counter_Value"]) for row in rows if row["Counter_Name"] == counter and kernel_prefix in row["Kernel_Name"]]
+            if r.returncode != 0 or not hit:
+                print("bench.py: rocprofv3 --pmc %s pass failed (rc %d, %d rows), roofline.traffic falls back to the committed profile"
+                      % (counter, r.returncode, len(rows)), file=sys.stderr)
+                return None
+            vals[counter] = hit[0]          # the only blind-rotation launch of that run
+        except Exception as e:              # noqa: BLE001 -- a profiler problem must not fail the benchmark
+            print("bench.py: rocprofv3 --pmc %s pass: %s" % (counter, e), file=sys.stderr)
+            return None
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return int(2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024)
+
+
 def redsec_set_legs(device_index, gates):
     """The second half of BASELINE.json's metric (configs[2]): ONE encrypted MNIST sign1024x1 image, device-resident, through
     the layer chain of redsec_amd/nets.py on the parameter set REDsec ships (1,220 bootstraps in batches of 196 and 1,024;
@@ -178,6 +215,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="gates timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-exact-check", action="store_true", help="skip the exact-NTT mode leg (its throughput and the full-batch cross-check)")
     ap.add_argument("--no-mnist", action="store_true", help="skip the legs on the parameter set REDsec ships: encrypted-MNIST-image latency and the same NAND step (N = 1 only)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not measure roofline.traffic with two rocprofv3 --pmc child runs "
+                    "of one step (N = 1 only, about 40 s); the committed profile's figure is reported instead, labelled as such")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xC0FFEE)
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) and run the output all-gather also at ONE rank: "
                     "walks the N > 1 code path on a one-GPU box (tools/scale_sweep.sh checks it against the plain run)")
@@ -400,7 +439,12 @@ def main():
         # fabric-side traffic of the same launch: rocprofv3 --pmc passes cannot be collected from inside the process, so
         # this is READ FROM THE COMMITTED PROFILE of the same command (tools/pmc_traffic.py), and labelled as such
         traffic, traffic_src = None, None
-        for rnd in ("r03", "r02", "r01"):
+        under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
+        if world == 1 and not args.no_live_traffic and not under_profiler and not os.environ.get("REDSEC_BENCH_PMC_CHILD"):
+            traffic = live_traffic(args, kernel_prefix="blind_rotate")
+            if traffic is not None:
+                traffic_src = "measured_in_this_run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one child run each of one step of the same workload on this GPU"
+        for rnd in (() if traffic is not None else ("r03", "r02", "r01")):
             try:
                 path = os.path.join("profiles", rnd, "pmc_traffic.json")
                 pmc = json.load(open(os.path.join(ROOT, path)))

@@ -5,9 +5,9 @@ set -o pipefail
 P="${1:-h}"; OUT=gpurun_out/final; mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py > $OUT/${P}_wg_fft_bench.json 2> $OUT/bench_default.err && tail -c 400 $OUT/${P}_wg_fft_bench.json && echo
-python bench.py --params redsec_small_v2 > $OUT/${P}_wg_fft_bench_redsec_params.json 2>> $OUT/bench_default.err
-python bench.py --mode exact --cpu-sample 0 > $OUT/${P}_exact_ntt_bench.json 2>> $OUT/bench_default.err
-python bench.py --mode exact --cpu-sample 0 --params redsec_small_v2 > $OUT/${P}_exact_ntt_bench_redsec_params.json 2>> $OUT/bench_default.err
+python bench.py --no-live-traffic --params redsec_small_v2 > $OUT/${P}_wg_fft_bench_redsec_params.json 2>> $OUT/bench_default.err
+python bench.py --no-live-traffic --mode exact --cpu-sample 0 > $OUT/${P}_exact_ntt_bench.json 2>> $OUT/bench_default.err
+python bench.py --no-live-traffic --mode exact --cpu-sample 0 --params redsec_small_v2 > $OUT/${P}_exact_ntt_bench_redsec_params.json 2>> $OUT/bench_default.err
 echo "benches done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-exact-check > $OUT/prof_bench.log 2>&1
 find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/${P}_wg_fft_kernel_stats.csv \;

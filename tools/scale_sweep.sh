@@ -8,7 +8,7 @@ set -o pipefail
 OUT="${1:-gpurun_out/scale_sweep}"; STEPS="${2:-5}"
 mkdir -p "$OUT"
 NGPU=$(python -c "import torch; print(torch.cuda.device_count())")
-COMMON="--steps $STEPS --warmup 1 --cpu-sample 0 --no-mnist"
+COMMON="--steps $STEPS --warmup 1 --cpu-sample 0 --no-mnist --no-live-traffic"
 python bench.py $COMMON > "$OUT/plain_1.json" || exit 1
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 $COMMON --force-dist > "$OUT/forced_dist_1.json" || exit 1
 python - "$OUT" <<'PY' || exit 1
