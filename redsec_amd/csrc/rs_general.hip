@@ -129,6 +129,12 @@ __global__ __launch_bounds__(Gen<LOGN>::T) void gen_bk_transform_kernel(const in
 #ifndef RS_GEN_LOOKAHEAD
 #define RS_GEN_LOOKAHEAD 2
 #endif
+#ifndef RS_GEN_STAGGER_TICKS
+#define RS_GEN_STAGGER_TICKS 0
+#endif
+#ifndef RS_GEN_STAGGER_SLOTS
+#define RS_GEN_STAGGER_SLOTS 32
+#endif
 #ifndef RS_GEN_FIRST_AT
 #define RS_GEN_FIRST_AT 2
 #endif
@@ -146,6 +152,16 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
   const int l = a.l, bgbit = a.bgbit, n = a.n;
   const uint32_t goff = gen_gadget_offset(l, bgbit);
   double dev = 0.0;
+#if RS_GEN_STAGGER_TICKS > 0
+  // De-phase the workgroups that share an L2 (blockIdx.x & 7 = XCD under round-robin dispatch): started together they reach the
+  // multiply-accumulate phases -- where all the key bytes of a CMUX step are pulled from L2 -- at the same moments.
+  {
+    const unsigned slot = (blockIdx.x >> 3) & (RS_GEN_STAGGER_SLOTS - 1);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long wait = (unsigned long long)slot * RS_GEN_STAGGER_TICKS;
+    while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
 
   for (long ct = blockIdx.x; ct < a.B; ct += gridDim.x) {
     const int32_t* row0 = a.in0 + ct * a.W;
