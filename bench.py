@@ -103,7 +103,7 @@ def live_traffic(args, kernel_prefix):
                "--params", args.params, "--mode", args.mode, "--gates", str(args.gates), "--seed", str(args.seed)]
         env = dict(os.environ, TMPDIR="/tmp", REDSEC_BENCH_PMC_CHILD="1")
         try:
-            r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+            r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
             rows = [row for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True) for row in csv.DictReader(open(f))]
             hit = [float(row["Counter_Value"]) for row in rows if row["Counter_Name"] == counter and kernel_prefix in row["Kernel_Name"]]
             if r.returncode != 0 or not hit:

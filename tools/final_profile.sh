@@ -13,6 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 ben
 find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/${P}_wg_fft_kernel_stats.csv \;
 head -4 $OUT/${P}_wg_fft_kernel_stats.csv
 python tools/mnist_latency.py > $OUT/${P}_mnist_latency.txt 2>&1; head -1 $OUT/${P}_mnist_latency.txt
+REDSEC_MODE=split python tools/mnist_latency.py > $OUT/${P}_mnist_latency_split_mode.txt 2>&1; head -1 $OUT/${P}_mnist_latency_split_mode.txt
 python tools/mnist_cpu_baseline.py > $OUT/${P}_mnist_cpu_baseline.txt 2>&1; tail -2 $OUT/${P}_mnist_cpu_baseline.txt
 python tools/cifar_profile.py binarynet $OUT/cifar_prof > $OUT/${P}_cifar_binarynet_driver.txt 2>&1; grep -E "wall|Classification" $OUT/${P}_cifar_binarynet_driver.txt
 find $OUT/cifar_prof -name "*kernel_stats.csv" -exec cp {} $OUT/${P}_cifar_binarynet_driver_kernel_stats.csv \;
