@@ -79,7 +79,7 @@ struct rs_ctx {
   double cert_limit = RS_CERTIFICATE_LIMIT;
   rs::LaunchOpts opts;
   double* d_tw = nullptr;          // exact-NTT tables (kTwTotal doubles)
-  double* d_tw_fft = nullptr;      // FFT tables (kFftTwDoubles doubles)
+  double* d_tw_fft = nullptr;      // FFT tables (kFftTwDoublesAll doubles: the forward / Gentleman-Sande tables, then those of the DIT inverse)
   double* d_bk_ntt = nullptr;      // key in the NTT domain
   double* d_bk_fft = nullptr;      // key in the FFT domain
   // general ring path (rs_general.h): every parameter set has it; sets outside the specialised N = 1024 kernels
@@ -434,8 +434,8 @@ int rs_create(rs_ctx** out, const rs_params* p, int device) {
   c->wgs_cfg = special ? c->cfg : ((p->N == rs::kN && p->bk_l == 3 && p->bk_Bgbit == 10) ? 2 : -1);
   if (special || c->wgs_cfg >= 0) {
     const std::vector<double> fft_tw = rs::make_fft_tables();
-    if (hipMalloc(&c->d_tw_fft, sizeof(double) * rs::kFftTwDoubles) != hipSuccess ||
-        hipMemcpy(c->d_tw_fft, fft_tw.data(), sizeof(double) * rs::kFftTwDoubles, hipMemcpyHostToDevice) != hipSuccess) {
+    if (hipMalloc(&c->d_tw_fft, sizeof(double) * rs::kFftTwDoublesAll) != hipSuccess ||
+        hipMemcpy(c->d_tw_fft, fft_tw.data(), sizeof(double) * rs::kFftTwDoublesAll, hipMemcpyHostToDevice) != hipSuccess) {
       destroy_ctx(c);
       return fail(RS_ERR_HIP, "twiddle table upload failed");
     }

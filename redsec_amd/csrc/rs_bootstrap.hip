@@ -237,6 +237,24 @@ struct XfFft {
   __device__ static __forceinline__ void inverse_pair_wg(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const State& st, double* buf, Seg seg) {
     finv_pair<true>(lane, xa, xb, st, buf, [] { wave_lds_sync(); }, seg);
   }
+  // -DRS_WG_DIT: the lock-step workgroup kernel stages the tables of the decimation-in-time inverse as well (18.9 KB) and runs
+  // its inverse pairs through them: 228 instead of 288 FP64 operations per transform, 14 instead of 8 table reads (rs_fft.h).
+  // Bit-exact (emulator, 78 GPU parity tests) and SLOWER on the same box: 309.7-310.7 against 307.5-308.2 ms per 65,536
+  // default-128 gates, 470.3-471.1 against 467.4-467.8 ms on the REDsec set (profiles/r03/m_ab_dit_inverse_pair.txt) -- the
+  // six extra LDS reads per transform cost more than the 60 FP64 operations save. The Gentleman-Sande pair stays.
+#ifdef RS_WG_DIT
+  static constexpr int kWgTableDoubles = kFftTwDoublesAll;
+#else
+  static constexpr int kWgTableDoubles = kFftTwDoubles;
+#endif
+  template <class Seg>
+  __device__ static __forceinline__ void inverse_pair_wg_dit(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const State& st, double* buf, Seg seg) {
+#ifdef RS_WG_DIT
+    finv_pair_dit<true>(lane, xa, xb, st, buf, [] { wave_lds_sync(); }, seg);
+#else
+    finv_pair<true>(lane, xa, xb, st, buf, [] { wave_lds_sync(); }, seg);
+#endif
+  }
 };
 
 // largest rounding distance of the wave -> device flag (positive doubles order like their bit patterns)
@@ -540,12 +558,13 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
   constexpr int kChunks = kRowDoubles / 128;      // 1 KB pieces = one wave-wide 16-byte load each
   constexpr int kChunksPerWave = kChunks / WPB;
   static_assert(kChunks % WPB == 0 && (kChunksPerWave == 1 || kChunksPerWave == 2 || kChunksPerWave == 4), "waves must split a key row evenly");
-  __shared__ double s_tw[Xf::kTableDoubles + 1];
+  __shared__ double s_tw[Xf::kWgTableDoubles + 1];
   __shared__ __attribute__((aligned(16))) double s_buf[WPB][Xf::kWgBufDoubles];
   __shared__ int32_t s_acc[WPB][2][kN];
   __shared__ __attribute__((aligned(16))) double s_key[2][kRowDoubles];
-  __shared__ uint16_t s_bara[WPB][kSmall];
-  stage_tables(s_tw, a.tw, 64 * WPB, Xf::kTableDoubles);
+  constexpr int kWin = 64;                       // mask words live in a 64-step window, as in the split kernel (leaves LDS for the tables of -DRS_WG_DIT)
+  __shared__ uint16_t s_bara[WPB][kWin];
+  stage_tables(s_tw, a.tw, 64 * WPB, Xf::kWgTableDoubles);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const Field f = a.f;
@@ -606,15 +625,19 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
   for (long group = blockIdx.x; group < n_groups; group += gridDim.x) {
     const long ct = group * WPB + wave;
     const bool active = ct < a.B;
+    const int32_t* row0 = a.in0 + (active ? ct : 0) * a.W;
+    const int32_t* row1 = a.in1 ? a.in1 + (active ? ct : 0) * a.W : nullptr;
+    auto word = [&](int i) -> int32_t {
+      uint32_t v = (uint32_t)a.c0 * (uint32_t)row0[i];
+      if (row1) v += (uint32_t)a.c1 * (uint32_t)row1[i];
+      return (int32_t)v;
+    };
+    auto fill_window = [&](int i0) {   // bara of steps [i0, i0 + 64): only this wave reads its row
+      const int i = i0 + lane;
+      s_bara[wave][lane] = (active && i < n) ? (uint16_t)modswitch_2N(word(i)) : (uint16_t)0;
+    };
+    fill_window(0);
     if (active) {
-      const int32_t* row0 = a.in0 + ct * a.W;
-      const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
-      auto word = [&](int i) -> int32_t {
-        uint32_t v = (uint32_t)a.c0 * (uint32_t)row0[i];
-        if (row1) v += (uint32_t)a.c1 * (uint32_t)row1[i];
-        return (int32_t)v;
-      };
-      for (int i = lane; i < n; i += 64) s_bara[wave][i] = (uint16_t)modswitch_2N(word(i));
       const int32_t barb = modswitch_2N((int32_t)((uint32_t)word(n) + (uint32_t)a.bconst));
       const int rot = 2 * kN - barb;  // in (0, 2N]
 #pragma unroll
@@ -640,10 +663,11 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
     // says every wave has finished reading them, after which the next pair's loads are issued and
     // have the whole next transform pair to land.
     long R = 0;
-    unsigned bara_next = active ? s_bara[wave][0] : 0;   // read one step ahead: its LDS latency is not exposed
+    unsigned bara_next = s_bara[wave][0];   // read one step ahead: its LDS latency is not exposed
     for (int i = 0; i < n; ++i) {
       const int32_t bara = __builtin_amdgcn_readfirstlane((int)bara_next);
-      bara_next = (active && i + 1 < n) ? s_bara[wave][i + 1] : 0;
+      if (((i + 1) & (kWin - 1)) == 0 && i + 1 < n) { wave_lds_sync(); fill_window(i + 1); wave_lds_sync(); }
+      bara_next = (i + 1 < n) ? s_bara[wave][(i + 1) & (kWin - 1)] : 0;
       const bool work = bara != 0;   // tfhe_blindRotate_FFT skips the identity CMUX
       double s0[kRegs], s1[kRegs];
 #pragma unroll
@@ -722,7 +746,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
 
       if (work) {
 #ifdef RS_NO_ACC_AHEAD
-        Xf::inverse_pair_wg(lane, s0, s1, tw, buf, seg);
+        Xf::inverse_pair_wg_dit(lane, s0, s1, tw, buf, seg);
 #pragma unroll
         for (int r = 0; r < kRegs; ++r) {
           const int j = lane + 64 * r;
@@ -737,7 +761,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
 #pragma unroll
         for (int r = 0; r < kRegs; ++r) { a0[r] = (uint32_t)acc0[lane + 64 * r]; a1[r] = (uint32_t)acc1[lane + 64 * r]; }
         wave_lds_sync();
-        Xf::inverse_pair_wg(lane, s0, s1, tw, buf, seg);
+        Xf::inverse_pair_wg_dit(lane, s0, s1, tw, buf, seg);
         RS_STAMP(5);
 #pragma unroll
         for (int r = 0; r < kRegs; ++r) {

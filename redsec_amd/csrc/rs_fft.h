@@ -34,6 +34,14 @@ namespace rs {
 constexpr int kM = kN / 2;           // complex points
 constexpr int kCRegs = 8;            // complex values per lane
 constexpr int kFftTwDoubles = 2 * kM;  // complex twiddle table (interleaved re, im), stage-transposed
+// Tables of the decimation-in-time inverse (finv_pair<.., DIT>), appended to the table above (complex entries):
+//   kDitB + 8 e + c   (c = lane & 7):  e = 0: w16^-c   1: w32^-c   2: w64^-c   3: w64^-(c+8)            w_n = exp(2 pi i / n)
+//   kDitA + 64 e + L  (L = lane):      e = 0: w128^-L  1: w256^-L  2 + k: alpha_k = psi^-(L + 64 k)   6 + k: beta_k = alpha_k w512^-(L + 64 k)
+// (k = 0..3, psi = exp(2 pi i / 2048): the twist the forward transform folds into its twiddles)
+constexpr int kDitB = kM;
+constexpr int kDitA = kM + 32;
+constexpr int kFftDitEntries = 32 + 640;
+constexpr int kFftTwDoublesAll = 2 * (kM + kFftDitEntries);   // 18.9 KB
 
 struct Cplx { double re, im; };
 
@@ -584,6 +592,120 @@ RS_HD void finv_pair(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const T
   fft_exchange_over<PLANAR, kLayB, kLayA, 1, 0, true>(lane, xb, xa, t, buf, sync);
   seg(5);
   fft_inv3<0>(xb, t);
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// Decimation-in-time inverse. The inverse map is (un-twist) o (cyclic inverse DFT of the bit-reversed spectrum): a DIT
+// network pairs the same positions in the same order as the Gentleman-Sande stages above (distance 1, 2, 4 ... 256 in
+// j = 64 a + 8 b + c), so layouts and exchanges are shared; stage t multiplies the upper element by w_(2^(t+1))^-(j mod 2^t)
+// BEFORE the add/subtract: the 6-FMA butterfly of the forward transform instead of the 8-operation one, literal twiddles
+// 1, -i, (+-1 - i)/sqrt2 in the first group, and the un-twist psi^-j folded into the last stage as z = alpha x +- beta y.
+// 228 FP64 operations per lane instead of 288; 14 table reads instead of 8.
+struct FftDitTw { double wr[8], wi[8]; };
+template <int T, class TW>
+RS_HD void fft_dit_tw(const TW& t, FftDitTw& w) {
+  const int c = t.lane & 7, L = t.lane;
+  auto get = [&](int slot, int entry) { w.wr[slot] = t.tw[2 * entry]; w.wi[slot] = t.tw[2 * entry + 1]; };
+  if (T == 3) get(0, kDitB + c);
+  if (T == 4) get(0, kDitB + 8 + c);
+  if (T == 5) { get(0, kDitB + 16 + c); get(1, kDitB + 24 + c); }
+  if (T == 6) get(0, kDitA + L);
+  if (T == 7) get(0, kDitA + 64 + L);
+  if (T == 8) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) get(k, kDitA + 64 * (2 + k) + L);
+  }
+}
+RS_HD void fft_dit_bfly_1(double& xr, double& xi, double& yr, double& yi) {     // w = 1
+  const double ar = xr + yr, ai = xi + yi;
+  yr = xr - yr; yi = xi - yi;
+  xr = ar; xi = ai;
+}
+RS_HD void fft_dit_bfly_mi(double& xr, double& xi, double& yr, double& yi) {    // w = -i: w y = (yi, -yr)
+  const double ar = xr + yi, ai = xi - yr;
+  const double br = xr - yi, bi = xi + yr;
+  xr = ar; xi = ai; yr = br; yi = bi;
+}
+// last stage with the un-twist: positions j = L + 64 k and j + 256 (k < 4) take psi^-j and psi^-(j + 256) = psi^-j e^(-i pi / 4):
+// (x, y) -> (alpha x + beta y, e^(-i pi/4) (alpha x - beta y)), alpha = psi^-j, beta = alpha w512^-j; 14 operations
+RS_HD void fft_dit_bfly_untwist(double& xr, double& xi, double& yr, double& yi, double ar, double ai, double br, double bi) {
+  constexpr double kS = 0x1.6a09e667f3bcdp-1;   // sqrt(1/2)
+  const double pr = __builtin_fma(-ai, xi, ar * xr), pi = __builtin_fma(ai, xr, ar * xi);
+  const double sr = __builtin_fma(-bi, yi, __builtin_fma(br, yr, pr));
+  const double si = __builtin_fma(bi, yr, __builtin_fma(br, yi, pi));
+  const double dr = __builtin_fma(2.0, pr, -sr), di = __builtin_fma(2.0, pi, -si);   // alpha x - beta y
+  yr = __builtin_fma(kS, dr, kS * di);      // (1 - i)/sqrt2 * d
+  yi = __builtin_fma(kS, di, -(kS * dr));
+  xr = sr; xi = si;
+}
+template <int T>
+RS_HD void fft_dit_run(double (&x)[kRegs], const FftDitTw& w) {
+  constexpr int g = T % 3, half = 1 << g;
+  constexpr double kS = 0x1.6a09e667f3bcdp-1;   // sqrt(1/2)
+#pragma unroll
+  for (int k = 0; k < kCRegs; ++k) {
+    if (k & half) continue;                      // k is the lower element of its pair (k, k + half)
+    const int m = k & (half - 1);                // position within the half block = the register part of j mod 2^t
+    double &xr = x[k], &xi = x[k + 8], &yr = x[k + half], &yi = x[k + half + 8];
+    if (T < 3) {
+      // literal twiddles w8^-(m 2^(2-g)): 1, (1 - i)/sqrt2, -i, (-1 - i)/sqrt2
+      const int e = m << (2 - g);
+      if (e == 0) fft_dit_bfly_1(xr, xi, yr, yi);
+      else if (e == 2) fft_dit_bfly_mi(xr, xi, yr, yi);
+      else if (e == 1) fft_bfly_fwd(xr, xi, yr, yi, kS, -kS);
+      else fft_bfly_fwd(xr, xi, yr, yi, -kS, -kS);
+    } else if (T < 8) {
+      // twiddle = (table entry of this lane) x (-i)^(m >> ...) : m = 0 plain; g = 1: m = 1 is the -i sibling;
+      // g = 2: m = 0, 1 take entries 0, 1 and m = 2, 3 their -i siblings
+      const int slot = (g == 2) ? (m & 1) : 0;
+      const bool sib = (g == 1) ? (m == 1) : (g == 2 ? m >= 2 : false);
+      if (!sib) fft_bfly_fwd(xr, xi, yr, yi, w.wr[slot], w.wi[slot]);
+      else fft_bfly_fwd(xr, xi, yr, yi, w.wi[slot], -w.wr[slot]);     // -i w = (wi, -wr)
+    } else {
+      fft_dit_bfly_untwist(xr, xi, yr, yi, w.wr[m], w.wi[m], w.wr[4 + m], w.wi[4 + m]);
+    }
+  }
+}
+// the three stages of inverse group G (2 = C': t = 0-2, 1 = B': t = 3-5, 0 = A': t = 6-8) with the twiddle reads up front
+template <int G, class TW>
+RS_HD void fft_dit3_ahead(double (&x)[kRegs], const TW& t) {
+  constexpr int T0 = 3 * (2 - G);
+  FftDitTw w0, w1, w2;
+  fft_dit_tw<T0>(t, w0); fft_dit_tw<T0 + 1>(t, w1); fft_dit_tw<T0 + 2>(t, w2);
+  fft_dit_run<T0>(x, w0); fft_dit_run<T0 + 1>(x, w1); fft_dit_run<T0 + 2>(x, w2);
+}
+template <bool PLANAR, int L0, int L1, int T, int G, class TW, class Sync>
+RS_HD void fft_exchange_over_dit(int lane, double (&x)[kRegs], double (&y)[kRegs], const TW& t, double* buf, Sync sync) {
+  constexpr int T0 = 3 * (2 - G);
+  FftDitTw w[3];
+  fft_exchange_with<PLANAR, L0, L1, T>(lane, x, buf, sync,
+                                       [&](int k) { if (k == 0) fft_dit_tw<T0>(t, w[0]); else if (k == 1) fft_dit_tw<T0 + 1>(t, w[1]); else fft_dit_tw<T0 + 2>(t, w[2]); },
+                                       [&](int k) { if (k == 0) fft_dit_run<T0>(y, w[0]); else if (k == 1) fft_dit_run<T0 + 1>(y, w[1]); else fft_dit_run<T0 + 2>(y, w[2]); });
+}
+// the pipelined inverse pair of finv_pair, decimation in time (needs the appended tables: kFftTwDoublesAll doubles at t.tw)
+template <bool PLANAR, class TW, class Sync, class Seg = FftNoSeg>
+RS_HD void finv_pair_dit(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TW& t, double* buf, Sync sync, Seg seg = Seg()) {
+  seg(0);
+  fft_dit3_ahead<2>(xa, t);
+  seg(1);
+  fft_exchange_over_dit<PLANAR, kLayC, kLayB, 2, 2>(lane, xa, xb, t, buf, sync);
+  seg(2);
+  fft_exchange_over_dit<PLANAR, kLayC, kLayB, 2, 1>(lane, xb, xa, t, buf, sync);
+  seg(3);
+  fft_exchange_over_dit<PLANAR, kLayB, kLayA, 1, 1>(lane, xa, xb, t, buf, sync);
+  seg(4);
+  fft_exchange_over_dit<PLANAR, kLayB, kLayA, 1, 0>(lane, xb, xa, t, buf, sync);
+  seg(5);
+  fft_dit3_ahead<0>(xb, t);
+}
+// single transform, planar exchanges
+template <class TW, class Sync>
+RS_HD void finv_planar_dit(int lane, double (&x)[kRegs], const TW& t, double* buf, Sync sync) {
+  fft_dit3_ahead<2>(x, t);
+  fpl_exchange<kLayC, kLayB, 2>(lane, x, buf, sync);
+  fft_dit3_ahead<1>(x, t);
+  fpl_exchange<kLayB, kLayA, 1>(lane, x, buf, sync);
+  fft_dit3_ahead<0>(x, t);
 }
 
 // pointwise complex multiply-accumulate: (sr, si) += (xr, xi) * (wr, wi)
