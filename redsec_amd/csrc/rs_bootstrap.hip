@@ -229,8 +229,8 @@ struct XfFft {
     finv_pair<true>(lane, xa, xb, st, buf, [] { wave_lds_sync(); });
   }
   // the same with a segment hook (issue-priority toggling in blind_rotate_wg_kernel)
-  template <class Seg>
-  __device__ static __forceinline__ void fwd_pair_wg(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const State& st, double* buf, Seg seg) {
+  template <class TWS, class Seg>
+  __device__ static __forceinline__ void fwd_pair_wg(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TWS& st, double* buf, Seg seg) {
     ffwd_pair<true>(lane, xa, xb, st, buf, [] { wave_lds_sync(); }, seg);
   }
   template <class Seg>
@@ -247,10 +247,10 @@ struct XfFft {
 #else
   static constexpr int kWgTableDoubles = kFftTwDoubles;
 #endif
-  template <class Seg>
-  __device__ static __forceinline__ void inverse_pair_wg_dit(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const State& st, double* buf, Seg seg) {
+  template <class TWS, class Seg>
+  __device__ static __forceinline__ void inverse_pair_wg_dit(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TWS& st, double* buf, Seg seg) {
 #ifdef RS_WG_DIT
-    finv_pair_dit<true>(lane, xa, xb, st, buf, [] { wave_lds_sync(); }, seg);
+    finv_pair_dit<true>(lane, xa, xb, st.tab, buf, [] { wave_lds_sync(); }, seg);
 #else
     finv_pair<true>(lane, xa, xb, st, buf, [] { wave_lds_sync(); }, seg);
 #endif
@@ -571,8 +571,13 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
   double* buf = s_buf[wave];
   int32_t* acc0 = s_acc[wave][0];
   int32_t* acc1 = s_acc[wave][1];
-  typename Xf::State tw;
-  Xf::init(tw, lane, s_tw, a.tw);
+  typename Xf::State tw_table;
+  Xf::init(tw_table, lane, s_tw, a.tw);
+#ifndef RS_WG_KEEP_TW
+#define RS_WG_KEEP_TW 9   // first stage whose per-lane twiddles stay in registers (3: all 8 values, 6: the last group's 4, 9: none)
+#endif
+  FftTwKept<RS_WG_KEEP_TW> tw;
+  fft_kept_load(tw, tw_table);
   const int n = a.n;
   constexpr uint32_t offset = gadget_offset<C>();
   double dev = 0.0;

@@ -152,6 +152,35 @@ RS_HD void fft_tw_get(const FftTwTable& t, int k, double& wr, double& wi) {
   wi = t.tw[2 * pos + 1];
 }
 
+// Twiddle source that KEEPS the even per-lane entries of stages FIRST..8 in registers and reads the rest from the table: the
+// lock-step workgroup kernel's pairs pass through the same entries again and again, and what an LDS read costs there is
+// issue time of a SIMD whose LDS pipe is the busier unit. FIRST = 3: 8 complex values (32 registers),
+// FIRST = 6: the 4 of the last group (16 registers).
+template <int FIRST>
+struct FftTwKept {
+  FftTwTable tab;
+  double wr[9 - FIRST][2], wi[9 - FIRST][2];
+};
+template <int S, int FIRST>
+RS_HD void fft_tw_get(const FftTwKept<FIRST>& t, int k, double& wr, double& wi) {
+  if (S >= FIRST) { wr = t.wr[S >= FIRST ? S - FIRST : 0][k >> 1]; wi = t.wi[S >= FIRST ? S - FIRST : 0][k >> 1]; }
+  else fft_tw_get<S>(t.tab, k, wr, wi);
+}
+template <int S, int FIRST>
+RS_HD void fft_kept_load_stage(FftTwKept<FIRST>& t) {
+  if (S >= FIRST) {
+    constexpr int ntw = kCRegs >> (3 - S % 3);
+#pragma unroll
+    for (int k = 0; k < ntw; k += 2) fft_tw_get<S>(t.tab, k, t.wr[S >= FIRST ? S - FIRST : 0][k >> 1], t.wi[S >= FIRST ? S - FIRST : 0][k >> 1]);
+  }
+}
+template <int FIRST>
+RS_HD void fft_kept_load(FftTwKept<FIRST>& t, const FftTwTable& tab) {
+  t.tab = tab;
+  fft_kept_load_stage<3>(t); fft_kept_load_stage<4>(t); fft_kept_load_stage<5>(t);
+  fft_kept_load_stage<6>(t); fft_kept_load_stage<7>(t); fft_kept_load_stage<8>(t);
+}
+
 // x[e] = re, x[e+8] = im of the lane's e-th complex value. Stage s in [0,9): pairs (e, e+half),
 // half = 4 >> (s % 3); twiddle index within the stage = e >> (3 - s % 3). Only the EVEN twiddle
 // indices are fetched: index k+1 is i times index k (theta + pi/2), applied by the _i butterflies.
@@ -526,6 +555,15 @@ RS_HD void fft_exchange_over(int lane, double (&x)[kRegs], double (&y)[kRegs], c
                                        [&](int k) { fft_group_run<G, INV>(y, w[k], k); });
 }
 
+// The same with the twiddles of group G kept by the caller: the two transforms of a pipelined pair pass through the same
+// stages of the same lane half a segment apart, so the values fetched for the first one (FETCH) serve the second one too
+// (24 registers across one exchange instead of 8 more 16-byte LDS reads per pair and group).
+template <bool PLANAR, int L0, int L1, int T, int G, bool INV, bool FETCH, class TW, class Sync>
+RS_HD void fft_exchange_over_keep(int lane, double (&x)[kRegs], double (&y)[kRegs], const TW& t, double* buf, Sync sync, FftStageTw (&w)[3]) {
+  fft_exchange_with<PLANAR, L0, L1, T>(lane, x, buf, sync, [&](int k) { if (FETCH) fft_group_tw<G, INV>(t, k, w[k]); },
+                                       [&](int k) { fft_group_run<G, INV>(y, w[k], k); });
+}
+
 // single inverse transform, planar exchanges (duo kernel): each group's twiddles fetched up front
 template <class TW, class Sync>
 RS_HD void finv_planar(int lane, double (&x)[kRegs], const TW& t, double* buf, Sync sync) {
@@ -561,6 +599,7 @@ RS_HD void ffwd_pair(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const T
   fft_fwd3<0>(xa, t);
   seg(1);
   fft_exchange_over<PLANAR, kLayA, kLayB, 1, 0, false>(lane, xa, xb, t, buf, sync);
+#ifdef RS_TW_NO_SHARE   // A/B: every transform fetches its own twiddles
   seg(2);
   fft_exchange_over<PLANAR, kLayA, kLayB, 1, 1, false>(lane, xb, xa, t, buf, sync);
   seg(3);
@@ -573,21 +612,47 @@ RS_HD void ffwd_pair(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const T
 #else
   fft_fwd3_ahead<2>(xb, t);
 #endif
+#else
+  FftStageTw w[3];
+  seg(2);
+  fft_exchange_over_keep<PLANAR, kLayA, kLayB, 1, 1, false, true>(lane, xb, xa, t, buf, sync, w);
+  seg(3);
+  fft_exchange_over_keep<PLANAR, kLayB, kLayC, 2, 1, false, false>(lane, xa, xb, t, buf, sync, w);
+  seg(4);
+  fft_exchange_over_keep<PLANAR, kLayB, kLayC, 2, 2, false, true>(lane, xb, xa, t, buf, sync, w);
+  seg(5);
+  fft_stage_fwd_tw<6>(xb, w[0]); fft_stage_fwd_tw<7>(xb, w[1]); fft_stage_fwd_tw<8>(xb, w[2]);
+#endif
 }
 template <bool PLANAR, class TW, class Sync, class Seg = FftNoSeg>
 RS_HD void finv_pair(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TW& t, double* buf, Sync sync, Seg seg = Seg()) {
   seg(0);
+#ifdef RS_TW_NO_SHARE
 #ifdef RS_NO_TW_AHEAD
   fft_inv3<2>(xa, t);
 #else
   fft_inv3_ahead<2>(xa, t);
 #endif
+#else
+  FftStageTw wk[3];   // group 2 (stages 8, 7, 6) in execution order; xb reuses them in segment 1
+  fft_group_tw<2, true>(t, 0, wk[0]); fft_group_tw<2, true>(t, 1, wk[1]); fft_group_tw<2, true>(t, 2, wk[2]);
+  fft_group_run<2, true>(xa, wk[0], 0); fft_group_run<2, true>(xa, wk[1], 1); fft_group_run<2, true>(xa, wk[2], 2);
+#endif
+#ifdef RS_TW_NO_SHARE
   seg(1);
   fft_exchange_over<PLANAR, kLayC, kLayB, 2, 2, true>(lane, xa, xb, t, buf, sync);
   seg(2);
   fft_exchange_over<PLANAR, kLayC, kLayB, 2, 1, true>(lane, xb, xa, t, buf, sync);
   seg(3);
   fft_exchange_over<PLANAR, kLayB, kLayA, 1, 1, true>(lane, xa, xb, t, buf, sync);
+#else
+  seg(1);
+  fft_exchange_over_keep<PLANAR, kLayC, kLayB, 2, 2, true, false>(lane, xa, xb, t, buf, sync, wk);
+  seg(2);
+  fft_exchange_over_keep<PLANAR, kLayC, kLayB, 2, 1, true, true>(lane, xb, xa, t, buf, sync, wk);
+  seg(3);
+  fft_exchange_over_keep<PLANAR, kLayB, kLayA, 1, 1, true, false>(lane, xa, xb, t, buf, sync, wk);
+#endif
   seg(4);
   fft_exchange_over<PLANAR, kLayB, kLayA, 1, 0, true>(lane, xb, xa, t, buf, sync);
   seg(5);
