@@ -574,7 +574,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
   typename Xf::State tw_table;
   Xf::init(tw_table, lane, s_tw, a.tw);
 #ifndef RS_WG_KEEP_TW
-#define RS_WG_KEEP_TW 9   // first stage whose per-lane twiddles stay in registers (3: all 8 values, 6: the last group's 4, 9: none)
+#define RS_WG_KEEP_TW 3   // first stage whose per-lane twiddles stay in registers (3: all 8 values, 6: the last group's 4, 9: none)
 #endif
   FftTwKept<RS_WG_KEEP_TW> tw;
   fft_kept_load(tw, tw_table);
