@@ -859,6 +859,11 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
   int32_t* acc1 = s_acc[wave][1];
   typename Xf::State tw;
   Xf::init(tw, lane, s_tw, a.tw);
+#ifndef RS_WGS_KEEP_TW
+#define RS_WGS_KEEP_TW 9   // as RS_WG_KEEP_TW, for the forward transforms of this kernel: 6 / 3 spill 41 / 57 registers here, -9 % / -16 % (profiles/r03/n_ab_twiddles_kept_other_kernels.txt)
+#endif
+  FftTwKept<RS_WGS_KEEP_TW> tw_kept;
+  fft_kept_load(tw_kept, tw);
   const int n = a.n;
   const long n_groups = (a.B + WPB - 1) / WPB;
   const long total_half = (long)n * KPL * 2;
@@ -938,7 +943,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
         double x[kRegs];
         if (work) {
           Xf::digits(x, d, q);
-          ffwd_planar(lane, x, tw, buf, sync_w);
+          ffwd_planar(lane, x, tw_kept, buf, sync_w);
         }
         publish();
         if (work) mac_half_stream(sl0, sl1, x, s_key[slot], lane);
@@ -1348,6 +1353,11 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
   int32_t* acc = s_acc[c][h];
   typename Xf::State tw;
   Xf::init(tw, lane, s_tw, a.tw);
+#ifndef RS_DUO_KEEP_TW
+#define RS_DUO_KEEP_TW 9   // as RS_WG_KEEP_TW, for the forward pairs of this kernel: 6 / 3 spill 17 / 56 registers here, no gain on the 1,024-neuron MNIST layer
+#endif
+  FftTwKept<RS_DUO_KEEP_TW> tw_kept;
+  fft_kept_load(tw_kept, tw);
   const int n = a.n;
   constexpr uint32_t offset = gadget_offset<C>();
   double dev = 0.0;
@@ -1417,7 +1427,7 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
         if (work) {
           Xf::digits(xa, d, 2 * p);
           Xf::digits(xb, d, 2 * p + 1);
-          Xf::fwd_pair_wg(lane, xa, xb, tw, buf);
+          Xf::fwd_pair_wg(lane, xa, xb, tw_kept, buf, FftNoSeg());
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                         // quad (i, p) published
