@@ -534,6 +534,18 @@ int rs_emu_fft_twiddle_check() {
   return bad;
 }
 
+// table entries 1, 2, 4, 6 of every general ring against the literals pass 0 uses instead (rs_general.h, gen_pass_tw): mismatches
+int rs_emu_gen_literal_twiddle_check() {
+  int bad = 0;
+  const int idx[4] = {1, 2, 4, 6};
+  for (int logn = rs::kGenMinLogN; logn <= rs::kGenMaxLogN; ++logn) {
+    std::vector<double> tw((size_t)1 << logn);
+    rs::gen_make_twiddles(logn, tw.data());
+    for (int e = 0; e < 4; ++e) bad += tw[2 * idx[e]] != rs::kFftTwU[2 * e] || tw[2 * idx[e] + 1] != rs::kFftTwU[2 * e + 1];
+  }
+  return bad;
+}
+
 // selects the exchange form emulated by the FFT entry points (0 interleaved, 1 planar)
 void rs_emu_set_planar(int on) { g_planar = on; }
 // selects the inverse transform emulated by the FFT entry points (0 Gentleman-Sande, 1 decimation in time)

@@ -80,6 +80,18 @@ template <int LOGN, int PASS>
 RS_HD void gen_pass_tw(GenPassTw& w, int t, const double* tw, const double* tw_near) {
   using G = Gen<LOGN>;
   constexpr int H = G::H(PASS), E0 = G::first_level(PASS), SB = G::LOGM - H;
+#ifndef RS_GEN_NO_LITERAL_TW
+  if constexpr (PASS == 0 && G::P > 1) {
+    // pass 0 is one block for the whole workgroup: its even entries 1, 2, 4, 6 are the same for every ring (an entry does not
+    // depend on M) and are the literals of rs_fft.h -- scalar registers instead of four table reads per transform
+    // (tests/test_emulator.py checks them against gen_make_twiddles)
+    w.lv[0].wr[0] = kFftTwU[0]; w.lv[0].wi[0] = kFftTwU[1];
+    w.lv[1].wr[0] = kFftTwU[2]; w.lv[1].wi[0] = kFftTwU[3];
+    w.lv[2].wr[0] = kFftTwU[4]; w.lv[2].wi[0] = kFftTwU[5];
+    w.lv[2].wr[1] = kFftTwU[6]; w.lv[2].wi[1] = kFftTwU[7];
+    return;
+  }
+#endif
   const unsigned blk = (unsigned)t >> (H - 3);
 #ifdef RS_GEN_TW_FAR_ONLY      // debugging switches: which levels take the scalar-base form
   constexpr bool kNearGlobal = false, kFarGlobal = true;

@@ -129,6 +129,12 @@ def test_fft_twiddle_literals_match_generated_table():
     assert emu_lib.lib().rs_emu_fft_twiddle_check() == 0
 
 
+def test_general_ring_pass0_literals_match_generated_tables():
+    """rs_general.h gen_pass_tw: pass 0 of every general ring takes its even twiddles (table entries 1, 2, 4, 6) from the
+    literals of rs_fft.h instead of the table; they must be the table's values bit for bit, for N = 1024 ... 8192."""
+    assert emu_lib.lib().rs_emu_gen_literal_twiddle_check() == 0
+
+
 def test_fft_planar_exchange_is_bit_identical_to_interleaved():
     """The workgroup kernel moves the re and im planes through one half-size LDS buffer in turn
     (rs_fft.h fpl_exchange); same data movement, so products AND rounding distances are identical."""
