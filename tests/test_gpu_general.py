@@ -247,7 +247,14 @@ def _random_key_parity(name, n, seed):
     ct[2, 5:9] = 0                               # a few identity steps
     mu = ol.to_torus(1, 4096)
     got = be.bootstrap(_dev(ct), mu).cpu().numpy()
-    assert np.array_equal(got, ctx.bootstrap_batch(ct, mu))
+    want = ctx.bootstrap_batch(ct, mu)
+    if not np.array_equal(got, want):
+        # say WHICH side moved before failing: both are deterministic functions of (key, ciphertexts)
+        again_gpu = be.bootstrap(_dev(ct), mu).cpu().numpy()
+        again_cpu = ctx.bootstrap_batch(ct, mu)
+        bad = np.argwhere(got != want)
+        pytest.fail("%d differing words, first at %s; GPU repeat equals first GPU run: %s, equals oracle: %s; oracle repeat equals first oracle run: %s"
+                    % (len(bad), bad[:3].tolist(), np.array_equal(again_gpu, got), np.array_equal(again_gpu, want), np.array_equal(again_cpu, want)))
     be.close()
     ctx.close()
     torch.cuda.empty_cache()
