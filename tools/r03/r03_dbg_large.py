@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """debug: outputs of redsec_large (synthetic key) on 2 ciphertexts, saved per variant for comparison"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, redsec_amd
 tag = sys.argv[1]; n_override = int(sys.argv[2]) if len(sys.argv) > 2 else None
 p = redsec_amd.params("redsec_large")
