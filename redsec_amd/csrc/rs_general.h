@@ -263,6 +263,48 @@ RS_HD void gen_fft_inv(double (&x)[kRegs], int t, const double* tw, const double
   gen_pass_inv<LOGN, 0>(x, w);
 }
 
+// Two inverse transforms side by side (the low- and the high-half sum of one column): every pass's twiddles are fetched once for
+// both, one guard barrier serves the pair, and the two butterfly streams are independent work for the scheduler while the
+// other one's exchange is in flight. The exchanges go through the planes one after the other (each begins with the fence or
+// barrier that lets the previous reader finish).
+template <int LOGN, class Sync, class WSync>
+RS_HD void gen_fft_inv2(double (&xa)[kRegs], double (&xb)[kRegs], int t, const double* tw, const double* tw_near, double* pre, double* pim,
+                        Sync sync, WSync wsync) {
+  constexpr int P = Gen<LOGN>::P;
+  GenPassTw w;
+  if constexpr (P > 2 && !gen_exchange_is_wave_local<LOGN, 0>()) sync();
+  if constexpr (P > 3) {
+    gen_pass_tw<LOGN, 3>(w, t, tw, tw_near);
+    gen_pass_inv<LOGN, 3>(xa, w);
+    gen_pass_inv<LOGN, 3>(xb, w);
+    gen_pass_tw<LOGN, 2>(w, t, tw, tw_near);
+    gen_exchange<LOGN, 2, true>(xa, t, pre, pim, sync, wsync);
+    gen_exchange<LOGN, 2, true>(xb, t, pre, pim, sync, wsync);
+  } else if constexpr (P > 2) {
+    gen_pass_tw<LOGN, 2>(w, t, tw, tw_near);
+  }
+  if constexpr (P > 2) {
+    gen_pass_inv<LOGN, 2>(xa, w);
+    gen_pass_inv<LOGN, 2>(xb, w);
+    gen_pass_tw<LOGN, 1>(w, t, tw, tw_near);
+    gen_exchange<LOGN, 1, true>(xa, t, pre, pim, sync, wsync);
+    gen_exchange<LOGN, 1, true>(xb, t, pre, pim, sync, wsync);
+  } else if constexpr (P > 1) {
+    gen_pass_tw<LOGN, 1>(w, t, tw, tw_near);
+  }
+  if constexpr (P > 1) {
+    gen_pass_inv<LOGN, 1>(xa, w);
+    gen_pass_inv<LOGN, 1>(xb, w);
+    gen_pass_tw<LOGN, 0>(w, t, tw, tw_near);
+    gen_exchange<LOGN, 0, true>(xa, t, pre, pim, sync, wsync);
+    gen_exchange<LOGN, 0, true>(xb, t, pre, pim, sync, wsync);
+  } else {
+    gen_pass_tw<LOGN, 0>(w, t, tw, tw_near);
+  }
+  gen_pass_inv<LOGN, 0>(xa, w);
+  gen_pass_inv<LOGN, 0>(xb, w);
+}
+
 // ---- CMUX pieces for a general ring ----
 // modSwitchFromTorus32(a, 2N)
 RS_HD int32_t gen_modswitch(int32_t a, int logn) {

@@ -300,8 +300,12 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
 #ifndef RS_GEN_T_NOINV
+#ifdef RS_GEN_INV_SINGLE   // A/B: the two halves of a column one after the other
         gen_fft_inv<LOGN>(S[0][c], gen_local(t), a.tw, twn, s_re, s_im, sync, wsync);
         gen_fft_inv<LOGN>(S[1][c], gen_local(t), a.tw, twn, s_re, s_im, sync, wsync);
+#else
+        gen_fft_inv2<LOGN>(S[0][c], S[1][c], gen_local(t), a.tw, twn, s_re, s_im, sync, wsync);
+#endif
 #endif
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
