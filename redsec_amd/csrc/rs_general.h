@@ -93,13 +93,7 @@ RS_HD void gen_pass_tw(GenPassTw& w, int t, const double* tw, const double* tw_n
   }
 #endif
   const unsigned blk = (unsigned)t >> (H - 3);
-#ifdef RS_GEN_TW_FAR_ONLY      // debugging switches: which levels take the scalar-base form
-  constexpr bool kNearGlobal = false, kFarGlobal = true;
-#elif defined(RS_GEN_TW_NEAR_ONLY)
-  constexpr bool kNearGlobal = !kGenStageTw<LOGN>, kFarGlobal = false;
-#else
-  constexpr bool kNearGlobal = !kGenStageTw<LOGN>, kFarGlobal = true;
-#endif
+  constexpr bool kNearGlobal = !kGenStageTw<LOGN>, kFarGlobal = true;   // which levels are read from the global table
 #pragma unroll
   for (int e = E0; e < 3; ++e) {
     const unsigned base = (1u << (SB + e)) + (blk << e);

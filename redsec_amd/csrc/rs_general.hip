@@ -126,6 +126,13 @@ __global__ __launch_bounds__(Gen<LOGN>::T) void gen_bk_transform_kernel(const in
   }
 }
 
+// A/B switches of gen_blind_rotate_kernel (same-box measurements: profiles/r03/f_*, h_*):
+//   RS_GEN_LOOKAHEAD     key positions requested ahead of the one being multiplied (2; 3 spills again and loses)
+//   RS_GEN_FIRST_AT      where a row's first key position is requested: 0 behind the forward transform, 1 in front of it,
+//                        2 in front of its last exchange (default), 3 behind its last exchange
+//   RS_GEN_INV_SINGLE    the two inverse transforms of a column one after the other instead of as a pair
+//   RS_GEN_STAGGER_TICKS de-phase the workgroups of an XCD at kernel start (no effect)
+//   RS_GEN_T_NOKEY / NOFWD / NOINV   timing-only probes (wrong results): drop one phase
 #ifndef RS_GEN_LOOKAHEAD
 #define RS_GEN_LOOKAHEAD 2
 #endif
