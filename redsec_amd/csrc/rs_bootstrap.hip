@@ -63,6 +63,8 @@ struct XfNtt {
   static constexpr bool kPreparedDigits = false;  // digits extracted from the raw rotated difference
   struct State { const double* tw; };
   __device__ static __forceinline__ void init(State& st, int, const double* tw_lds, const double*) { st.tw = tw_lds; }
+  using LatencyState = State;   // the cooperative kernel's twiddle source (XfFft keeps its per-lane twiddles in registers there)
+  __device__ static __forceinline__ void init_latency(LatencyState& st, int lane, const double* tw_lds, const double* tw_g) { init(st, lane, tw_lds, tw_g); }
 
   __device__ static __forceinline__ void fwd_digits(int lane, double (&x)[kRegs], const int32_t (&d)[kRegs], int q, uint32_t offset,
                                                     const State& st, double* buf, const Field& f) {
@@ -157,7 +159,15 @@ struct XfFft {
   using State = FftTwTable;
   __device__ static __forceinline__ void init(State& st, int lane, const double* tw_lds, const double*) { st.tw = tw_lds; st.lane = lane; }
 
-  __device__ static __forceinline__ void fwd_generic(int lane, double (&x)[kRegs], const State& st, double* buf, const Field&) {
+  // One wave per SIMD in the cooperative kernel (512 registers): all eight per-lane twiddles stay in registers
+  using LatencyState = FftTwKept<3>;
+  __device__ static __forceinline__ void init_latency(LatencyState& st, int lane, const double* tw_lds, const double* tw_g) {
+    State t;
+    init(t, lane, tw_lds, tw_g);
+    fft_kept_load(st, t);
+  }
+  template <class TWS>
+  __device__ static __forceinline__ void fwd_generic(int lane, double (&x)[kRegs], const TWS& st, double* buf, const Field&) {
     ffwd_F1(lane, x, st, buf);
     wave_lds_sync();
     ffwd_F2(lane, x, st, buf);
@@ -167,8 +177,9 @@ struct XfFft {
     ffwd_F4(lane, x, st, buf);
     wave_lds_sync();
   }
+  template <class TWS>
   __device__ static __forceinline__ void fwd_digits(int lane, double (&x)[kRegs], const int32_t (&d)[kRegs], int q, uint32_t offset,
-                                                    const State& st, double* buf, const Field& f) {
+                                                    const TWS& st, double* buf, const Field& f) {
 #pragma unroll
     for (int r = 0; r < kRegs; ++r) x[r] = (double)gadget_digit_prepared<C>(d[r], q);
     fwd_generic(lane, x, st, buf, f);
@@ -197,7 +208,8 @@ struct XfFft {
   }
   __device__ static __forceinline__ void mid(double (&)[kRegs], double (&)[kRegs], const Field&) {}
   __device__ static __forceinline__ double partial(double v, const Field&) { return v; }
-  __device__ static __forceinline__ void inverse(int lane, double (&x)[kRegs], const State& st, double* buf, const Field&) {
+  template <class TWS>
+  __device__ static __forceinline__ void inverse(int lane, double (&x)[kRegs], const TWS& st, double* buf, const Field&) {
     finv_I1(lane, x, st, buf);
     wave_lds_sync();
     finv_I2(lane, x, st, buf);
@@ -1510,8 +1522,14 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateAr
   const long ct = blockIdx.x;
   const Field f = a.f;
   double* buf = s_buf[wave];
+#ifdef RS_COOP_KEEP_TW   // A/B: per-lane twiddles in registers (XfFft). Measured: no gain on the 196-neuron MNIST layer, which is
+                         // bound by key streaming (3.31-3.38 against 3.34-3.41 ms, profiles/r03/n_ab_twiddles_kept_other_kernels.txt)
+  typename Xf::LatencyState tw;
+  Xf::init_latency(tw, lane, s_tw, a.tw);
+#else
   typename Xf::State tw;
   Xf::init(tw, lane, s_tw, a.tw);
+#endif
   const int32_t* row0 = a.in0 + ct * a.W;
   const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
   const int n = a.n;
