@@ -513,7 +513,45 @@ static long plane_violations() {
   return bad;
 }
 
+// Wave-local exchanges (rs_general.h, gen_exchange_is_wave_local) rely on every exchange mapping the 512 values of wavefront w to
+// the SAME slots [576 w, 576 (w + 1)): what a wavefront reads in one exchange must be where it alone writes in the next, or
+// its barrier-free stores overwrite data another wavefront is still reading. Counts, over all exchanges of ring 2^LOGN in both
+// directions, the slots a wavefront READS outside its region (always forbidden) and the slots it WRITES outside it in an
+// exchange that runs without workgroup barriers.
+template <int LOGN, int XP>
+long gen_wave_region_violations_xp() {
+  using G = rs::Gen<LOGN>;
+  long bad = 0;
+  if constexpr (XP + 1 < G::P) {
+    const bool local = rs::gen_exchange_is_wave_local<LOGN, XP>();
+    for (int t = 0; t < G::T; ++t) {
+      const int w = t >> 6, lo = 576 * w, hi = 576 * (w + 1);
+      for (int r = 0; r < 8; ++r) {
+        // forward: stores in the layout of pass XP, loads in the layout of pass XP + 1; the inverse swaps the two roles
+        const int p_lay0 = rs::gen_phys(rs::gen_idx(t, G::H(XP), r), G::H(XP + 1));
+        const int p_lay1 = rs::gen_phys(rs::gen_idx(t, G::H(XP + 1), r), G::H(XP + 1));
+        const bool in0 = p_lay0 >= lo && p_lay0 < hi, in1 = p_lay1 >= lo && p_lay1 < hi;
+        bad += !in1;                       // forward reader / inverse writer: its own block region in every exchange
+        if (local) bad += !in0;            // forward writer / inverse reader of a barrier-free exchange
+        bad += p_lay0 < 0 || p_lay0 >= G::kPlane || p_lay1 < 0 || p_lay1 >= G::kPlane;
+      }
+    }
+    bad += gen_wave_region_violations_xp<LOGN, XP + 1>();
+  }
+  return bad;
+}
+
 extern "C" {
+
+long rs_emu_gen_wave_region_violations(int logn) {
+  switch (logn) {
+    case 10: return gen_wave_region_violations_xp<10, 0>();
+    case 11: return gen_wave_region_violations_xp<11, 0>();
+    case 12: return gen_wave_region_violations_xp<12, 0>();
+    case 13: return gen_wave_region_violations_xp<13, 0>();
+  }
+  return -1;
+}
 
 // number of mismatches between (a) the literal twiddles of stages 0-2 and the generated table,
 // (b) odd-indexed table entries and i times their even sibling -- both must be 0

@@ -42,8 +42,17 @@ struct Gen {
 constexpr RS_HD int gen_idx(int t, int H, int r) { return ((t >> (H - 3)) << H) | (r << (H - 3)) | (t & ((1 << (H - 3)) - 1)); }
 // LDS position of logical index idx for the exchange whose READER (forward direction) has parameter Hr: blocks of
 // 2^Hr values are spaced by 2^(Hr-3) extra slots, which makes the 8-byte accesses of both sides conflict-free
-// (rs_fft.h's ppos_t1 / ppos_t2 are the Hr = 6 and Hr = 3 cases).
+// (rs_fft.h's ppos_t1 / ppos_t2 are the Hr = 6 and Hr = 3 cases). EVERY exchange pads, also Hr >= 8 where the banks would not
+// need it: a block of 2^h values then occupies the same 9/8 2^h slots in every exchange, so the region a wavefront reads in
+// one exchange is the region it writes in the next -- which is what lets the exchanges whose groups fit a wavefront run
+// without workgroup barriers. (Until round 3's last day Hr >= 8 was left unpadded: the wave-local stores of exchange 1 then
+// landed in slots that ANOTHER wave could still be reading as exchange 0's data -- a write-after-read race seen as a rare
+// wrong product at N = 4096 / 8192, caught by the enforced rounding certificate.)
+#ifdef RS_GEN_UNPADDED_WIDE_EXCHANGE   // the racy form, kept only to reproduce the failure (tools/r03/r03_race_repro.py)
 constexpr RS_HD int gen_phys(int idx, int Hr) { return Hr < 8 ? idx + ((idx >> Hr) << (Hr - 3)) : idx; }
+#else
+constexpr RS_HD int gen_phys(int idx, int Hr) { return idx + ((idx >> Hr) << (Hr - 3)); }
+#endif
 
 // the (at most four) EVEN twiddles of one pass: level e of the pass uses blocks (blk << e) | g, g < 2^e; odd g is
 // i times its even sibling and is applied by the _i butterflies (rs_fft.h)
@@ -53,8 +62,11 @@ struct GenPassTw { FftStageTw lv[3]; };
 // trip of its own (10 transforms x 3-4 passes per CMUX step).
 constexpr int kGenTwLds = 512;   // complex entries
 // the kernels stage the near levels in LDS for these rings (measured: N = 8192 is faster reading them from the L1-resident table)
+#ifndef RS_GEN_STAGE_TW_MAX_LOGN
+#define RS_GEN_STAGE_TW_MAX_LOGN 12   // A/B: 13 stages them for N = 8192 too, 9 for no ring
+#endif
 template <int LOGN>
-constexpr bool kGenStageTw = LOGN <= 12;
+constexpr bool kGenStageTw = LOGN <= RS_GEN_STAGE_TW_MAX_LOGN;
 // One table entry. On the device a read of the GLOBAL table is written as (uniform base) + (32-bit lane offset), which the
 // compiler turns into one load with a scalar base; indexed as a plain `const double*` it kept a 64-bit address pair per entry
 // (80 pairs live or recomputed per CMUX step at N = 8192, most of that kernel's register spills).

@@ -129,6 +129,16 @@ def test_fft_twiddle_literals_match_generated_table():
     assert emu_lib.lib().rs_emu_fft_twiddle_check() == 0
 
 
+@pytest.mark.parametrize("logn", [10, 11, 12, 13])
+def test_general_ring_exchanges_keep_every_wavefront_in_its_own_region(logn):
+    """rs_general.h: the exchanges whose groups fit one wavefront run without workgroup barriers. That is only safe if every
+    exchange maps the 512 values of wavefront w to the same slots [576 w, 576 (w + 1)) -- the region it reads in the previous
+    exchange and alone writes in the next. (With the exchanges of reader parameter >= 8 left unpadded, as they were for most of
+    round 3, the barrier-free stores of exchange 1 overwrote slots another wavefront could still be reading as exchange 0's
+    data at N = 4096 / 8192: a rare wrong product. This check fails on that layout.)"""
+    assert emu_lib.lib().rs_emu_gen_wave_region_violations(logn) == 0
+
+
 def test_general_ring_pass0_literals_match_generated_tables():
     """rs_general.h gen_pass_tw: pass 0 of every general ring takes its even twiddles (table entries 1, 2, 4, 6) from the
     literals of rs_fft.h instead of the table; they must be the table's values bit for bit, for N = 1024 ... 8192."""
