@@ -385,18 +385,28 @@ __global__ __launch_bounds__(256) void sumpool_kernel(int32_t* __restrict__ out,
 // -------------------------------------------------------------------------------------------------
 hipError_t launch_keyswitch(const KeyswitchArgs& a, hipStream_t st) {
   if (a.B <= 0) return hipSuccess;
+  // small batches: slice the input coefficients until enough workgroups exist (latency form); the slices add their partial
+  // sums into a zeroed output with integer atomics
+  auto slice = [&](dim3& g, unsigned want, int min_per_slice) -> hipError_t {
+    unsigned split = 1;
+    while (split < 64 && g.x * g.y * split < want && a.N / (int)(2 * split) >= min_per_slice) split *= 2;
+    if (split > 1) {
+      hipError_t e = hipMemsetAsync(a.out, 0, (size_t)a.B * a.W * sizeof(int32_t), st);
+      if (e != hipSuccess) return e;
+      g.z = split;
+    }
+    return hipSuccess;
+  };
+  // (basebit = 1, the (18, 1) keys of redsec_params_small / medium / large: a digit is one bit and the selected row is the same
+  // for every lane, so a form that reads the rows with SCALAR loads and adds them under the execution mask -- no LDS at all --
+  // was built and measured in round 3: bit-exact, and slower than the tiled kernel, 21.7 against 14.7 ms per 1,024 medium
+  // ciphertexts, 44.7 against 29.1 ms per 512 large ones, 9.8 against 2.2 ms per 4,096 small ones: two 64-byte scalar loads per
+  // (i, j) with ~100 scalar registers to keep three rows in flight is latency-bound. Removed again; profiles/r03/t_*.)
   dim3 grid((unsigned)((a.B + KS_TILE_THREADS - 1) / KS_TILE_THREADS), (unsigned)((a.W + KS_CH - 1) / KS_CH), 1);
   // tiled forms: the two shipped shapes and (18, 1) of redsec_params_small / medium / large; any power-of-two ring
   const bool tiled = (a.t == 8 && a.basebit == 2) || (a.t == 9 && a.basebit == 3) || (a.t == 18 && a.basebit == 1);
   if (tiled) {
-    // small batches: slice the input coefficients until ~1024 workgroups exist (latency form)
-    unsigned split = 1;
-    while (split < 64 && grid.x * grid.y * split < 1024) split *= 2;
-    if (split > 1) {
-      hipError_t e = hipMemsetAsync(a.out, 0, (size_t)a.B * a.W * sizeof(int32_t), st);
-      if (e != hipSuccess) return e;
-      grid.z = split;
-    }
+    if (hipError_t e = slice(grid, 1024, 4); e != hipSuccess) return e;
   }
   if (tiled && a.t == 8) {
     hipLaunchKernelGGL((keyswitch_tiled_kernel<8, 2, 4>), grid, dim3(KS_TILE_THREADS), 0, st, a);
