@@ -185,6 +185,7 @@ rs_ctx** redsec_fleet_of(const TFheGateBootstrappingCloudKeySet* bk, int* count)
 void redsec_materialize(void* host_array);
 // resident slabs and cached device blocks of a context, released before the context itself (called by the keyset deleters)
 void redsec_pool_release(rs_ctx* ctx);
+double redsec_take_setup_seconds(void);   /* seconds of device-context creation + key upload since the last call (REDSEC_TRACE) */
 void redsec_pack(int32_t* words, const LweSample* s, int32_t n);
 void redsec_unpack(LweSample* s, const int32_t* words, int32_t n);
 

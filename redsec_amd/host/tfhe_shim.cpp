@@ -12,6 +12,7 @@
 
 #include <initializer_list>
 #include <map>
+#include <chrono>
 #include <mutex>
 #include <random>
 #include <string>
@@ -19,6 +20,11 @@
 #include <vector>
 
 #include "redsec_hip.h"
+
+// seconds spent creating device contexts and uploading / transforming keys since the last call (REDSEC_TRACE reports them apart
+// from a layer's own staging: they happen once per process, inside whichever call touches the GPU first)
+static double g_setup_seconds = 0.0;
+double redsec_take_setup_seconds() { const double v = g_setup_seconds; g_setup_seconds = 0.0; return v; }
 
 namespace {
 
@@ -142,10 +148,12 @@ rs_ctx* ctx_of_fft(const LweBootstrappingKeyFFT* cf) {
   }
   if (devices.empty()) { const char* dev = getenv("REDSEC_DEVICE"); devices.push_back(dev ? atoi(dev) : 0); }
   rs_ctx** fleet = (rs_ctx**)calloc(devices.size(), sizeof(rs_ctx*));
+  const auto t_setup = std::chrono::steady_clock::now();
   for (size_t i = 0; i < devices.size(); ++i) {
     if (rs_create(&fleet[i], &rp, devices[i]) != 0) die("rs_create");
     if (rs_load_keys(fleet[i], f->src->bk_words, f->src->ksk_words) != 0) die("rs_load_keys");
   }
+  g_setup_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup).count();
   f->fleet = fleet;
   f->fleet_size = (int)devices.size();
   f->ctx = fleet[0];
