@@ -131,6 +131,8 @@ __global__ __launch_bounds__(Gen<LOGN>::T) void gen_bk_transform_kernel(const in
 //   RS_GEN_FIRST_AT      where a row's first key position is requested: 0 behind the forward transform, 1 in front of it,
 //                        2 in front of its last exchange (default), 3 behind its last exchange
 //   RS_GEN_INV_SINGLE    the two inverse transforms of a column one after the other instead of as a pair
+//   RS_GEN_ROW0_AHEAD    the whole key row of a step's first digit requested at the start of the step, into the registers the
+//                        column sums do not need yet (bit-exact; measured 1.2-1.5 % SLOWER: off)
 //   RS_GEN_STAGGER_TICKS de-phase the workgroups of an XCD at kernel start (no effect)
 //   RS_GEN_T_NOKEY / NOFWD / NOINV   timing-only probes (wrong results): drop one phase
 #ifndef RS_GEN_LOOKAHEAD
@@ -204,17 +206,9 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
       bara_next = (i + 1 < n) ? gen_modswitch(word(i + 1), LOGN) : 0;
       if (bara == 0) continue;   // tfhe_blindRotate_FFT skips the identity CMUX (uniform over the workgroup)
       double S[2][2][kRegs];     // [key half][column]
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int u = 0; u < kRegs; ++u) S[h][c][u] = 0.0;
-
-#pragma unroll 1
-      for (int comp = 0; comp < 2; ++comp) {
-        int32_t v[kRegs];   // prepared rotated difference of this component, shared by its l digit rows
-        {
+      const uint32_t tb = (uint32_t)t * (uint32_t)sizeof(double2);
+      // prepared rotated difference of one component, shared by its l digit rows
+      auto prep = [&](int comp, int32_t (&v)[kRegs]) {
           // all 32 accumulator words first, then the arithmetic: left to itself the compiler read them one at a time, each
           // behind a full s_waitcnt (24 exposed LDS round trips per component; the ISA timeline of profiles/r03 shows it)
           const int32_t* accc = s_acc[comp];
@@ -233,14 +227,13 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
             const int neg = (j < aa ? 1 : 0) ^ nb;
             v[r] = gen_gadget_prepare((int32_t)((neg ? (0u - rot[r]) : rot[r]) - own[r]), goff);   // gen_rotated_diff, same arithmetic
           }
-        }
-#pragma unroll 1
-        for (int q = 0; q < l; ++q) {
+      };
+      // one digit row: transform, then both key halves x both columns multiplied into S
+      auto row = [&](int comp, int q, const int32_t (&v)[kRegs]) {
           double x[kRegs];
 #pragma unroll
           for (int r = 0; r < 16; ++r) x[r] = (double)gen_gadget_digit(v[r], q, bgbit);
           GenKeyPtr kp = gen_uniform_ptr(reinterpret_cast<const double2*>(a.bk_x) + ((size_t)i * 2 * l + (size_t)comp * l + q) * 4 * M);
-          const uint32_t tb = (uint32_t)t * (uint32_t)sizeof(double2);
           constexpr int LA = RS_GEN_LOOKAHEAD, NB = LA + 1;   // key positions requested ahead of the one being multiplied
           double2 w[NB][4];
           // both halves x both columns of position r; position 0 is requested in front of the transform's last exchange, position
@@ -300,8 +293,50 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
             for (int hc = 0; hc < 4; ++hc) fft_cmac(S[hc >> 1][hc & 1][r], S[hc >> 1][hc & 1][r + 8], x[r], x[r + 8], w[r % NB][hc].x, w[r % NB][hc].y);
             __builtin_amdgcn_sched_barrier(0);
           }
-        }
+      };
+      int32_t v[kRegs];
+#ifdef RS_GEN_ROW0_AHEAD
+      // The column sums are not alive between the accumulator update and the first multiply of the next step: the WHOLE key row of
+      // the step's first digit (32 loads, 128 registers) is requested here, across the rotated difference and the first forward
+      // transform, and that row's products INITIALISE the sums position by position as its key registers die.
+      {
+        GenKeyPtr kp0 = gen_uniform_ptr(reinterpret_cast<const double2*>(a.bk_x) + ((size_t)i * 2 * l) * 4 * M);
+        double2 wpre[8][4];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+          for (int hc = 0; hc < 4; ++hc) wpre[r][hc] = gen_key_load(kp0 + (size_t)hc * M + r * T, tb);
+        __builtin_amdgcn_sched_barrier(0);
+        prep(0, v);
+        double x[kRegs];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = (double)gen_gadget_digit(v[r], 0, bgbit);
+        gen_fft_fwd<LOGN>(x, gen_local(t), a.tw, twn, s_re, s_im, sync, wsync);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+          for (int hc = 0; hc < 4; ++hc) {
+            // fft_cmac on a zero sum, written as the initialisation it is
+            S[hc >> 1][hc & 1][r] = __builtin_fma(-x[r + 8], wpre[r][hc].y, __builtin_fma(x[r], wpre[r][hc].x, 0.0));
+            S[hc >> 1][hc & 1][r + 8] = __builtin_fma(x[r + 8], wpre[r][hc].x, __builtin_fma(x[r], wpre[r][hc].y, 0.0));
+          }
       }
+#pragma unroll 1
+      for (int q = 1; q < l; ++q) row(0, q, v);
+#else
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int u = 0; u < kRegs; ++u) S[h][c][u] = 0.0;
+      prep(0, v);
+#pragma unroll 1
+      for (int q = 0; q < l; ++q) row(0, q, v);
+#endif
+      prep(1, v);
+#pragma unroll 1
+      for (int q = 0; q < l; ++q) row(1, q, v);
 
       // every thread passed at least one barrier since its reads of the accumulator: the update cannot overtake them
 #pragma unroll
