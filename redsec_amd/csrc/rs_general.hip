@@ -159,6 +159,17 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
   auto wsync = [] { gen_wave_sync(); };
   const double* twn = gen_stage_twiddles<LOGN>(s_twn, a.tw, t);
   const int l = a.l, bgbit = a.bgbit, n = a.n;
+  // Pass 1's four twiddles of this thread stay in registers for the whole kernel where the table is read from global memory
+  // (N = 8192: +0.8 %; where the near levels are staged in LDS the 9-15 registers it spills cost more than the reads: -0.7 % at
+  // N = 4096, profiles/r03/h_general_ab_pass1_twiddles_kept.txt). RS_GEN_KEEP_PASS1=0/1 forces it off / on for every ring.
+#ifndef RS_GEN_KEEP_PASS1
+  constexpr bool kKeepPass1 = !kGenStageTw<LOGN> && Gen<LOGN>::P > 1;
+#else
+  constexpr bool kKeepPass1 = (RS_GEN_KEEP_PASS1 != 0) && Gen<LOGN>::P > 1;
+#endif
+  GenPassTw tw_pass1;
+  if constexpr (kKeepPass1) gen_pass_tw<LOGN, 1>(tw_pass1, t, a.tw, twn);
+  const GenPassTw* kept1 = kKeepPass1 ? &tw_pass1 : nullptr;
   const uint32_t goff = gen_gadget_offset(l, bgbit);
   double dev = 0.0;
 #if RS_GEN_STAGGER_TICKS > 0
@@ -256,9 +267,9 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
 #ifdef RS_GEN_T_NOFWD           // timing-only probes (wrong results): RS_GEN_T_NOFWD / NOKEY / NOINV drop one phase each
           first();
 #elif RS_GEN_FIRST_AT == 2
-          gen_fft_fwd<LOGN>(x, gen_local(t), a.tw, twn, s_re, s_im, sync, wsync, first);
+          gen_fft_fwd<LOGN>(x, gen_local(t), a.tw, twn, s_re, s_im, sync, wsync, first, kept1);
 #elif RS_GEN_FIRST_AT == 3    // A/B: behind the last exchange, in front of the last pass's butterflies
-          gen_fft_fwd<LOGN, true>(x, gen_local(t), a.tw, twn, s_re, s_im, sync, wsync, first);
+          gen_fft_fwd<LOGN, true>(x, gen_local(t), a.tw, twn, s_re, s_im, sync, wsync, first, kept1);
 #else
           gen_fft_fwd<LOGN>(x, gen_local(t), a.tw, twn, s_re, s_im, sync, wsync);
 #endif
@@ -346,7 +357,7 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
         gen_fft_inv<LOGN>(S[0][c], gen_local(t), a.tw, twn, s_re, s_im, sync, wsync);
         gen_fft_inv<LOGN>(S[1][c], gen_local(t), a.tw, twn, s_re, s_im, sync, wsync);
 #else
-        gen_fft_inv2<LOGN>(S[0][c], S[1][c], gen_local(t), a.tw, twn, s_re, s_im, sync, wsync);
+        gen_fft_inv2<LOGN>(S[0][c], S[1][c], gen_local(t), a.tw, twn, s_re, s_im, sync, wsync, kept1);
 #endif
 #endif
 #pragma unroll
