@@ -119,11 +119,12 @@ RS_HD void gen_pass_tw(GenPassTw& w, int t, const double* tw, const double* tw_n
 }
 template <int LOGN, int PASS>
 RS_HD void gen_pass_tw(GenPassTw& w, int t, const double* tw) { gen_pass_tw<LOGN, PASS>(w, t, tw, tw); }
-// the same, or the caller's kept copy of pass 1's values (a thread's twiddles of a pass are the same for every transform: the
+// the same, or the caller's kept copy of ONE pass's values (a thread's twiddles of a pass are the same for every transform: the
 // blind rotation keeps pass 1's four in registers instead of reading them for each of the ten transforms of a CMUX step)
+struct GenKeptTw { const GenPassTw* w; int pass; };   // w == nullptr: nothing kept
 template <int LOGN, int PASS>
-RS_HD void gen_pass_tw_k(GenPassTw& w, int t, const double* tw, const double* tw_near, const GenPassTw* kept1) {
-  if (PASS == 1 && kept1) w = *kept1;
+RS_HD void gen_pass_tw_k(GenPassTw& w, int t, const double* tw, const double* tw_near, GenKeptTw kept) {
+  if (kept.w && PASS == kept.pass) w = *kept.w;
   else gen_pass_tw<LOGN, PASS>(w, t, tw, tw_near);
 }
 template <int LOGN, int PASS>
@@ -208,27 +209,27 @@ RS_HD void gen_exchange(double (&x)[kRegs], int t, double* pre, double* pim, Syn
 // forward: x[r] + i x[r+8] = folded input value t + T r  ->  transform value 8 t + r (bit-reversed-order tree leaves)
 template <int LOGN, bool TAIL_AFTER_EXCHANGE = false, class Sync, class WSync, class Tail>
 RS_HD void gen_fft_fwd(double (&x)[kRegs], int t, const double* tw, const double* tw_near, double* pre, double* pim, Sync sync, WSync wsync,
-                       Tail tail, const GenPassTw* kept1 = nullptr) {
+                       Tail tail, GenKeptTw kept = GenKeptTw{nullptr, 0}) {
   constexpr int P = Gen<LOGN>::P;
   GenPassTw w;
   gen_pass_tw<LOGN, 0>(w, t, tw, tw_near);
   gen_pass_fwd<LOGN, 0>(x, w);
   if constexpr (P > 1) {
-    gen_pass_tw_k<LOGN, 1>(w, t, tw, tw_near, kept1);
+    gen_pass_tw_k<LOGN, 1>(w, t, tw, tw_near, kept);
     if constexpr (P == 2 && !TAIL_AFTER_EXCHANGE) tail();
     gen_exchange<LOGN, 0, false>(x, t, pre, pim, sync, wsync);
     if constexpr (P == 2 && TAIL_AFTER_EXCHANGE) tail();
     gen_pass_fwd<LOGN, 1>(x, w);
   }
   if constexpr (P > 2) {
-    gen_pass_tw<LOGN, 2>(w, t, tw, tw_near);
+    gen_pass_tw_k<LOGN, 2>(w, t, tw, tw_near, kept);
     if constexpr (P == 3 && !TAIL_AFTER_EXCHANGE) tail();
     gen_exchange<LOGN, 1, false>(x, t, pre, pim, sync, wsync);
     if constexpr (P == 3 && TAIL_AFTER_EXCHANGE) tail();
     gen_pass_fwd<LOGN, 2>(x, w);
   }
   if constexpr (P > 3) {
-    gen_pass_tw<LOGN, 3>(w, t, tw, tw_near);
+    gen_pass_tw_k<LOGN, 3>(w, t, tw, tw_near, kept);
     if constexpr (P == 4 && !TAIL_AFTER_EXCHANGE) tail();
     gen_exchange<LOGN, 2, false>(x, t, pre, pim, sync, wsync);
     if constexpr (P == 4 && TAIL_AFTER_EXCHANGE) tail();
@@ -240,12 +241,12 @@ RS_HD void gen_fft_fwd(double (&x)[kRegs], int t, const double* tw, const double
 // values: their L2 round trip then overlaps the exchange and the last pass instead of following them)
 template <int LOGN, class Sync, class WSync>
 RS_HD void gen_fft_fwd(double (&x)[kRegs], int t, const double* tw, const double* tw_near, double* pre, double* pim, Sync sync, WSync wsync) {
-  gen_fft_fwd<LOGN>(x, t, tw, tw_near, pre, pim, sync, wsync, [] {}, nullptr);
+  gen_fft_fwd<LOGN>(x, t, tw, tw_near, pre, pim, sync, wsync, [] {}, GenKeptTw{nullptr, 0});
 }
 // inverse (unscaled: 1/M lives in the key): transform value 8 t + r -> folded value t + T r
 template <int LOGN, class Sync, class WSync>
 RS_HD void gen_fft_inv(double (&x)[kRegs], int t, const double* tw, const double* tw_near, double* pre, double* pim, Sync sync, WSync wsync,
-                       const GenPassTw* kept1 = nullptr) {
+                       GenKeptTw kept = GenKeptTw{nullptr, 0}) {
   constexpr int P = Gen<LOGN>::P;
   GenPassTw w;
   // The inverse STARTS with its wave-local exchanges, whose stores land in block regions that the LAST exchange of a preceding
@@ -253,19 +254,19 @@ RS_HD void gen_fft_inv(double (&x)[kRegs], int t, const double* tw, const double
   // (A preceding forward transform ends with a wave-local exchange of the same groups and needs none; it costs little there.)
   if constexpr (P > 2 && !gen_exchange_is_wave_local<LOGN, 0>()) sync();
   if constexpr (P > 3) {
-    gen_pass_tw<LOGN, 3>(w, t, tw, tw_near);
+    gen_pass_tw_k<LOGN, 3>(w, t, tw, tw_near, kept);
     gen_pass_inv<LOGN, 3>(x, w);
-    gen_pass_tw<LOGN, 2>(w, t, tw, tw_near);
+    gen_pass_tw_k<LOGN, 2>(w, t, tw, tw_near, kept);
     gen_exchange<LOGN, 2, true>(x, t, pre, pim, sync, wsync);
   } else if constexpr (P > 2) {
-    gen_pass_tw<LOGN, 2>(w, t, tw, tw_near);
+    gen_pass_tw_k<LOGN, 2>(w, t, tw, tw_near, kept);
   }
   if constexpr (P > 2) {
     gen_pass_inv<LOGN, 2>(x, w);
-    gen_pass_tw_k<LOGN, 1>(w, t, tw, tw_near, kept1);
+    gen_pass_tw_k<LOGN, 1>(w, t, tw, tw_near, kept);
     gen_exchange<LOGN, 1, true>(x, t, pre, pim, sync, wsync);
   } else if constexpr (P > 1) {
-    gen_pass_tw_k<LOGN, 1>(w, t, tw, tw_near, kept1);
+    gen_pass_tw_k<LOGN, 1>(w, t, tw, tw_near, kept);
   }
   if constexpr (P > 1) {
     gen_pass_inv<LOGN, 1>(x, w);
@@ -283,28 +284,28 @@ RS_HD void gen_fft_inv(double (&x)[kRegs], int t, const double* tw, const double
 // barrier that lets the previous reader finish).
 template <int LOGN, class Sync, class WSync>
 RS_HD void gen_fft_inv2(double (&xa)[kRegs], double (&xb)[kRegs], int t, const double* tw, const double* tw_near, double* pre, double* pim,
-                        Sync sync, WSync wsync, const GenPassTw* kept1 = nullptr) {
+                        Sync sync, WSync wsync, GenKeptTw kept = GenKeptTw{nullptr, 0}) {
   constexpr int P = Gen<LOGN>::P;
   GenPassTw w;
   if constexpr (P > 2 && !gen_exchange_is_wave_local<LOGN, 0>()) sync();
   if constexpr (P > 3) {
-    gen_pass_tw<LOGN, 3>(w, t, tw, tw_near);
+    gen_pass_tw_k<LOGN, 3>(w, t, tw, tw_near, kept);
     gen_pass_inv<LOGN, 3>(xa, w);
     gen_pass_inv<LOGN, 3>(xb, w);
-    gen_pass_tw<LOGN, 2>(w, t, tw, tw_near);
+    gen_pass_tw_k<LOGN, 2>(w, t, tw, tw_near, kept);
     gen_exchange<LOGN, 2, true>(xa, t, pre, pim, sync, wsync);
     gen_exchange<LOGN, 2, true>(xb, t, pre, pim, sync, wsync);
   } else if constexpr (P > 2) {
-    gen_pass_tw<LOGN, 2>(w, t, tw, tw_near);
+    gen_pass_tw_k<LOGN, 2>(w, t, tw, tw_near, kept);
   }
   if constexpr (P > 2) {
     gen_pass_inv<LOGN, 2>(xa, w);
     gen_pass_inv<LOGN, 2>(xb, w);
-    gen_pass_tw_k<LOGN, 1>(w, t, tw, tw_near, kept1);
+    gen_pass_tw_k<LOGN, 1>(w, t, tw, tw_near, kept);
     gen_exchange<LOGN, 1, true>(xa, t, pre, pim, sync, wsync);
     gen_exchange<LOGN, 1, true>(xb, t, pre, pim, sync, wsync);
   } else if constexpr (P > 1) {
-    gen_pass_tw_k<LOGN, 1>(w, t, tw, tw_near, kept1);
+    gen_pass_tw_k<LOGN, 1>(w, t, tw, tw_near, kept);
   }
   if constexpr (P > 1) {
     gen_pass_inv<LOGN, 1>(xa, w);

@@ -159,17 +159,22 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
   auto wsync = [] { gen_wave_sync(); };
   const double* twn = gen_stage_twiddles<LOGN>(s_twn, a.tw, t);
   const int l = a.l, bgbit = a.bgbit, n = a.n;
-  // Pass 1's four twiddles of this thread stay in registers for the whole kernel where the table is read from global memory
-  // (N = 8192: +0.8 %; where the near levels are staged in LDS the 9-15 registers it spills cost more than the reads: -0.7 % at
-  // N = 4096, profiles/r03/h_general_ab_pass1_twiddles_kept.txt). RS_GEN_KEEP_PASS1=0/1 forces it off / on for every ring.
-#ifndef RS_GEN_KEEP_PASS1
-  constexpr bool kKeepPass1 = !kGenStageTw<LOGN> && Gen<LOGN>::P > 1;
+  // The LAST pass's twiddles of this thread stay in registers for the whole kernel where that pass reads the table from GLOBAL
+  // memory (N >= 2048: its levels lie above the LDS-staged ones): same-box +3.7 % at N = 4096 and +3.4 % at N = 8192 -- those loads
+  // were requested one exchange ahead of their use and mostly waited for (profiles/r03/h_general_ab_last_pass_twiddles_kept.txt,
+  // h_general_ab_which_pass_kept.txt). Keeping an LDS-served pass costs more in spilled registers than its reads save (pass 1 or 2
+  // at N = 4096: -0.7 % / -3.8 %). RS_GEN_KEEP_PASS forces a pass (-1: none).
+#ifndef RS_GEN_KEEP_PASS
+  constexpr bool kLastPassGlobal = !kGenStageTw<LOGN> || (2 << (Gen<LOGN>::LOGM - 1)) > kGenTwLds;
+  constexpr int kKeepPass = (Gen<LOGN>::P >= 2 && kLastPassGlobal) ? Gen<LOGN>::P - 1 : -1;
 #else
-  constexpr bool kKeepPass1 = (RS_GEN_KEEP_PASS1 != 0) && Gen<LOGN>::P > 1;
+  constexpr int kKeepPass = Gen<LOGN>::P < 2 ? -1 : RS_GEN_KEEP_PASS;
 #endif
-  GenPassTw tw_pass1;
-  if constexpr (kKeepPass1) gen_pass_tw<LOGN, 1>(tw_pass1, t, a.tw, twn);
-  const GenPassTw* kept1 = kKeepPass1 ? &tw_pass1 : nullptr;
+  GenPassTw tw_kept;
+  if constexpr (kKeepPass == 1) gen_pass_tw<LOGN, 1>(tw_kept, t, a.tw, twn);
+  if constexpr (kKeepPass == 2 && Gen<LOGN>::P > 2) gen_pass_tw<LOGN, 2>(tw_kept, t, a.tw, twn);
+  if constexpr (kKeepPass == 3 && Gen<LOGN>::P > 3) gen_pass_tw<LOGN, 3>(tw_kept, t, a.tw, twn);
+  const GenKeptTw kept1{kKeepPass >= 1 && kKeepPass < Gen<LOGN>::P ? &tw_kept : nullptr, kKeepPass};
   const uint32_t goff = gen_gadget_offset(l, bgbit);
   double dev = 0.0;
 #if RS_GEN_STAGGER_TICKS > 0
