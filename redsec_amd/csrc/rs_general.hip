@@ -147,6 +147,10 @@ __global__ __launch_bounds__(Gen<LOGN>::T) void gen_bk_transform_kernel(const in
 #ifndef RS_GEN_FIRST_AT
 #define RS_GEN_FIRST_AT 2
 #endif
+#ifndef RS_GEN_FIRST_GROUPS
+#define RS_GEN_FIRST_GROUPS 1   // key positions requested at the tail hook (the rest of the lookahead behind the transform); 2: +0.4 % at
+                                // N = 4096, +-0 at N = 8192 for 2-4 more spilled registers (profiles/r03/h_general_ab_two_positions_at_tail.txt)
+#endif
 template <int LOGN>
 __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2, 2))) void gen_blind_rotate_kernel(GenArgs a) {
   using G = Gen<LOGN>;
@@ -255,14 +259,18 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
           // both halves x both columns of position r; position 0 is requested in front of the transform's last exchange, position
           // r + LA before the FMAs of position r (the compiler's own schedule waited for each group of four in full before its 16
           // FMAs: eight exposed L2 round trips per row, most of a CMUX step on the large rings)
+          constexpr int FG = RS_GEN_FIRST_GROUPS < LA ? RS_GEN_FIRST_GROUPS : LA;   // positions requested at the tail hook
           auto first = [&] {
 #pragma unroll
-            for (int hc = 0; hc < 4; ++hc) {
+            for (int g = 0; g < FG; ++g) {
+#pragma unroll
+              for (int hc = 0; hc < 4; ++hc) {
 #ifdef RS_GEN_T_NOKEY
-              w[0][hc] = make_double2(1.0 + hc, 2.0);
+                w[g][hc] = make_double2(1.0 + hc, 2.0 + g);
 #else
-              w[0][hc] = gen_key_load(kp + (size_t)hc * M, tb);
+                w[g][hc] = gen_key_load(kp + (size_t)hc * M + g * T, tb);
 #endif
+              }
             }
             __builtin_amdgcn_sched_barrier(0);
           };
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
           first();
 #endif
 #pragma unroll
-          for (int g = 1; g < LA; ++g) {
+          for (int g = FG; g < LA; ++g) {
 #pragma unroll
             for (int hc = 0; hc < 4; ++hc) {
 #ifdef RS_GEN_T_NOKEY
