@@ -77,7 +77,8 @@ RS_HD void gen_tw_fetch(const double* src, unsigned entry, double& wr, double& w
     typedef double D2 __attribute__((ext_vector_type(2)));
     typedef const char __attribute__((address_space(1)))* BytePtr;
     // (An opaque `asm volatile("" : "+v"(offset))` HERE, to stop the hoisting by itself, produced wrong values at N = 8192 with
-    // the full-size key -- all words, deterministically, toy sizes unaffected; not understood, not used. The kernels pass the
+    // the full-size key -- all words, toy sizes unaffected. Not used; in hindsight most likely the exchange race that gen_phys's
+    // uniform padding removed (it changed the timing of the key-transform kernel), not a fault of the idea. The kernels pass the
     // thread index through gen_local() once per transform instead, which keeps base + offset in the using block just as well.)
     const D2 v = *(const D2 __attribute__((address_space(1)))*)((BytePtr)src + entry * 16u);
     wr = v.x;
