@@ -1505,6 +1505,9 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
 // and 1 sum one column each, run the inverse transform and update the shared accumulator. Two
 // workgroup barriers per CMUX step.
 // -------------------------------------------------------------------------------------------------
+#ifndef RS_COOP_ROTATE_ROWS
+#define RS_COOP_ROTATE_ROWS 1   // 0: every workgroup walks its rows in the same order; 1: rotated by the workgroup index; 2: row groups rotated over the waves too
+#endif
 template <class Xf, int G>
 __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateArgs a) {
   using C = typename Xf::Cfg;
@@ -1533,8 +1536,13 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateAr
   const int32_t* row0 = a.in0 + ct * a.W;
   const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
   const int n = a.n;
-  const int comp = wave / (G / 2);
-  const int row_begin = wave * R;
+#if RS_COOP_ROTATE_ROWS >= 2   // ... and which wave takes which group of rows
+  const int grp = (int)((wave + blockIdx.x) % G);
+#else
+  const int grp = wave;
+#endif
+  const int comp = grp / (G / 2);
+  const int row_begin = grp * R;
   double dev = 0.0;
   auto word = [&](int i) -> int32_t {
     uint32_t v = (uint32_t)a.c0 * (uint32_t)row0[i];
@@ -1567,7 +1575,14 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateAr
     }
 #pragma unroll 1
     for (int rr = 0; rr < R; ++rr) {
+#if RS_COOP_ROTATE_ROWS >= 1   // workgroups walk their rows of a step in different orders (the rows of a step are independent), so that the
+                               // whole chip does not pull the same key rows through the same L2 channels at the same moments: the 196-neuron MNIST
+                               // layer 3.33 -> 3.15 ms (4 alternating runs each; rotating the row groups over the waves as well: 3.24 ms;
+                               // profiles/r03/v_ab_coop_row_rotation.txt)
+      const int row = row_begin + (int)((rr + blockIdx.x) % R);
+#else
       const int row = row_begin + rr;
+#endif
       const int q = row - comp * C::L;
       const double2* bp0 = reinterpret_cast<const double2*>(bk_i + (size_t)(row * 2) * kN);
       const double2* bp1 = bp0 + kN / 2;
