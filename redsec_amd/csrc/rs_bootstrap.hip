@@ -1179,6 +1179,9 @@ __global__ __launch_bounds__(512) void blind_rotate_duos_kernel(BlindRotateArgs 
   }
 }
 
+#ifndef RS_COOP_ROTATE_ROWS
+#define RS_COOP_ROTATE_ROWS 1   // 0: every workgroup walks its rows in the same order; 1: rotated by the workgroup index; 2: row groups rotated over the waves too
+#endif
 // -------------------------------------------------------------------------------------------------
 // Cooperative blind rotation on the SPLIT key (RS_MODE_FFT_SPLIT at latency batch sizes, B <= 2 x #CUs, N = 1024): G waves
 // share ONE ciphertext as in blind_rotate_coop_kernel. Wave g transforms the digit rows [g R, (g+1) R) and multiplies each
@@ -1243,7 +1246,11 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coops_kernel(BlindRotateA
     for (int r = 0; r < kRegs; ++r) d[r] = gadget_prepare<C>(rotated_diff(s_acc[comp], lane + 64 * r, bara));
 #pragma unroll 1
     for (int rr = 0; rr < R; ++rr) {
+#if RS_COOP_ROTATE_ROWS >= 1   // as in blind_rotate_coop_kernel: the rows of a step in an order rotated by the workgroup index
+      const int row = row_begin + (int)((rr + blockIdx.x) % R);
+#else
       const int row = row_begin + rr;
+#endif
       const int q = row - comp * C::L;
       // half-row (row, half) = [column 0: N doubles][column 1: N doubles], pairs (re, im) of position 8 lane + v at [v][lane]
       const double2* lo0 = reinterpret_cast<const double2*>(a.bk_x + ((size_t)i * KPL + row) * 4 * kN);
@@ -1505,9 +1512,6 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
 // and 1 sum one column each, run the inverse transform and update the shared accumulator. Two
 // workgroup barriers per CMUX step.
 // -------------------------------------------------------------------------------------------------
-#ifndef RS_COOP_ROTATE_ROWS
-#define RS_COOP_ROTATE_ROWS 1   // 0: every workgroup walks its rows in the same order; 1: rotated by the workgroup index; 2: row groups rotated over the waves too
-#endif
 template <class Xf, int G>
 __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateArgs a) {
   using C = typename Xf::Cfg;
