@@ -1047,18 +1047,27 @@ __global__ __launch_bounds__(512) void blind_rotate_duos_kernel(BlindRotateArgs 
     const double2* k = reinterpret_cast<const double2*>(slot);
     mac_half_stream_cols(own, given, x, k + h * (kN / 2), k + (1 - h) * (kN / 2), lane);
   };
-  // pair p = (i L + q) 2 + half holds the half-rows ((i KPL + comp L + q) 2 + half) of comp = 0, 1; this wave fetches chunks
-  // [4 (wave & 3), +4) of component wave >> 2. Consecutive pairs are consecutive half-rows, except across a step (+ 2 l + 1).
+  // pair p = (i L + k) 2 + half holds the half-rows ((i KPL + comp L + q_k) 2 + half) of comp = 0, 1, where q_k = (k + rot) mod L:
+  // workgroup b walks the l digits of a step in the order rotated by b (the rows of a step are independent), so that the 256
+  // workgroups of a launch do not pull the same half-rows through the same L2 channels at the same moments (RS_DUOS_ROTATE=0:
+  // the same order everywhere). This wave fetches chunks [4 (wave & 3), +4) of component wave >> 2.
+#ifndef RS_DUOS_ROTATE
+#define RS_DUOS_ROTATE 1
+#endif
+  const int rot = RS_DUOS_ROTATE ? (int)(blockIdx.x % C::L) : 0;
   const int kcomp = wave >> 2;
   const size_t chunk_off = (size_t)((wave & 3) * 4) * 128;
-  long issued, hrow_next;
-  int within;
-  auto issue_reset = [&] { issued = 0; within = 0; hrow_next = (long)kcomp * C::L * 2; };
+  long issued;
+  int iss_i, iss_k;   // step and position (digit slot, half) of the next pair to request
+  auto issue_reset = [&] { issued = 0; iss_i = 0; iss_k = 0; };
   auto issue_next = [&] {
     if (issued >= total_pairs) return;
-    glds_chunks<4>(a.bk_x + (size_t)hrow_next * kSlotDoubles + chunk_off, lane_off, s_key[2 * (int)(issued & 1) + kcomp] + chunk_off);
+    int q = (iss_k >> 1) + rot;
+    if (q >= C::L) q -= C::L;
+    const long hrow = (((long)iss_i * KPL + (long)kcomp * C::L + q) << 1) + (iss_k & 1);
+    glds_chunks<4>(a.bk_x + (size_t)hrow * kSlotDoubles + chunk_off, lane_off, s_key[2 * (int)(issued & 1) + kcomp] + chunk_off);
     ++issued;
-    if (++within == 2 * C::L) { within = 0; hrow_next += 2 * C::L + 1; } else { hrow_next += 1; }
+    if (++iss_k == 2 * C::L) { iss_k = 0; ++iss_i; }
   };
 
   for (long group = blockIdx.x; group < n_groups; group += gridDim.x) {
@@ -1114,7 +1123,9 @@ __global__ __launch_bounds__(512) void blind_rotate_duos_kernel(BlindRotateArgs 
       for (int q = 0; q < C::L; ++q) {
         double x[kRegs];
         if (work) {
-          Xf::digits(x, d, q);
+          int qd = q + rot;
+          if (qd >= C::L) qd -= C::L;
+          Xf::digits(x, d, qd);
           ffwd_planar(lane, x, tw, buf, sync_w);
         }
         publish(false);
@@ -1383,6 +1394,13 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
   const long n_groups = (a.B + kCts - 1) / kCts;
 
   const unsigned lane_off = (unsigned)lane * 16u;
+  // Workgroup b walks the row pairs of a step in the order rotated by b (they are independent), so that the workgroups of a launch
+  // do not pull the same key rows through the same L2 channels at the same moments (RS_DUO_ROTATE=0: the same order everywhere).
+#ifndef RS_DUO_ROTATE
+#define RS_DUO_ROTATE 0   // measured: no effect on the 1,024-neuron MNIST layer (profiles/r03/v_ab_duo_row_rotation.txt), unlike the split forms
+#endif
+  const int prot0 = RS_DUO_ROTATE ? (int)(blockIdx.x % (C::L / 2)) : 0;
+  auto prot = [&](int p) { const int v = p + prot0; return v >= C::L / 2 ? v - C::L / 2 : v; };
   // quad (i, p): rows i KPL + hh L + 2 p + k; this wave fetches half of slot (wave >> 1)
   auto issue_quad = [&](int i, int p) {
     const int slot = wave >> 1;
@@ -1425,7 +1443,7 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
       }
     }
     __syncthreads();   // bara complete; previous group's last reads of the quad buffer are over
-    issue_quad(0, 0);
+    issue_quad(0, prot(0));
 
     unsigned bara_next = active ? s_bara[c][0] : 0;   // read one step ahead
     for (int i = 0; i < n; ++i) {
@@ -1444,8 +1462,8 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
       for (int p = 0; p < C::L / 2; ++p) {
         double xa[kRegs], xb[kRegs];
         if (work) {
-          Xf::digits(xa, d, 2 * p);
-          Xf::digits(xb, d, 2 * p + 1);
+          Xf::digits(xa, d, 2 * prot(p));
+          Xf::digits(xb, d, 2 * prot(p) + 1);
           Xf::fwd_pair_wg(lane, xa, xb, tw_kept, buf, FftNoSeg());
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1459,7 +1477,7 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
 #endif
         }
         __syncthreads();                         // every wave has finished reading it
-        if (p + 1 < C::L / 2) issue_quad(i, p + 1);
+        if (p + 1 < C::L / 2) issue_quad(i, prot(p + 1));
       }
       // partial exchange through the idle quad buffer: wave (c, h) hands over its partial of column 1 - h
       double* xchg = &s_key[0][0] + (size_t)wave * kN;
@@ -1475,7 +1493,7 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
         for (int u = 0; u < kRegs; ++u) mine[u] += theirs[u * 64 + lane];
       }
       __syncthreads();                           // partials consumed: the quad buffer may be refilled
-      if (i + 1 < n) issue_quad(i + 1, 0);
+      if (i + 1 < n) issue_quad(i + 1, prot(0));
       if (work) {
         uint32_t a0[kRegs];   // accumulator words read ahead of the inverse transform (see the workgroup kernel)
 #pragma unroll
