@@ -667,8 +667,25 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
     // all global reads of this prologue are complete and every wave has left the previous group's
     // last multiply-accumulate before the ring is refilled
     __syncthreads();
-    issue_row(0);
-    issue_row(1);
+#ifndef RS_WG_ROTATE
+#define RS_WG_ROTATE 0   // even l: workgroup b walks the row pairs of a component in the order rotated by b. Measured -1.6 % on the REDsec
+                         // set (profiles/r03/v_ab_wg_pair_rotation_redsec.txt): this kernel pulls 16 KB per row and CU with a whole transform
+                         // pair to land, and gains more from every CU finding the row in L2 than it loses to channel contention
+#endif
+    // first row of the pair with running number kk (L pairs per step when l is even): the pairs of a component in rotated order
+    constexpr bool kRotate = RS_WG_ROTATE && C::L % 2 == 0;
+    const int wrot = kRotate ? (int)(blockIdx.x % (C::L / 2 > 0 ? C::L / 2 : 1)) : 0;
+    auto pair_row = [&](long kk) -> long {
+      if constexpr (!kRotate) return 2 * kk;
+      const long i = kk / C::L;
+      const int k = (int)(kk - i * C::L), comp = k / (C::L / 2);
+      int pp = k % (C::L / 2) + wrot;
+      if (pp >= C::L / 2) pp -= C::L / 2;
+      return i * KPL + (long)comp * C::L + 2 * pp;
+    };
+    long kk = 0;
+    issue_row(pair_row(0));
+    issue_row(pair_row(0) + 1);
     RS_STAMP(7);
 #ifdef RS_T_STAGGER   // timing experiments only: start the waves RS_T_STAGGER x 64 cycles apart
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -740,17 +757,18 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
         __syncthreads();
 #endif
         R += 2;
-        if (R < total_rows) { issue_row(R); issue_row(R + 1); }
+        ++kk;
+        if (R < total_rows) { const long Rn = pair_row(kk); issue_row(Rn); issue_row(Rn + 1); }
 #endif
         RS_STAMP(4);
       };
       if constexpr (C::L % 2 == 0) {
         if (work) load_d(std::false_type{});
 #pragma unroll 1
-        for (int q = 0; q < C::L; q += 2) pair(0, q, 0, q + 1);
+        for (int q = 0; q < C::L; q += 2) { int qq = q + 2 * wrot; if (qq >= C::L) qq -= C::L; pair(0, qq, 0, qq + 1); }
         if (work) { Xf::mid(s0, s1, f); load_d(std::true_type{}); }
 #pragma unroll 1
-        for (int q = 0; q < C::L; q += 2) pair(1, q, 1, q + 1);
+        for (int q = 0; q < C::L; q += 2) { int qq = q + 2 * wrot; if (qq >= C::L) qq -= C::L; pair(1, qq, 1, qq + 1); }
       } else {
         // odd l: the middle pair straddles the two accumulator components (no place for Xf::mid:
         // the workgroup form is only instantiated for policies whose mid() is empty)
