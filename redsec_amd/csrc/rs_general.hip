@@ -147,10 +147,6 @@ __global__ __launch_bounds__(Gen<LOGN>::T) void gen_bk_transform_kernel(const in
 #ifndef RS_GEN_FIRST_AT
 #define RS_GEN_FIRST_AT 2
 #endif
-#ifndef RS_GEN_FIRST_GROUPS
-#define RS_GEN_FIRST_GROUPS 1   // key positions requested at the tail hook (the rest of the lookahead behind the transform); 2: +0.4 % at
-                                // N = 4096, +-0 at N = 8192 for 2-4 more spilled registers (profiles/r03/h_general_ab_two_positions_at_tail.txt)
-#endif
 template <int LOGN>
 __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2, 2))) void gen_blind_rotate_kernel(GenArgs a) {
   using G = Gen<LOGN>;
@@ -259,7 +255,12 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
           // both halves x both columns of position r; position 0 is requested in front of the transform's last exchange, position
           // r + LA before the FMAs of position r (the compiler's own schedule waited for each group of four in full before its 16
           // FMAs: eight exposed L2 round trips per row, most of a CMUX step on the large rings)
-          constexpr int FG = RS_GEN_FIRST_GROUPS < LA ? RS_GEN_FIRST_GROUPS : LA;   // positions requested at the tail hook
+#ifdef RS_GEN_FIRST_GROUPS
+          constexpr int kFirstGroups = RS_GEN_FIRST_GROUPS;
+#else
+          constexpr int kFirstGroups = LOGN >= 13 ? 2 : 1;   // N = 8192 (with the row rotation): 458.5 -> 445.7 ms; N = 4096: +0.4 % at best
+#endif
+          constexpr int FG = kFirstGroups < LA ? kFirstGroups : LA;   // positions requested at the tail hook
           auto first = [&] {
 #pragma unroll
             for (int g = 0; g < FG; ++g) {
@@ -347,6 +348,9 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
       }
 #pragma unroll 1
       for (int q = 1; q < l; ++q) row(0, q, v);
+      prep(1, v);
+#pragma unroll 1
+      for (int q = 0; q < l; ++q) row(1, q, v);
 #else
 #pragma unroll
       for (int h = 0; h < 2; ++h)
@@ -354,13 +358,32 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
         for (int c = 0; c < 2; ++c)
 #pragma unroll
           for (int u = 0; u < kRegs; ++u) S[h][c][u] = 0.0;
-      prep(0, v);
-#pragma unroll 1
-      for (int q = 0; q < l; ++q) row(0, q, v);
+      // Workgroup b walks the 2 l rows of a step in its own order (the rows are independent; the sums are exact in any order): started
+      // together, all workgroups otherwise pull the same key rows through the same L2 channels at the same moments. Mode 1 (digit
+      // rotation + component order from b): N = 8192 516.5 -> 458.8 ms per 512 (+12.6 %); at N = 4096 digit rotation costs 8-10 %
+      // (two workgroups per CU and 512 per launch lose more L2 locality than they gain), component order alone +0.4 %
+      // (profiles/r03/h_general_ab_row_rotation_modes.txt). RS_GEN_ROTATE forces a mode: 0 none, 1 both, 2 digits, 3 components.
+      {
+#ifdef RS_GEN_ROTATE
+        constexpr int kRot = RS_GEN_ROTATE;
+#else
+        constexpr int kRot = LOGN >= 13 ? 1 : 3;
 #endif
-      prep(1, v);
+        const int qrot = (kRot == 1 || kRot == 2) ? (int)(blockIdx.x % (unsigned)l) : 0;
+        const int cfirst = kRot == 1 ? (int)((blockIdx.x / (unsigned)l) & 1u) : (kRot == 3 ? (int)(blockIdx.x & 1u) : 0);
 #pragma unroll 1
-      for (int q = 0; q < l; ++q) row(1, q, v);
+        for (int cc = 0; cc < 2; ++cc) {
+          const int comp = cc ^ cfirst;
+          prep(comp, v);
+#pragma unroll 1
+          for (int qi = 0; qi < l; ++qi) {
+            int q = qi + qrot;
+            if (q >= l) q -= l;
+            row(comp, q, v);
+          }
+        }
+      }
+#endif
 
       // every thread passed at least one barrier since its reads of the accumulator: the update cannot overtake them
 #pragma unroll
