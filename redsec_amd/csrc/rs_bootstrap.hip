@@ -929,9 +929,24 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
     __syncthreads();
     long h_issue = 0;        // next half-row to request
     int slot_issue = 0;      // its slot, h_issue mod 3
+#ifndef RS_WGS_ROTATE
+#define RS_WGS_ROTATE 0   // workgroup b walks the l digits of a component in the order rotated by b: measured -11 % / -9 % (default-128 /
+                          // REDsec set, profiles/r03/v_ab_wgs_digit_rotation_split_mode.txt): like the unsplit lock-step kernel this form
+                          // lives on every CU finding the half-row in L2
+#endif
+    const int wrot = RS_WGS_ROTATE ? (int)(blockIdx.x % C::L) : 0;
+    int iss_i = 0, iss_k = 0;   // step and position (component, digit slot, half) of the next half-row to request
     auto issue_next = [&]() {
       if (h_issue < total_half) {
-        glds_chunks<kChunks>(a.bk_x + (size_t)h_issue * kSlotDoubles + (size_t)(wave * kChunks) * 128, lane_off, s_key[slot_issue] + (wave * kChunks) * 128);
+        long hsrc = h_issue;
+        if (RS_WGS_ROTATE) {
+          const int comp = iss_k / (2 * C::L), k = iss_k - comp * 2 * C::L;
+          int q = (k >> 1) + wrot;
+          if (q >= C::L) q -= C::L;
+          hsrc = (((long)iss_i * KPL + (long)comp * C::L + q) << 1) + (k & 1);
+          if (++iss_k == 2 * KPL) { iss_k = 0; ++iss_i; }
+        }
+        glds_chunks<kChunks>(a.bk_x + (size_t)hsrc * kSlotDoubles + (size_t)(wave * kChunks) * 128, lane_off, s_key[slot_issue] + (wave * kChunks) * 128);
         ++h_issue;
         slot_issue = slot_issue == 2 ? 0 : slot_issue + 1;
       }
@@ -972,7 +987,9 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
       auto row = [&](int q) {
         double x[kRegs];
         if (work) {
-          Xf::digits(x, d, q);
+          int qd = q + wrot;
+          if (qd >= C::L) qd -= C::L;
+          Xf::digits(x, d, qd);
           ffwd_planar(lane, x, tw_kept, buf, sync_w);
         }
         publish();
