@@ -1644,7 +1644,12 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateAr
       const double2* bp0 = reinterpret_cast<const double2*>(bk_i + (size_t)(row * 2) * kN);
       const double2* bp1 = bp0 + kN / 2;
       double x[kRegs];
-      if constexpr (Xf::kSplitKeyLoads) {
+#ifndef RS_COOP_HALF_ROW
+#define RS_COOP_HALF_ROW 0   // 1: only the first half of a key row requested across the transform. With every workgroup on the same rows
+                             // that was the faster form (3.12 against 3.45 ms, round 1); with the rows walked in rotated orders the
+                             // whole row in flight wins: 3.21 -> 3.01 ms for 196 sign bootstraps (profiles/r03/v_ab_coop_whole_row.txt)
+#endif
+      if constexpr (Xf::kSplitKeyLoads && RS_COOP_HALF_ROW) {
         // first half of the key row prefetched across the transform, second half fetched after it
         double2 wa0[4], wa1[4];
 #pragma unroll
