@@ -1307,9 +1307,36 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coops_kernel(BlindRotateA
 #pragma unroll
         for (int v = 0; v < 4; ++v) { w0[v] = k0[(v0 + v) * 64 + lane]; w1[v] = k1[(v0 + v) * 64 + lane]; }
       };
+#ifndef RS_COOPS_AHEAD
+#define RS_COOPS_AHEAD 4   // key chunks (of 4 per row) requested across the transform: 1, 2 (the low half-row) or 4 (the whole row); with rotated
+                           // rows 196 sign bootstraps take 4.80 / 4.49 / 4.33 ms (profiles/r03/v_ab_coops_chunks_ahead.txt)
+#endif
+      double x[kRegs];
+#if RS_COOPS_AHEAD >= 4
+      double2 wa0[4], wa1[4], wb0[4], wb1[4], wc0[4], wc1[4], wd0[4], wd1[4];
+      load4(lo0, lo1, 0, wa0, wa1);
+      load4(lo0, lo1, 4, wb0, wb1);
+      load4(hi0, hi1, 0, wc0, wc1);
+      load4(hi0, hi1, 4, wd0, wd1);
+      Xf::fwd_digits(lane, x, d, q, 0u, tw, buf, f);
+      Xf::mac(s[0], s[1], x, wa0, wa1, 0, f);
+      Xf::mac(s[0], s[1], x, wb0, wb1, 4, f);
+      Xf::mac(s[2], s[3], x, wc0, wc1, 0, f);
+      Xf::mac(s[2], s[3], x, wd0, wd1, 4, f);
+#elif RS_COOPS_AHEAD >= 2
+      double2 wa0[4], wa1[4], wb0[4], wb1[4], wc0[4], wc1[4];
+      load4(lo0, lo1, 0, wa0, wa1);
+      load4(lo0, lo1, 4, wb0, wb1);
+      Xf::fwd_digits(lane, x, d, q, 0u, tw, buf, f);
+      load4(hi0, hi1, 0, wc0, wc1);
+      Xf::mac(s[0], s[1], x, wa0, wa1, 0, f);
+      load4(hi0, hi1, 4, wa0, wa1);
+      Xf::mac(s[0], s[1], x, wb0, wb1, 4, f);
+      Xf::mac(s[2], s[3], x, wc0, wc1, 0, f);
+      Xf::mac(s[2], s[3], x, wa0, wa1, 4, f);
+#else
       double2 wa0[4], wa1[4], wb0[4], wb1[4];
       load4(lo0, lo1, 0, wa0, wa1);
-      double x[kRegs];
       Xf::fwd_digits(lane, x, d, q, 0u, tw, buf, f);
       load4(lo0, lo1, 4, wb0, wb1);
       Xf::mac(s[0], s[1], x, wa0, wa1, 0, f);
@@ -1318,6 +1345,7 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coops_kernel(BlindRotateA
       load4(hi0, hi1, 4, wb0, wb1);
       Xf::mac(s[2], s[3], x, wa0, wa1, 0, f);
       Xf::mac(s[2], s[3], x, wb0, wb1, 4, f);
+#endif
     }
     // partial sums a wave does not own go through LDS (position u*64 + lane is conflict-free)
 #pragma unroll
