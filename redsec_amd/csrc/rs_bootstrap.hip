@@ -1593,6 +1593,11 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
 // and 1 sum one column each, run the inverse transform and update the shared accumulator. Two
 // workgroup barriers per CMUX step.
 // -------------------------------------------------------------------------------------------------
+#ifndef RS_COOP_HALF_ROW
+#define RS_COOP_HALF_ROW 0   // 1: only the first half of a key row requested across the transform. With every workgroup on the same rows
+                             // that was the faster form (3.12 against 3.45 ms, round 1); with the rows walked in rotated orders the
+                             // whole row in flight wins: 3.21 -> 3.01 ms for 196 sign bootstraps (profiles/r03/v_ab_coop_whole_row.txt)
+#endif
 template <class Xf, int G>
 __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateArgs a) {
   using C = typename Xf::Cfg;
@@ -1658,6 +1663,43 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateAr
       d[r] = rotated_diff(s_acc[comp], lane + 64 * r, bara);
       if (Xf::kPreparedDigits) d[r] = gadget_prepare<C>(d[r]);
     }
+#ifndef RS_COOP_TWO_ROWS
+#define RS_COOP_TWO_ROWS 0   // the key of the NEXT row requested before the transform of this one (two rows in flight per wave): measured
+                             // slower, 3.31 against 3.0 ms for 196 sign bootstraps (profiles/r03/v_ab_coop_two_rows_in_flight.txt): one row is the spot
+#endif
+#if RS_COOP_TWO_ROWS
+    if constexpr (!(Xf::kSplitKeyLoads && RS_COOP_HALF_ROW)) {
+      auto row_of = [&](int rr) {
+#if RS_COOP_ROTATE_ROWS >= 1
+        return row_begin + (int)((rr + blockIdx.x) % R);
+#else
+        return row_begin + rr;
+#endif
+      };
+      auto load_row = [&](int rr, double2 (&w0)[8], double2 (&w1)[8]) {
+        const double2* bp0 = reinterpret_cast<const double2*>(bk_i + (size_t)(row_of(rr) * 2) * kN);
+        const double2* bp1 = bp0 + kN / 2;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) { w0[v] = bp0[v * 64 + lane]; w1[v] = bp1[v * 64 + lane]; }
+      };
+      auto do_row = [&](int rr, const double2 (&w0)[8], const double2 (&w1)[8]) {
+        double x[kRegs];
+        Xf::fwd_digits(lane, x, d, row_of(rr) - comp * C::L, offset, tw, buf, f);
+        Xf::mac8(s0, s1, x, w0, w1, f);
+      };
+      double2 wA0[8], wA1[8], wB0[8], wB1[8];
+      load_row(0, wA0, wA1);
+      int rr = 0;
+#pragma unroll 1
+      for (; rr + 1 < R; rr += 2) {
+        load_row(rr + 1, wB0, wB1);
+        do_row(rr, wA0, wA1);
+        if (rr + 2 < R) load_row(rr + 2, wA0, wA1);
+        do_row(rr + 1, wB0, wB1);
+      }
+      if (rr < R) do_row(rr, wA0, wA1);
+    } else
+#endif
 #pragma unroll 1
     for (int rr = 0; rr < R; ++rr) {
 #if RS_COOP_ROTATE_ROWS >= 1   // workgroups walk their rows of a step in different orders (the rows of a step are independent), so that the
@@ -1672,11 +1714,6 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateAr
       const double2* bp0 = reinterpret_cast<const double2*>(bk_i + (size_t)(row * 2) * kN);
       const double2* bp1 = bp0 + kN / 2;
       double x[kRegs];
-#ifndef RS_COOP_HALF_ROW
-#define RS_COOP_HALF_ROW 0   // 1: only the first half of a key row requested across the transform. With every workgroup on the same rows
-                             // that was the faster form (3.12 against 3.45 ms, round 1); with the rows walked in rotated orders the
-                             // whole row in flight wins: 3.21 -> 3.01 ms for 196 sign bootstraps (profiles/r03/v_ab_coop_whole_row.txt)
-#endif
       if constexpr (Xf::kSplitKeyLoads && RS_COOP_HALF_ROW) {
         // first half of the key row prefetched across the transform, second half fetched after it
         double2 wa0[4], wa1[4];
