@@ -20,6 +20,11 @@ EMU_LIB = os.path.join(HERE, "librs_emulate.so")
 
 HIP_SOURCES = ["rs_bootstrap.hip", "rs_general.hip", "rs_kernels.hip", "rs_api.cpp"]
 HIP_DEPS = HIP_SOURCES + ["rs_kernels.h", "rs_ntt.h", "rs_fft.h", "rs_general.h", "rs_host.h", os.path.join(INCLUDE, "redsec_hip.h")]
+# Per-file code-generation flags. rs_bootstrap.hip (the blind-rotation kernels): LLVM's post-register-allocation scheduler
+# off -- its in-block reordering of the hand-laid-out LDS / FP64 sequences costs 1-2 % on every form measured (same-box A/B,
+# profiles/r03/y_ab_compiler_scheduling_*.txt: default-128 +1.3 %, REDsec set +0.9 %, sign1024x1 image 12.36 -> 12.11 ms);
+# the keyswitch of the (9, 3) set in rs_kernels.hip LOSES 12 % without that pass, so the other files keep it.
+HIP_FILE_FLAGS = {"rs_bootstrap.hip": ["-mllvm", "-enable-post-misched=0"]}
 EMU_SOURCES = ["rs_emulate.cpp"]
 EMU_DEPS = EMU_SOURCES + ["rs_ntt.h", "rs_fft.h", "rs_general.h", "rs_host.h"]
 
@@ -80,8 +85,22 @@ def build_hip(force=False, verbose=False):
         if os.path.exists(HIP_LIB):
             return HIP_LIB  # prebuilt library shipped with the snapshot
         raise RuntimeError("hipcc not found and no prebuilt libredsec_hip.so present")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-I" + INCLUDE, "-I" + CSRC] + _abs(HIP_SOURCES) + ["-o", HIP_LIB]
+    # One object per source (compiled side by side), then one link: the files carry different code-generation flags.
+    objdir = os.path.join(ROOT, "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    common = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
+    jobs, objs = [], []
+    for src in HIP_SOURCES:
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        cmd = common + HIP_FILE_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        jobs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, job in jobs:
+        if job.wait() != 0:
+            raise subprocess.CalledProcessError(job.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", HIP_LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
