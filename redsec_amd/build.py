@@ -20,11 +20,19 @@ EMU_LIB = os.path.join(HERE, "librs_emulate.so")
 
 HIP_SOURCES = ["rs_bootstrap.hip", "rs_general.hip", "rs_kernels.hip", "rs_api.cpp"]
 HIP_DEPS = HIP_SOURCES + ["rs_kernels.h", "rs_ntt.h", "rs_fft.h", "rs_general.h", "rs_host.h", os.path.join(INCLUDE, "redsec_hip.h")]
-# Per-file code-generation flags. rs_bootstrap.hip (the blind-rotation kernels): LLVM's post-register-allocation scheduler
-# off -- its in-block reordering of the hand-laid-out LDS / FP64 sequences costs 1-2 % on every form measured (same-box A/B,
+# Objects of the product library: (object name, source, extra flags). rs_bootstrap.hip is compiled twice (its RS_BS_PART
+# switch): part 1 -- the FFT / exact-NTT blind-rotation kernels and the split duo form -- with LLVM's post-register-allocation
+# scheduler off: its in-block reordering of the hand-laid-out LDS / FP64 sequences costs these kernels 1-3 % (same-box A/B,
 # profiles/r03/y_ab_compiler_scheduling_*.txt: default-128 +1.3 %, REDsec set +0.9 %, sign1024x1 image 12.36 -> 12.11 ms);
-# the keyswitch of the (9, 3) set in rs_kernels.hip LOSES 12 % without that pass, so the other files keep it.
-HIP_FILE_FLAGS = {"rs_bootstrap.hip": ["-mllvm", "-enable-post-misched=0"]}
+# part 2 -- the split cooperative and split lock-step kernels -- with the default pipeline (they lose 6 % / 0.7 % without
+# that pass), like the other files (the (9, 3) keyswitch in rs_kernels.hip loses 12 % without it).
+HIP_OBJECTS = [
+    ("rs_bootstrap_1", "rs_bootstrap.hip", ["-DRS_BS_PART=1", "-mllvm", "-enable-post-misched=0"]),
+    ("rs_bootstrap_2", "rs_bootstrap.hip", ["-DRS_BS_PART=2"]),
+    ("rs_general", "rs_general.hip", []),
+    ("rs_kernels", "rs_kernels.hip", []),
+    ("rs_api", "rs_api.cpp", []),
+]
 EMU_SOURCES = ["rs_emulate.cpp"]
 EMU_DEPS = EMU_SOURCES + ["rs_ntt.h", "rs_fft.h", "rs_general.h", "rs_host.h"]
 
@@ -90,9 +98,9 @@ def build_hip(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     common = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
     jobs, objs = [], []
-    for src in HIP_SOURCES:
-        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-        cmd = common + HIP_FILE_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+    for name, src, extra in HIP_OBJECTS:
+        obj = os.path.join(objdir, name + ".o")
+        cmd = common + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         jobs.append((cmd, subprocess.Popen(cmd)))

@@ -35,6 +35,15 @@
 #include "rs_kernels.h"
 #include "rs_ntt.h"
 
+// RS_BS_PART: redsec_amd/build.py compiles this file TWICE, because its kernels want different code-generation flags
+// (profiles/r03/y_ab_compiler_scheduling_*.txt). Bit 1 = every launcher except the one of bit 2 (built with LLVM's post-RA
+// scheduler off: the FFT / exact-NTT kernels and the split duo form gain 1-3 % from it); bit 2 = launch_blind_rotate_split_wg
+// with the split cooperative and split lock-step kernels (built with the default pipeline: they lose 6 % / 0.7 % without that
+// pass). Kernels are templates, so each object holds only what its launchers name. Default 3: one object with everything.
+#ifndef RS_BS_PART
+#define RS_BS_PART 3
+#endif
+
 namespace rs {
 
 // Same-wave LDS hand-off: DS operations of one wavefront execute in order, so only the compiler
@@ -1817,6 +1826,7 @@ __global__ __launch_bounds__(64 * WPB) void polymul_kernel(const int32_t* __rest
 // -------------------------------------------------------------------------------------------------
 // Launchers. cfg: 0 = default-128-shaped gadget, 1 = REDsec-shaped; mode: 0 = exact NTT, 1 = FFT.
 // -------------------------------------------------------------------------------------------------
+#if RS_BS_PART & 1
 template <class Xf, int WPB>
 static hipError_t launch_br(const BlindRotateArgs& a, long max_blocks, hipStream_t st) {
   long blocks = (a.B + WPB - 1) / WPB;
@@ -1935,6 +1945,18 @@ hipError_t launch_blind_rotate(int cfg, int mode, const BlindRotateArgs& a, int 
                   : launch_br_xf<XfFft<CfgRedsecV2>>(a, wpb, num_cus, true, opts, st, info);
 }
 
+// The split duo form's launch (mid-size batches of the split mode): lives in part 1, called from part 2.
+hipError_t launch_split_duos(int cfg, const BlindRotateArgs& a, long grid, hipStream_t st) {
+  if (cfg == 0) hipLaunchKernelGGL((blind_rotate_duos_kernel<CfgDefault128>), dim3((unsigned)grid), dim3(512), 0, st, a);
+  else if (cfg == 1) hipLaunchKernelGGL((blind_rotate_duos_kernel<CfgRedsecV2>), dim3((unsigned)grid), dim3(512), 0, st, a);
+  else if (cfg == 2) hipLaunchKernelGGL((blind_rotate_duos_kernel<CfgRedsecSmall>), dim3((unsigned)grid), dim3(512), 0, st, a);
+  else return hipErrorNotSupported;
+  return hipGetLastError();
+}
+#endif  // RS_BS_PART & 1
+
+#if RS_BS_PART & 2
+hipError_t launch_split_duos(int cfg, const BlindRotateArgs& a, long grid, hipStream_t st);
 // Split-key workgroup form (N = 1024; cfg 0 / 1 = the two shipped gadgets, 2 = redsec_params_small's l=3 Bgbit=10): a.bk_x = the split key of rs_general.h,
 // a.tw = the FFT tables of rs_fft.h. Returns hipErrorNotSupported for an unknown gadget id (caller: general kernel).
 hipError_t launch_blind_rotate_split_wg(int cfg, const BlindRotateArgs& a, int num_cus, const LaunchOpts& o, hipStream_t st, LaunchInfo* info) {
@@ -1966,12 +1988,9 @@ hipError_t launch_blind_rotate_split_wg(int cfg, const BlindRotateArgs& a, int n
   }
   if (!o.no_duo && a.B <= 4L * num_cus) {   // mid-size batches: 4 ciphertexts x 2 waves per workgroup (no_duo: the 4-wave lock-step groups)
     const long grid = std::min<long>((a.B + 3) / 4, num_cus);
-    if (cfg == 0) hipLaunchKernelGGL((blind_rotate_duos_kernel<CfgDefault128>), dim3((unsigned)grid), dim3(512), 0, st, a);
-    else if (cfg == 1) hipLaunchKernelGGL((blind_rotate_duos_kernel<CfgRedsecV2>), dim3((unsigned)grid), dim3(512), 0, st, a);
-    else if (cfg == 2) hipLaunchKernelGGL((blind_rotate_duos_kernel<CfgRedsecSmall>), dim3((unsigned)grid), dim3(512), 0, st, a);
-    else return hipErrorNotSupported;
+    if (cfg < 0 || cfg > 2) return hipErrorNotSupported;
     if (info) { info->form = kFormSplitDuo; info->waves_per_block = 8; info->resident = 4 * grid; }
-    return hipGetLastError();
+    return launch_split_duos(cfg, a, grid, st);
   }
   const int wpb = (a.B <= 4L * num_cus && !o.no_wg4) ? 4 : 8;
   const long groups = (a.B + wpb - 1) / wpb;
@@ -1989,6 +2008,9 @@ hipError_t launch_blind_rotate_split_wg(int cfg, const BlindRotateArgs& a, int n
   return hipGetLastError();
 }
 
+#endif  // RS_BS_PART & 2
+
+#if RS_BS_PART & 1
 hipError_t launch_bk_transform(int cfg, int mode, const int32_t* bk, double* bk_x, const double* tw, Field f, double scale,
                                long n_polys, hipStream_t st) {
   constexpr int WPB = 4;
@@ -2016,6 +2038,8 @@ hipError_t launch_polymul(int cfg, int mode, const int32_t* a_small, const int32
   }
   return hipGetLastError();
 }
+
+#endif  // RS_BS_PART & 1
 
 }  // namespace rs
 
