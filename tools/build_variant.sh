@@ -7,7 +7,7 @@ set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 NAME="$1"; SRC="${2:-$ROOT}"; shift; shift || true
 BS_FLAGS="${BS_FLAGS:--mllvm -enable-post-misched=0}"   # rs_bootstrap.hip part 1 only (FFT / NTT kernels, split duo form)
-BS2_FLAGS="${BS2_FLAGS:-}"                               # rs_bootstrap.hip part 2 only (split cooperative / lock-step kernels)
+BS2_FLAGS="${BS2_FLAGS:--mllvm -amdgpu-sched-strategy=max-memory-clause}"                               # rs_bootstrap.hip part 2 only (split cooperative / lock-step kernels)
 GEN_FLAGS="${GEN_FLAGS:-}"                               # rs_general.hip only (A/B)
 mkdir -p "$ROOT/variants"
 OBJ="$(mktemp -d /tmp/variant_$NAME.XXXX)"
