@@ -8,6 +8,7 @@ ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 NAME="$1"; SRC="${2:-$ROOT}"; shift; shift || true
 BS_FLAGS="${BS_FLAGS:--mllvm -enable-post-misched=0}"   # rs_bootstrap.hip part 1 only (FFT / NTT kernels, split duo form)
 BS2_FLAGS="${BS2_FLAGS:--mllvm -amdgpu-sched-strategy=max-memory-clause}"                               # rs_bootstrap.hip part 2 only (split cooperative / lock-step kernels)
+K_FLAGS="${K_FLAGS:-}"                                   # rs_kernels.hip only (A/B)
 GEN_FLAGS="${GEN_FLAGS:-}"                               # rs_general.hip only (A/B)
 mkdir -p "$ROOT/variants"
 OBJ="$(mktemp -d /tmp/variant_$NAME.XXXX)"
@@ -22,7 +23,7 @@ else   # an older source tree: one object
   cc $BS_FLAGS "$@" -c "$B/rs_bootstrap.hip" -o "$OBJ/rs_bootstrap.o"
 fi
 cc $GEN_FLAGS "$@" -c "$B/rs_general.hip" -o "$OBJ/rs_general.o"
-cc "$@" -c "$B/rs_kernels.hip" -o "$OBJ/rs_kernels.o"
+cc $K_FLAGS "$@" -c "$B/rs_kernels.hip" -o "$OBJ/rs_kernels.o"
 cc "$@" -c "$B/rs_api.cpp" -o "$OBJ/rs_api.o"
 for p in "${pids[@]}"; do wait "$p"; done
 hipcc --offload-arch=gfx950 -shared -fPIC "$OBJ"/*.o -o "$ROOT/variants/lib_$NAME.so"
