@@ -87,6 +87,23 @@ def find_hipcc():
     return None
 
 
+def _locked(name):
+    """Exclusive advisory lock for one build target: several ranks of a torch.distributed.run job may import the package at the
+    same moment on a tree whose stamp is missing, and must not write the same objects and library side by side."""
+    import fcntl
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    f = open(os.path.join(ROOT, "build", "." + name + ".lock"), "w")
+    fcntl.flock(f, fcntl.LOCK_EX)
+    return f
+
+
+def _publish(tmp, target, deps):
+    """Stamp first (under a temporary name), then both renamed into place: a reader never sees a half-written library."""
+    write_stamp(tmp, _abs(deps) + [os.path.abspath(__file__)])
+    os.replace(tmp, target)
+    os.replace(tmp + ".stamp", target + ".stamp")
+
+
 def build_hip(force=False, verbose=False):
     if not force and not _stale(HIP_LIB, HIP_DEPS):
         return HIP_LIB
@@ -95,27 +112,41 @@ def build_hip(force=False, verbose=False):
         if os.path.exists(HIP_LIB):
             return HIP_LIB  # prebuilt library shipped with the snapshot
         raise RuntimeError("hipcc not found and no prebuilt libredsec_hip.so present")
-    # One object per source (compiled side by side), then one link: the files carry different code-generation flags.
-    objdir = os.path.join(ROOT, "build", "obj")
-    os.makedirs(objdir, exist_ok=True)
-    common = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
-    jobs, objs = [], []
-    for name, src, extra in HIP_OBJECTS:
-        obj = os.path.join(objdir, name + ".o")
-        cmd = common + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        jobs.append((cmd, subprocess.Popen(cmd)))
-        objs.append(obj)
-    for cmd, job in jobs:
-        if job.wait() != 0:
-            raise subprocess.CalledProcessError(job.returncode, cmd)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", HIP_LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    _stamp(HIP_LIB, HIP_DEPS)
-    return HIP_LIB
+    lock = _locked("hip")
+    try:
+        if not force and not _stale(HIP_LIB, HIP_DEPS):     # another process built it while this one waited for the lock
+            return HIP_LIB
+        # One object per source (compiled side by side), then one link: the files carry different code-generation flags.
+        # Objects and the linked library are written under per-process names and renamed into place.
+        objdir = os.path.join(ROOT, "build", "obj.%d" % os.getpid())
+        os.makedirs(objdir, exist_ok=True)
+        common = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
+        jobs, objs = [], []
+        for name, src, extra in HIP_OBJECTS:
+            obj = os.path.join(objdir, name + ".o")
+            cmd = common + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((cmd, subprocess.Popen(cmd)))
+            objs.append(obj)
+        try:
+            for cmd, job in jobs:
+                if job.wait() != 0:
+                    raise subprocess.CalledProcessError(job.returncode, cmd)
+            tmp = HIP_LIB + ".tmp.%d" % os.getpid()
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            _publish(tmp, HIP_LIB, HIP_DEPS)
+        finally:
+            for _, job in jobs:
+                if job.poll() is None:
+                    job.kill()
+            shutil.rmtree(objdir, ignore_errors=True)
+        return HIP_LIB
+    finally:
+        lock.close()
 
 
 def build_emulator(force=False, verbose=False):

@@ -1780,6 +1780,157 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateAr
 }
 
 // -------------------------------------------------------------------------------------------------
+// Cooperative blind rotation, EIGHT waves per ciphertext (latency form for B <= #CUs, FFT mode; round 4).
+// The four-wave form above runs one wave per SIMD: a lone wave issues its FP64 and LDS instructions one behind
+// the other (78 % of a two-wave SIMD's rate per wave-slot), and its critical path per CMUX step is
+// R = 2l/4 forward transforms plus one inverse. Here the 2l digit rows of a step go to 8 waves -- waves 0-3 the
+// rows of accumulator component 0, waves 4-7 those of component 1, split so that every SIMD (waves s and s + 4)
+// carries the same number of rows (l = 10: 3+2, 3+2, 2+3, 2+3; l = 3: 1+0, 1+1, 1+1, 0+1) -- and the two inverse
+// transforms to the two waves with the fewest rows, on different SIMDs (kInvA = 3: column 0, kInvB = 4: column 1).
+// Partial column sums meet in LDS in ONE exchange: 14 partials of 8 KB need homes, and every wave's transform
+// buffer is idle by then, so wave w leaves its column-0 partial in its own exchange buffer and its column-1
+// partial in slot w of s_part -- except that kInvA keeps column 0 and kInvB column 1 in registers, and kInvB's
+// column-0 partial goes to ITS s_part slot (free for that reason): after the barrier both inverse waves find
+// their own exchange buffers unused by anyone. LDS: 8 KB tables + 8 x 9 KB buffers + 64 KB partials + 8 KB
+// accumulator = 152 KB, one workgroup per CU. Integer results are independent of the summation order (the
+// sums are rounded to the exact integers, certificate-tracked as everywhere); two workgroup barriers per step.
+// -------------------------------------------------------------------------------------------------
+#ifndef RS_COOP8_KEEP_TW
+#define RS_COOP8_KEEP_TW 0   // 1: per-lane twiddles in registers (FftTwKept<3>) instead of LDS table reads
+#endif
+template <class Xf>
+__global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs a) {
+  using C = typename Xf::Cfg;
+  static_assert(Xf::kCertificate, "FFT policy only: the exact-NTT reduction schedule is validated for four partials");
+  if (recompute_not_needed(a)) return;
+  constexpr int G = 8, H = 4, L = C::L, KPL = 2 * L;
+  constexpr int kInvA = 3, kInvB = 4;
+  constexpr int kBase = L / H, kRem = L % H;
+  __shared__ double s_tw[Xf::kTableDoubles + 1];
+  __shared__ double s_buf[G][kBufDoubles];
+  __shared__ double s_part[G][kN];
+  __shared__ int32_t s_acc[2][kN];
+  stage_tables(s_tw, a.tw, 64 * G, Xf::kTableDoubles);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const long ct = blockIdx.x;
+  const Field f = a.f;
+  double* buf = s_buf[wave];
+#if RS_COOP8_KEEP_TW
+  typename Xf::LatencyState tw;
+  Xf::init_latency(tw, lane, s_tw, a.tw);
+#else
+  typename Xf::State tw;
+  Xf::init(tw, lane, s_tw, a.tw);
+#endif
+  const int32_t* row0 = a.in0 + ct * a.W;
+  const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
+  const int n = a.n;
+  const int comp = wave / H, jw = wave % H;
+  // rows [first, first + cnt) of this wave's component (digit index q = first + rr, TGSW row comp * L + q)
+  const int cnt = comp == 0 ? kBase + (jw < kRem ? 1 : 0) : kBase + (jw >= H - kRem ? 1 : 0);
+  const int first = comp == 0 ? jw * kBase + (jw < kRem ? jw : kRem) : jw * kBase + (jw > H - kRem ? jw - (H - kRem) : 0);
+  double dev = 0.0;
+  auto word = [&](int i) -> int32_t {
+    uint32_t v = (uint32_t)a.c0 * (uint32_t)row0[i];
+    if (row1) v += (uint32_t)a.c1 * (uint32_t)row1[i];
+    return (int32_t)v;
+  };
+  if (wave < 2) {
+    const int32_t barb = modswitch_2N((int32_t)((uint32_t)word(n) + (uint32_t)a.bconst));
+    const int rot = 2 * kN - barb;
+#pragma unroll
+    for (int r = 0; r < kRegs; ++r) {
+      const int j = lane + 64 * r;
+      s_acc[wave][j] = wave == 0 ? 0 : test_vector(a, ct, j, rot);
+    }
+  }
+  __syncthreads();
+  constexpr uint32_t offset = gadget_offset<C>();
+  for (int i = 0; i < n; ++i) {
+    const int32_t bara = __builtin_amdgcn_readfirstlane(modswitch_2N(word(i)));
+    if (bara == 0) continue;   // uniform over the workgroup
+    double s0[kRegs], s1[kRegs];
+#pragma unroll
+    for (int u = 0; u < kRegs; ++u) { s0[u] = 0.0; s1[u] = 0.0; }
+    if (cnt > 0) {
+      const double* bk_i = a.bk_x + (size_t)i * KPL * 2 * kN;
+      int32_t d[kRegs];
+#pragma unroll
+      for (int r = 0; r < kRegs; ++r) d[r] = gadget_prepare<C>(rotated_diff(s_acc[comp], lane + 64 * r, bara));
+#pragma unroll 1
+      for (int rr = 0; rr < cnt; ++rr) {
+        const int q = first + (int)((rr + blockIdx.x) % (unsigned)cnt);   // per-workgroup row order, as in the four-wave form
+        const double2* bp0 = reinterpret_cast<const double2*>(bk_i + (size_t)((comp * L + q) * 2) * kN);
+        const double2* bp1 = bp0 + kN / 2;
+        double x[kRegs];
+        double2 w0[8], w1[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) { w0[v] = bp0[v * 64 + lane]; w1[v] = bp1[v * 64 + lane]; }
+        Xf::fwd_digits(lane, x, d, q, offset, tw, buf, f);
+        Xf::mac8(s0, s1, x, w0, w1, f);
+      }
+    }
+    // partial sums: column 0 into the wave's own (now idle) exchange buffer, column 1 into its s_part slot; position
+    // u * 64 + lane is conflict-free. kInvA / kInvB keep the column they will invert in registers.
+    {
+      double* p0 = wave == kInvB ? s_part[kInvB] : buf;
+      if (wave != kInvA) {
+#pragma unroll
+        for (int u = 0; u < kRegs; ++u) p0[u * 64 + lane] = s0[u];
+      }
+      if (wave != kInvB) {
+#pragma unroll
+        for (int u = 0; u < kRegs; ++u) s_part[wave][u * 64 + lane] = s1[u];
+      }
+    }
+    __syncthreads();   // partials visible; every wave has finished reading the accumulator
+    if (wave == kInvA || wave == kInvB) {
+      double x[kRegs];
+      if (wave == kInvA) {
+#pragma unroll
+        for (int u = 0; u < kRegs; ++u) x[u] = s0[u];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          if (g == kInvA) continue;
+          const double* src = g == kInvB ? s_part[kInvB] : s_buf[g];
+#pragma unroll
+          for (int u = 0; u < kRegs; ++u) x[u] += src[u * 64 + lane];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < kRegs; ++u) x[u] = s1[u];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          if (g == kInvB) continue;
+#pragma unroll
+          for (int u = 0; u < kRegs; ++u) x[u] += s_part[g][u * 64 + lane];
+        }
+      }
+      wave_lds_sync();   // this wave's reads of the partials are issued before its transform reuses LDS (in-order DS queue)
+      Xf::inverse(lane, x, tw, buf, f);
+      int32_t* acc = s_acc[wave == kInvA ? 0 : 1];
+#pragma unroll
+      for (int r = 0; r < kRegs; ++r) {
+        const int j = lane + 64 * r;
+        acc[j] = (int32_t)((uint32_t)acc[j] + (uint32_t)Xf::to_torus(x[r], dev));
+      }
+    }
+    __syncthreads();   // accumulator updated; partial slots free
+  }
+  int32_t* out = a.u_out + ct * (kN + 1);
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < kRegs; ++r) {
+      const int j = lane + 64 * r;
+      out[j] = (j == 0) ? s_acc[0][0] : (int32_t)(0u - (uint32_t)s_acc[0][kN - j]);
+    }
+    if (lane == 0) out[kN] = s_acc[1][0];
+  }
+  if (wave == kInvA || wave == kInvB) publish_certificate(dev, a.dev_flag, lane);
+}
+
+// -------------------------------------------------------------------------------------------------
 // Debug tap: out = a_small * b_torus (negacyclic, mod 2^32) through forward/pointwise/inverse.
 // -------------------------------------------------------------------------------------------------
 template <class Xf, int WPB>
@@ -1852,6 +2003,13 @@ static hipError_t launch_br_xf(const BlindRotateArgs& a, int wpb, long num_cus, 
   };
   // latency form: several waves per ciphertext while the batch cannot fill the chip by itself
   if (!o.no_coop) {
+    if constexpr (Xf::kWorkgroupForm) {
+      // at most one ciphertext per CU: eight waves share it (two per SIMD), see blind_rotate_coop8_kernel
+      if (!o.no_coop8 && a.B <= num_cus) {
+        hipLaunchKernelGGL((blind_rotate_coop8_kernel<Xf>), dim3((unsigned)a.B), dim3(512), 0, st, a);
+        return done(kFormCoop8, 8, 1);
+      }
+    }
     if (coop4 && a.B <= num_cus) {
       if constexpr ((2 * Xf::Cfg::L) % 4 == 0) {
         hipLaunchKernelGGL((blind_rotate_coop_kernel<Xf, 4>), dim3((unsigned)a.B), dim3(256), 0, st, a);

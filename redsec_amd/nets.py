@@ -312,19 +312,28 @@ class EncryptedCifar:
             self._pool_index[key] = self._t(np.stack([a.reshape(-1) for a in taps]).astype(np.int32))
         return self._pool_index[key]
 
-    def run(self, image_ct, shard=False):
-        """image_ct: int32 CUDA tensor [32*32*3][W] in (row, column, channel) order. Returns int32 [10][W]."""
+    def run(self, image_ct, shard=False, taps=None):
+        """image_ct: int32 CUDA tensor [32*32*3][W] in (row, column, channel) order. Returns int32 [10][W].
+        `taps` (list) receives one record per BOOTSTRAPPED stage, in execution order: dict(name, kind = "sign" | "or",
+        mu, inputs = the stage's input slab(s) [B][W], out = its output slab) -- what the stage-level parity test
+        (tests/test_gpu_cifar.py) compares with the oracle row by row."""
         be = self.be
         if shard:
             from . import sharding
-            stage = lambda fn, *xs: sharding.sharded_stage(lambda rows: fn(*[rows[k] for k in range(len(xs))]), _Rows(xs))
+            run_stage = lambda fn, *xs: sharding.sharded_stage(lambda rows: fn(*[rows[k] for k in range(len(xs))]), _Rows(xs))
         else:
-            stage = lambda fn, *xs: fn(*xs)
+            run_stage = lambda fn, *xs: fn(*xs)
+
+        def stage(fn, *xs, name=None, kind="sign", mu=MU_SIGN):
+            out = run_stage(fn, *xs)
+            if taps is not None:
+                taps.append(dict(name=name, kind=kind, mu=int(mu), inputs=xs, out=out))
+            return out
         W = be.W
         H = Wd = 32
         one = dict(H=H, Wd=Wd, C=3, win_h=1, win_w=1, stride_h=1, stride_w=1, off_h=0, off_w=0, Ho=H, Wo=Wd)
         pre = be.sumpool(image_ct.view(H, Wd, 3, W), one, bias_b=self.bias0).view(-1, W)     # Quantize: x + bias[i % depth]
-        bits = stage(lambda r: be.bootstrap(r, MU_SIGN), pre)
+        bits = stage(lambda r: be.bootstrap(r, MU_SIGN), pre, name="quantize0")
         C = 3
         for li, (sign, zero, bias) in enumerate(self.convs):
             Cout = sign.shape[3]
@@ -334,11 +343,11 @@ class EncryptedCifar:
             pooled = li % 2 == 1
             fused = pooled and self.maxpool == "fused"
             mu = MU_SIGN if not pooled else ((1 << 28) if fused else self.MU8)
-            bits = stage(lambda r: be.bootstrap(r, mu), pre)
+            bits = stage(lambda r: be.bootstrap(r, mu), pre, name="conv%d" % (li + 1), mu=mu)
             if fused:
                 win = dict(H=H, Wd=Wd, C=C, win_h=2, win_w=2, stride_h=2, stride_w=2, off_h=0, off_w=0, Ho=H // 2, Wo=Wd // 2)
                 pre = be.sumpool(bits.view(H, Wd, C, W), win, bias_b=self.pool_bias).view(-1, W)
-                bits = stage(lambda r: be.bootstrap(r, MU_SIGN), pre)
+                bits = stage(lambda r: be.bootstrap(r, MU_SIGN), pre, name="maxpool%d" % (li + 1))
                 H //= 2; Wd //= 2
             elif pooled:
                 idx = self._pool(H, Wd, C)
@@ -346,7 +355,7 @@ class EncryptedCifar:
                 for tp in range(1, 4):
                     tap = be.gather_rows(bits, idx[tp])
                     mu = MU_SIGN if tp == 3 else self.MU8
-                    acc = stage(lambda a, b: be.gate_mu("OR", a, b, mu), acc, tap)
+                    acc = stage(lambda a, b: be.gate_mu("OR", a, b, mu), acc, tap, name="maxpool%d_or%d" % (li + 1, tp), kind="or", mu=mu)
                 bits = acc
                 H //= 2; Wd //= 2
         v = bits
@@ -354,7 +363,7 @@ class EncryptedCifar:
             pre = be.linear_fc(v, sign, zero, zero_tap_b=0, bias_b=bias)
             if i == len(self.fcs) - 1:
                 return pre
-            v = stage(lambda r: be.bootstrap(r, MU_SIGN), pre)
+            v = stage(lambda r: be.bootstrap(r, MU_SIGN), pre, name="fc%d" % (i + 1))
 
 
 class _Rows:

@@ -119,7 +119,7 @@ def test_kernel_form_is_reported_per_launch(toy_redsec):
         _, ct = _bits(ks, B, B)
         be.bootstrap(_dev(ct), mu)
         seen[B] = be.last_launch()
-    assert seen[3]["form"] == "coop4" and seen[cus + 9]["form"] == "coop2"
+    assert seen[3]["form"] == "coop8" and seen[3]["waves_per_block"] == 8 and seen[cus + 9]["form"] == "coop2"
     assert seen[3 * cus]["form"] == "duo" and seen[3 * cus]["resident"] == 3 * cus
     assert seen[8 * cus]["form"] == "workgroup" and seen[8 * cus]["resident"] == 8 * cus and seen[8 * cus]["waves_per_block"] == 8
     assert be.info()["waves_per_block"] == 8
