@@ -1665,7 +1665,11 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateAr
     double s0[kRegs], s1[kRegs];
 #pragma unroll
     for (int u = 0; u < kRegs; ++u) { s0[u] = 0.0; s1[u] = 0.0; }
+#ifdef RS_T_COOP_NOKEY   // TIMING PROBE (results are wrong): every step reads the rows of step 0, which stay in the L2s
+    const double* bk_i = a.bk_x;
+#else
     const double* bk_i = a.bk_x + (size_t)i * KPL * 2 * kN;
+#endif
     int32_t d[kRegs];
 #pragma unroll
     for (int r = 0; r < kRegs; ++r) {
@@ -1854,7 +1858,11 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
 #pragma unroll
     for (int u = 0; u < kRegs; ++u) { s0[u] = 0.0; s1[u] = 0.0; }
     if (cnt > 0) {
+#ifdef RS_T_COOP_NOKEY   // TIMING PROBE (results are wrong): every step reads the rows of step 0, which stay in the L2s
+      const double* bk_i = a.bk_x;
+#else
       const double* bk_i = a.bk_x + (size_t)i * KPL * 2 * kN;
+#endif
       int32_t d[kRegs];
 #pragma unroll
       for (int r = 0; r < kRegs; ++r) d[r] = gadget_prepare<C>(rotated_diff(s_acc[comp], lane + 64 * r, bara));

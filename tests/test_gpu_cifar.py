@@ -113,10 +113,37 @@ def test_binarynet_full_every_bootstrapped_stage_against_the_oracle(maxpool):
         checked += len(first) + len(more)
     assert checked >= 100 * len(taps)
     assert be.rounding_certificate() < 0.2 and be.fft_fallbacks() == 0
-    # decrypt level: the class of the plaintext model (pinned to the reference's plaintext build, tests/golden/cifar_binarynet.json)
+    # decrypt level, EVERY row of every stage: wherever the stage's (pre-combined) input phase is at least 32 message steps
+    # away from both decision boundaries, the output decrypts to sign(input) * mu within half of mu (SURVEY.md hard part 7:
+    # closer inputs flip under the mod-switch rounding in any TFHE implementation of this parameter set)
+    key = torch.from_numpy(np.ascontiguousarray(sk.lwe_key, dtype=np.int64)).cuda()
+
+    def phase(ct):
+        ph = ct[:, -1].long() - (ct[:, :-1].long() * key).sum(dim=1)
+        return ((ph + (1 << 31)) % (1 << 32)) - (1 << 31)
+
+    def wrap(v):
+        return ((v + (1 << 31)) % (1 << 32)) - (1 << 31)
+    for rec in taps:
+        ph_in = phase(rec["inputs"][0]) if rec["kind"] == "sign" else wrap(phase(rec["inputs"][0]) + phase(rec["inputs"][1]) + (1 << 29))
+        strong = (ph_in.abs() >= (32 << 20)) & (ph_in.abs() <= (1 << 31) - (32 << 20))
+        want = torch.where(ph_in >= 0, rec["mu"], -rec["mu"])
+        err = (phase(rec["out"]) - want).abs()
+        assert int(strong.sum()) > 0 and bool((err[strong] < rec["mu"] // 2).all()), rec["name"]
+        if rec["kind"] == "or":
+            assert bool(strong.all()), rec["name"]            # gate inputs at +-1/8 are never near a boundary
+    # the logits are the final layer of the bits the last bootstrapped stage produced (no bootstrap behind it)
+    bits = torch.where(phase(taps[-1]["out"]) >= 0, 1, -1).cpu().numpy()
+    sgn, zero, bias = net.fcs[-1]
+    w = np.where(zero == 1, 0, np.where(sgn == 1, 1, -1)).astype(np.int64)
     logits = sk.decrypt_ints(out.cpu().numpy())
-    plain = pm.cifar_forward(net, pix[i])
-    assert int(np.argmax(logits)) == int(np.argmax(plain)) == int(labels[i])
+    assert np.abs(logits - (bits @ w + bias.astype(np.int64))).max() <= 8
+    if maxpool == "fused":
+        # ... and, for this key and image, the class of the plaintext model (pinned to the reference's plaintext build,
+        # tests/golden/cifar_binarynet.json). Weak-margin units flip differently under another noise realisation -- the
+        # OR-chain form re-randomises every pooled bit -- so the class is asserted for the default form only.
+        plain = pm.cifar_forward(net, pix[i])
+        assert int(np.argmax(logits)) == int(np.argmax(plain)) == int(labels[i])
     # the split-key mode: every stage's whole slab, word for word
     be.set_mode("split")
     taps_s = []
