@@ -62,6 +62,8 @@ struct Lane {
   unsigned slot_next = 0;
   uint32_t* d_conv_scratch = nullptr;     // expanded weights of the tiled convolution (grown on demand)
   size_t conv_scratch_words = 0;
+  uint32_t* d_ks_scratch = nullptr;       // partial sums of the sliced (small-batch) keyswitch (grown on demand; <= ~50 MB)
+  size_t ks_scratch_words = 0;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   bool ev_valid = false;
   rs::LaunchInfo last;
@@ -139,7 +141,7 @@ int use_device(rs_ctx* c) {
 void free_lane(Lane* ln) {
   if (ln->h_split_max) (void)hipHostFree(ln->h_split_max);
   (void)hipFree(ln->d_u0); (void)hipFree(ln->d_u1); (void)hipFree(ln->d_counter); (void)hipFree(ln->d_cert);
-  (void)hipFree(ln->d_conv_scratch);
+  (void)hipFree(ln->d_conv_scratch); (void)hipFree(ln->d_ks_scratch);
   for (auto& e : ln->ev) if (e) (void)hipEventDestroy(e);
 }
 
@@ -176,6 +178,20 @@ int ensure_ws(Lane* ln, size_t B) {
   RS_HIP(hipMalloc(&ln->d_u1, bytes));
   ln->ws_batch = B;
   return RS_OK;
+}
+
+// Scratch of the sliced keyswitch for this launch (rs_kernels.h); a failed allocation is not an error: the launch then takes
+// the atomics form.
+void attach_ks_scratch(const rs_ctx* c, Lane* ln, rs::KeyswitchArgs& k) {
+  const size_t need = rs::keyswitch_scratch_words(k);
+  if (need == 0 || c->opts.ks_atomics) return;
+  if (need > ln->ks_scratch_words) {
+    if (ln->d_ks_scratch) { (void)hipFree(ln->d_ks_scratch); ln->d_ks_scratch = nullptr; ln->ks_scratch_words = 0; }   // hipFree waits for the device
+    if (hipMalloc(&ln->d_ks_scratch, need * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); ln->d_ks_scratch = nullptr; return; }
+    ln->ks_scratch_words = need;
+  }
+  k.scratch = ln->d_ks_scratch;
+  k.scratch_words = ln->ks_scratch_words;
 }
 
 int ensure_io(rs_ctx* c, size_t B) {
@@ -321,6 +337,7 @@ int run_bootstrap(rs_ctx* c, hipStream_t st, int32_t* out, const Combo* combos, 
     rs::KeyswitchArgs k;
     k.u0 = ln->d_u0; k.u1 = count == 2 ? ln->d_u1 : nullptr; k.bconst = ks_bconst; k.ksk = c->d_ksk;
     k.W = c->p.n + 1; k.t = c->p.ks_t; k.basebit = c->p.ks_basebit; k.B = (long)B; k.out = out; k.N = c->p.N;
+    attach_ks_scratch(c, ln, k);
     RS_HIP(rs::launch_keyswitch(k, st));
   }
   if (c->timing) { RS_HIP(hipEventRecord(ln->ev[2], st)); ln->ev_valid = true; }
@@ -456,7 +473,7 @@ int rs_create(rs_ctx** out, const rs_params* p, int device) {
   if (const char* v = getenv("REDSEC_SPLIT_CERT_LIMIT")) { const double x = atof(v); if (x > 0.0 && x < 0.25) c->split_cert_limit = x; }   // test hook: can only tighten
   c->opts.no_coop = env_on("RS_NO_COOP"); c->opts.no_wg = env_on("RS_NO_WG"); c->opts.no_duo = env_on("RS_NO_DUO");
   c->opts.no_persist = env_on("RS_NO_PERSIST"); c->opts.no_conv_tiled = env_on("RS_NO_CONV_TILED");
-  c->opts.no_wg4 = env_on("RS_NO_WG4"); c->opts.no_tail = env_on("RS_NO_TAIL"); c->opts.no_coop8 = env_on("RS_NO_COOP8");
+  c->opts.no_wg4 = env_on("RS_NO_WG4"); c->opts.no_tail = env_on("RS_NO_TAIL"); c->opts.no_coop8 = env_on("RS_NO_COOP8"); c->opts.ks_atomics = env_on("RS_KS_ATOMICS");
   Lane* ln = nullptr;
   if (lane_of(c, nullptr, &ln) != RS_OK) { destroy_ctx(c); return RS_ERR_HIP; }   // the default stream's lane
   *out = c;
@@ -615,6 +632,10 @@ int rs_keyswitch_dev(rs_ctx* c, int32_t* out, const int32_t* u, size_t B, void* 
   rs::KeyswitchArgs k;
   k.u0 = u; k.u1 = nullptr; k.bconst = 0; k.ksk = c->d_ksk;
   k.W = c->p.n + 1; k.t = c->p.ks_t; k.basebit = c->p.ks_basebit; k.B = (long)B; k.out = out; k.N = c->p.N;
+  Lane* ln = nullptr;
+  rc = lane_of(c, (hipStream_t)stream, &ln);
+  if (rc) return rc;
+  attach_ks_scratch(c, ln, k);
   RS_HIP(rs::launch_keyswitch(k, (hipStream_t)stream));
   return RS_OK;
 }

@@ -41,7 +41,7 @@ struct BlindRotateArgs {
 
 // Launch policy switches, read from the environment ONCE at rs_create (A/B experiments only).
 struct LaunchOpts {
-  bool no_coop = false, no_wg = false, no_duo = false, no_persist = false, no_conv_tiled = false, no_wg4 = false, no_tail = false, no_coop8 = false;
+  bool no_coop = false, no_wg = false, no_duo = false, no_persist = false, no_conv_tiled = false, no_wg4 = false, no_tail = false, no_coop8 = false, ks_atomics = false;
 };
 // What a blind-rotate launch actually ran: kernel form and how many ciphertexts share one sweep of the key
 // from L2/HBM (R of SURVEY.md section 8d).
@@ -57,7 +57,14 @@ struct KeyswitchArgs {
   long B;
   int32_t* out;         // [B][W]
   int32_t N = kN;       // ring degree of the extracted samples (the tiled kernels are N = 1024 only)
+  // Small batches: the N input coefficients are cut into slices (blockIdx.z) so that enough workgroups exist; with a scratch
+  // of keyswitch_scratch_words() words every slice stores its partial sums there ([slice][W][B], ciphertext fastest: coalesced)
+  // and keyswitch_reduce_kernel sums them into `out`. Without one (or one too small) the slices meet by integer atomics in a
+  // zeroed output (the round-1 form: 17 G uncoalesced atomics/s were what bounded it, profiles/r03/y_ab_*).
+  uint32_t* scratch = nullptr;
+  size_t scratch_words = 0;
 };
+size_t keyswitch_scratch_words(const KeyswitchArgs& a);   // 0 when the launch will not be sliced
 
 // General ring path (rs_general.h / rs_general.hip): any N = 2^logn in [1024, 8192], any gadget, split key.
 struct GenArgs {

@@ -164,12 +164,61 @@ __global__ __launch_bounds__(KS_TILE_THREADS) void keyswitch_tiled_kernel(Keyswi
       const int w = w0 + k;
       if (w < W) out[k] = (int32_t)((w == W - 1 ? bw : 0u) - acc[k]);
     }
+  } else if (a.scratch) {
+    // sliced form: this slice's partial sums, [slice][word][ciphertext] -- consecutive lanes write consecutive words
+    uint32_t* part = a.scratch + ((size_t)blockIdx.z * W + w0) * (size_t)a.B + ct;
+#pragma unroll
+    for (int k = 0; k < KS_CH; ++k) {
+      if (w0 + k < W) part[(size_t)k * a.B] = acc[k];
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < KS_CH; ++k) {
       const int w = w0 + k;
       if (w < W) atomicAdd(reinterpret_cast<unsigned int*>(out + k), (w == W - 1 ? bw : 0u) - acc[k]);
     }
+  }
+}
+
+// Sliced keyswitch, second step: out[ct][w] = (w == n ? b word : 0) - sum over slices of scratch[slice][w][ct]. A workgroup
+// owns a 16 x 16 tile: the partial sums are read with the ciphertext index fastest (as the slices wrote them), transposed
+// through LDS and stored with the word index fastest. Exact in any order (wrapping 32-bit sums).
+constexpr int KS_RT = 16;
+__global__ __launch_bounds__(KS_RT * KS_RT) void keyswitch_reduce_kernel(KeyswitchArgs a, int slices) {
+  __shared__ uint32_t tile[KS_RT][KS_RT + 1];
+  const int tx = threadIdx.x % KS_RT, ty = threadIdx.x / KS_RT;
+  const long ct0 = (long)blockIdx.x * KS_RT;
+  const int w0 = (int)blockIdx.y * KS_RT, W = a.W, N = a.N;
+  {
+    const int w = w0 + ty;
+    const long ct = ct0 + tx;
+    uint32_t s = 0;
+    if (w < W && ct < a.B) {
+      const uint32_t* p = a.scratch + (size_t)w * (size_t)a.B + ct;
+      const size_t stride = (size_t)W * (size_t)a.B;
+      int z = 0;
+      for (; z + 8 <= slices; z += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = p[(size_t)(z + e) * stride];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[e];
+      }
+      for (; z < slices; ++z) s += p[(size_t)z * stride];
+    }
+    tile[ty][tx] = s;
+  }
+  __syncthreads();
+  const long ct = ct0 + ty;
+  const int w = w0 + tx;
+  if (ct < a.B && w < W) {
+    uint32_t v = 0u - tile[tx][ty];
+    if (w == W - 1) {
+      uint32_t bw = (uint32_t)a.u0[ct * (size_t)(N + 1) + N];
+      if (a.u1) bw += (uint32_t)a.u1[ct * (size_t)(N + 1) + N];
+      v += bw + (uint32_t)a.bconst;
+    }
+    a.out[ct * W + w] = (int32_t)v;
   }
 }
 
@@ -383,20 +432,26 @@ __global__ __launch_bounds__(256) void sumpool_kernel(int32_t* __restrict__ out,
 // -------------------------------------------------------------------------------------------------
 // Launchers
 // -------------------------------------------------------------------------------------------------
-hipError_t launch_keyswitch(const KeyswitchArgs& a, hipStream_t st) {
-  if (a.B <= 0) return hipSuccess;
-  // small batches: slice the input coefficients until enough workgroups exist (latency form); the slices add their partial
-  // sums into a zeroed output with integer atomics
-  auto slice = [&](dim3& g, unsigned want, int min_per_slice) -> hipError_t {
-    unsigned split = 1;
-    while (split < 64 && g.x * g.y * split < want && a.N / (int)(2 * split) >= min_per_slice) split *= 2;
-    if (split > 1) {
-      hipError_t e = hipMemsetAsync(a.out, 0, (size_t)a.B * a.W * sizeof(int32_t), st);
-      if (e != hipSuccess) return e;
-      g.z = split;
-    }
-    return hipSuccess;
-  };
+// Slices of the N input coefficients for a tiled launch of a.B ciphertexts (1 = plain-store throughput form): doubled until
+// ~1024 workgroups exist, at most 64, every slice at least `min_per_slice` staging groups... coefficients long.
+static bool ks_tiled_shape(const KeyswitchArgs& a) {
+  return (a.t == 8 && a.basebit == 2) || (a.t == 9 && a.basebit == 3) || (a.t == 18 && a.basebit == 1);
+}
+static unsigned ks_slices(const KeyswitchArgs& a) {
+  if (!ks_tiled_shape(a) || a.B <= 0) return 1;
+  const unsigned gx = (unsigned)((a.B + KS_TILE_THREADS - 1) / KS_TILE_THREADS), gy = (unsigned)((a.W + KS_CH - 1) / KS_CH);
+  unsigned split = 1;
+  while (split < 64 && gx * gy * split < 1024 && a.N / (int)(2 * split) >= 4) split *= 2;
+  return split;
+}
+size_t keyswitch_scratch_words(const KeyswitchArgs& a) {
+  const unsigned split = ks_slices(a);
+  return split > 1 ? (size_t)split * (size_t)a.W * (size_t)a.B : 0;
+}
+
+hipError_t launch_keyswitch(const KeyswitchArgs& a_in, hipStream_t st) {
+  if (a_in.B <= 0) return hipSuccess;
+  KeyswitchArgs a = a_in;
   // (basebit = 1, the (18, 1) keys of redsec_params_small / medium / large: a digit is one bit and the selected row is the same
   // for every lane, so a form that reads the rows with SCALAR loads and adds them under the execution mask -- no LDS at all --
   // was built and measured in round 3: bit-exact, and slower than the tiled kernel, 21.7 against 14.7 ms per 1,024 medium
@@ -404,9 +459,16 @@ hipError_t launch_keyswitch(const KeyswitchArgs& a, hipStream_t st) {
   // (i, j) with ~100 scalar registers to keep three rows in flight is latency-bound. Removed again; profiles/r03/t_*.)
   dim3 grid((unsigned)((a.B + KS_TILE_THREADS - 1) / KS_TILE_THREADS), (unsigned)((a.W + KS_CH - 1) / KS_CH), 1);
   // tiled forms: the two shipped shapes and (18, 1) of redsec_params_small / medium / large; any power-of-two ring
-  const bool tiled = (a.t == 8 && a.basebit == 2) || (a.t == 9 && a.basebit == 3) || (a.t == 18 && a.basebit == 1);
-  if (tiled) {
-    if (hipError_t e = slice(grid, 1024, 4); e != hipSuccess) return e;
+  const bool tiled = ks_tiled_shape(a);
+  // small batches: slice the input coefficients until enough workgroups exist (latency form). The slices leave their partial
+  // sums in the scratch and a second kernel adds them up; without a scratch they add into a zeroed output with integer atomics.
+  const unsigned split = ks_slices(a);
+  grid.z = split;
+  const bool two_step = split > 1 && a.scratch && a.scratch_words >= keyswitch_scratch_words(a);
+  if (!two_step) a.scratch = nullptr;
+  if (split > 1 && !two_step) {
+    hipError_t e = hipMemsetAsync(a.out, 0, (size_t)a.B * a.W * sizeof(int32_t), st);
+    if (e != hipSuccess) return e;
   }
   if (tiled && a.t == 8) {
     hipLaunchKernelGGL((keyswitch_tiled_kernel<8, 2, 4>), grid, dim3(KS_TILE_THREADS), 0, st, a);
@@ -418,6 +480,11 @@ hipError_t launch_keyswitch(const KeyswitchArgs& a, hipStream_t st) {
     // generic gather form: any ring degree, any (t, basebit), any sample width
     const unsigned wy = (unsigned)((a.W + KS_THREADS * KS_MAXR - 1) / (KS_THREADS * KS_MAXR));
     hipLaunchKernelGGL(keyswitch_kernel, dim3((unsigned)a.B, wy), dim3(KS_THREADS), 0, st, a);
+  }
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+  if (two_step) {
+    const dim3 rgrid((unsigned)((a.B + KS_RT - 1) / KS_RT), (unsigned)((a.W + KS_RT - 1) / KS_RT));
+    hipLaunchKernelGGL(keyswitch_reduce_kernel, rgrid, dim3(KS_RT * KS_RT), 0, st, a, (int)split);
   }
   return hipGetLastError();
 }

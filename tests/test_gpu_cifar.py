@@ -124,14 +124,17 @@ def test_binarynet_full_every_bootstrapped_stage_against_the_oracle(maxpool):
 
     def wrap(v):
         return ((v + (1 << 31)) % (1 << 32)) - (1 << 31)
+    n_strong = 0
     for rec in taps:
         ph_in = phase(rec["inputs"][0]) if rec["kind"] == "sign" else wrap(phase(rec["inputs"][0]) + phase(rec["inputs"][1]) + (1 << 29))
         strong = (ph_in.abs() >= (32 << 20)) & (ph_in.abs() <= (1 << 31) - (32 << 20))
         want = torch.where(ph_in >= 0, rec["mu"], -rec["mu"])
         err = (phase(rec["out"]) - want).abs()
-        assert int(strong.sum()) > 0 and bool((err[strong] < rec["mu"] // 2).all()), rec["name"]
+        assert bool((err[strong] < rec["mu"] // 2).all()), rec["name"]      # (conv1 has 27 taps: no pre-activation reaches 32)
+        n_strong += int(strong.sum())
         if rec["kind"] == "or":
             assert bool(strong.all()), rec["name"]            # gate inputs at +-1/8 are never near a boundary
+    assert n_strong > 100000
     # the logits are the final layer of the bits the last bootstrapped stage produced (no bootstrap behind it)
     bits = torch.where(phase(taps[-1]["out"]) >= 0, 1, -1).cpu().numpy()
     sgn, zero, bias = net.fcs[-1]
