@@ -229,11 +229,16 @@ int rs_copy_dev_to_dev(rs_ctx* dst_ctx, void* dst_dev, rs_ctx* src_ctx, const vo
  * NUM_GPUS devices, lib/GPU/Layer.cuh:15,22-37, which has no merge step at all). bufs[d] is context d's full replica
  * int32[rows][row_words]; context d has just computed rows shard(d) = the d-th of n balanced contiguous slices (sizes differ
  * by at most one, lower ranks first) into it, on ITS default stream. Afterwards every replica holds every slice.
- * Entirely asynchronous and event-ordered: each context records an event behind its slice; every destination pulls
- * slice e on a private copy stream as soon as e's event has fired (hipMemcpyPeerAsync over xGMI, peer access enabled once per
- * device pair; contexts on one device copy device-to-device), so slice e moves while e+1 is still being computed; finally
- * every context's default stream waits for all copies, so later launches (and buffer reuse) on any of them are ordered
- * behind the exchange. Nothing blocks the host. */
+ * Entirely asynchronous and event-ordered: each context records an event on its default stream at the start of the call
+ * (behind the kernels that wrote its slice AND behind whatever it queued earlier that still reads bufs[d]'s previous
+ * contents); every destination first waits for its own event, then pulls slice e on a private copy stream as soon as e's
+ * event has fired, so slice e moves while e+1 is still being computed; finally every context's default stream waits for
+ * all copies, so later launches (and buffer reuse) on any of them are ordered behind the exchange. Nothing blocks the host.
+ * Path per device pair: contexts on one device copy device-to-device; different devices use hipMemcpyPeerAsync over xGMI
+ * when hipDeviceCanAccessPeer + hipDeviceEnablePeerAccess succeed (asked once per pair), and otherwise the library stages the
+ * slice through pinned host memory itself (source D2H once, each such destination H2D) -- slower, same result
+ * (RS_FORCE_HOST_STAGED=1 at rs_create forces that path everywhere: how a one-GPU box tests it). The operation list is
+ * host logic (csrc/rs_host.h exchange_plan), checked on the CPU. */
 int rs_allgather_rows(rs_ctx* const* ctxs, int n_ctx, int32_t* const* bufs, size_t rows, size_t row_words);
 int rs_sync(rs_ctx* ctx);
 /* Drops the private state a context keeps for `stream` (workspace, certificate slots, events; see "Streams" above) after

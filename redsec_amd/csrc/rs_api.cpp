@@ -106,8 +106,11 @@ struct rs_ctx {
   size_t io_batch = 0;
   // rs_allgather_rows: private copy stream, "my slice is computed" / "my copies are done" events, peers already enabled
   hipStream_t copy_stream = nullptr;
-  hipEvent_t ev_slice = nullptr, ev_copied = nullptr;
-  std::vector<int> peers_enabled;
+  hipEvent_t ev_slice = nullptr, ev_copied = nullptr, ev_staged = nullptr;
+  bool copied_recorded = false;
+  std::vector<int> peers_enabled, peers_denied;
+  int32_t* h_stage = nullptr;                       // pinned staging buffer of this context's slice (host-staged exchange only)
+  size_t h_stage_bytes = 0;
 };
 
 namespace {
@@ -351,6 +354,8 @@ void destroy_ctx(rs_ctx* c) {
   for (auto& p : c->d_io) (void)hipFree(p);
   if (c->ev_slice) (void)hipEventDestroy(c->ev_slice);
   if (c->ev_copied) (void)hipEventDestroy(c->ev_copied);
+  if (c->ev_staged) (void)hipEventDestroy(c->ev_staged);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   delete c;
 }
@@ -473,7 +478,7 @@ int rs_create(rs_ctx** out, const rs_params* p, int device) {
   if (const char* v = getenv("REDSEC_SPLIT_CERT_LIMIT")) { const double x = atof(v); if (x > 0.0 && x < 0.25) c->split_cert_limit = x; }   // test hook: can only tighten
   c->opts.no_coop = env_on("RS_NO_COOP"); c->opts.no_wg = env_on("RS_NO_WG"); c->opts.no_duo = env_on("RS_NO_DUO");
   c->opts.no_persist = env_on("RS_NO_PERSIST"); c->opts.no_conv_tiled = env_on("RS_NO_CONV_TILED");
-  c->opts.no_wg4 = env_on("RS_NO_WG4"); c->opts.no_tail = env_on("RS_NO_TAIL"); c->opts.no_coop8 = env_on("RS_NO_COOP8"); c->opts.ks_atomics = env_on("RS_KS_ATOMICS");
+  c->opts.no_wg4 = env_on("RS_NO_WG4"); c->opts.no_tail = env_on("RS_NO_TAIL"); c->opts.no_coop8 = env_on("RS_NO_COOP8"); c->opts.ks_atomics = env_on("RS_KS_ATOMICS"); c->opts.force_host_staged = env_on("RS_FORCE_HOST_STAGED");
   Lane* ln = nullptr;
   if (lane_of(c, nullptr, &ln) != RS_OK) { destroy_ctx(c); return RS_ERR_HIP; }   // the default stream's lane
   *out = c;
@@ -929,42 +934,73 @@ static int exchange_state(rs_ctx* c) {
   if (!c->copy_stream) RS_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   if (!c->ev_slice) RS_HIP(hipEventCreateWithFlags(&c->ev_slice, hipEventDisableTiming));
   if (!c->ev_copied) RS_HIP(hipEventCreateWithFlags(&c->ev_copied, hipEventDisableTiming));
+  if (!c->ev_staged) RS_HIP(hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
   return RS_OK;
+}
+// May context dc's device read context sc's device directly? Asked once per device pair; a refusal (no link, or enabling fails)
+// is remembered and the pair exchanges through pinned host memory from then on.
+static bool peer_access(rs_ctx* dc, rs_ctx* sc) {
+  if (dc->device == sc->device) return true;
+  if (std::find(dc->peers_enabled.begin(), dc->peers_enabled.end(), sc->device) != dc->peers_enabled.end()) return true;
+  if (std::find(dc->peers_denied.begin(), dc->peers_denied.end(), sc->device) != dc->peers_denied.end()) return false;
+  int can = 0;
+  bool ok = hipSetDevice(dc->device) == hipSuccess && hipDeviceCanAccessPeer(&can, dc->device, sc->device) == hipSuccess && can;
+  if (ok) {
+    const hipError_t pe = hipDeviceEnablePeerAccess(sc->device, 0);
+    ok = pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled;
+  }
+  (void)hipGetLastError();
+  (ok ? dc->peers_enabled : dc->peers_denied).push_back(sc->device);
+  return ok;
 }
 int rs_allgather_rows(rs_ctx* const* ctxs, int n, int32_t* const* bufs, size_t rows, size_t row_words) {
   if (!ctxs || !bufs || n < 1) return fail(RS_ERR_INVALID, "null argument");
   if (n == 1 || rows == 0) return RS_OK;
+  std::vector<int> devices(n);
   for (int d = 0; d < n; ++d) {
     if (!ctxs[d] || !bufs[d]) return fail(RS_ERR_INVALID, "null context or buffer %d", d);
     const int rc = exchange_state(ctxs[d]);
     if (rc) return rc;
-    RS_HIP(hipEventRecord(ctxs[d]->ev_slice, nullptr));   // behind the kernels that wrote slice d (default stream of device d)
+    // behind everything queued on device d's default stream so far: the kernels that wrote slice d, and the kernels that still
+    // read the block bufs[d] was recycled from (see rs_host.h, exchange_plan)
+    RS_HIP(hipEventRecord(ctxs[d]->ev_slice, nullptr));
+    devices[d] = ctxs[d]->device;
   }
-  const std::vector<rs::SliceCopy> plan = rs::exchange_schedule(rows, n);   // destination-major: each destination's copies queue on ITS stream
+  std::vector<unsigned char> peer((size_t)n * n, 1);
+  bool force_staged = false;
   for (int d = 0; d < n; ++d) {
-    rs_ctx* dc = ctxs[d];
-    RS_HIP(hipSetDevice(dc->device));
-    for (const rs::SliceCopy& cp : plan) {
-      if (cp.dst != d) continue;
-      rs_ctx* sc = ctxs[cp.src];
-      const size_t off = cp.lo * row_words, bytes = (cp.hi - cp.lo) * row_words * sizeof(int32_t);
-      RS_HIP(hipStreamWaitEvent(dc->copy_stream, sc->ev_slice, 0));
-      if (dc->device == sc->device) {
-        RS_HIP(hipMemcpyAsync(bufs[d] + off, bufs[cp.src] + off, bytes, hipMemcpyDeviceToDevice, dc->copy_stream));
-      } else {
-        if (std::find(dc->peers_enabled.begin(), dc->peers_enabled.end(), sc->device) == dc->peers_enabled.end()) {
-          int can = 0;
-          if (hipDeviceCanAccessPeer(&can, dc->device, sc->device) == hipSuccess && can) {
-            const hipError_t pe = hipDeviceEnablePeerAccess(sc->device, 0);
-            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return fail(RS_ERR_HIP, "hipDeviceEnablePeerAccess(%d -> %d): %s", dc->device, sc->device, hipGetErrorString(pe));
-            (void)hipGetLastError();
-          }
-          dc->peers_enabled.push_back(sc->device);       // without peer access hipMemcpyPeerAsync stages through the host: slower, still correct
+    force_staged = force_staged || ctxs[d]->opts.force_host_staged;
+    for (int e = 0; e < n; ++e) if (e != d) peer[(size_t)d * n + e] = peer_access(ctxs[d], ctxs[e]) ? 1 : 0;
+  }
+  const std::vector<rs::ExchangeOp> ops = rs::exchange_plan(rows, n, devices.data(), peer.data(), force_staged);
+  for (const rs::ExchangeOp& op : ops) {
+    rs_ctx* c = ctxs[op.ctx];
+    rs_ctx* o = ctxs[op.other];
+    RS_HIP(hipSetDevice(c->device));
+    const size_t off = op.lo * row_words, bytes = (op.hi - op.lo) * row_words * sizeof(int32_t);
+    switch (op.kind) {
+      case rs::kOpWaitSlice: RS_HIP(hipStreamWaitEvent(c->copy_stream, o->ev_slice, 0)); break;
+      case rs::kOpWaitCopied: if (o->copied_recorded) RS_HIP(hipStreamWaitEvent(c->copy_stream, o->ev_copied, 0)); break;
+      case rs::kOpWaitStaged: RS_HIP(hipStreamWaitEvent(c->copy_stream, o->ev_staged, 0)); break;
+      case rs::kOpStageOut:
+        if (bytes > c->h_stage_bytes) {
+          // growing the pinned buffer: nothing of an earlier exchange may still read the old one
+          for (int e = 0; e < n; ++e) { RS_HIP(hipSetDevice(ctxs[e]->device)); RS_HIP(hipStreamSynchronize(ctxs[e]->copy_stream)); }
+          RS_HIP(hipSetDevice(c->device));
+          if (c->h_stage) { (void)hipHostFree(c->h_stage); c->h_stage = nullptr; c->h_stage_bytes = 0; }
+          RS_HIP(hipHostMalloc((void**)&c->h_stage, bytes, hipHostMallocPortable));
+          c->h_stage_bytes = bytes;
         }
-        RS_HIP(hipMemcpyPeerAsync(bufs[d] + off, dc->device, bufs[cp.src] + off, sc->device, bytes, dc->copy_stream));
-      }
+        RS_HIP(hipMemcpyAsync(c->h_stage, bufs[op.ctx] + off, bytes, hipMemcpyDeviceToHost, c->copy_stream));
+        RS_HIP(hipEventRecord(c->ev_staged, c->copy_stream));
+        break;
+      case rs::kOpCopy:
+        if (op.path == rs::kPathSameDevice) RS_HIP(hipMemcpyAsync(bufs[op.ctx] + off, bufs[op.other] + off, bytes, hipMemcpyDeviceToDevice, c->copy_stream));
+        else if (op.path == rs::kPathPeer) RS_HIP(hipMemcpyPeerAsync(bufs[op.ctx] + off, c->device, bufs[op.other] + off, o->device, bytes, c->copy_stream));
+        else RS_HIP(hipMemcpyAsync(bufs[op.ctx] + off, o->h_stage, bytes, hipMemcpyHostToDevice, c->copy_stream));
+        break;
+      case rs::kOpRecordCopied: RS_HIP(hipEventRecord(c->ev_copied, c->copy_stream)); c->copied_recorded = true; break;
     }
-    RS_HIP(hipEventRecord(dc->ev_copied, dc->copy_stream));
   }
   // every default stream continues behind ALL copies: its own (it reads the gathered slices next) and the others' (they read
   // its slice; the caller may reuse or free the buffer in stream order afterwards)

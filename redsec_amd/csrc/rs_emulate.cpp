@@ -741,6 +741,16 @@ long rs_emu_exchange_schedule(long rows, int n, long* out) {
   }
   return (long)plan.size();
 }
+// the operation list of rs_allgather_rows for n contexts on `devices`, peer[d * n + s] = direct access allowed; rows of
+// (kind, ctx, other, path, lo, hi); returns the number of operations (out may be null)
+long rs_emu_exchange_plan(long rows, int n, const int* devices, const unsigned char* peer, int force_staged, long* out) {
+  const std::vector<rs::ExchangeOp> ops = rs::exchange_plan((size_t)rows, n, devices, peer, force_staged != 0);
+  if (out) for (size_t i = 0; i < ops.size(); ++i) {
+    out[6 * i] = ops[i].kind; out[6 * i + 1] = ops[i].ctx; out[6 * i + 2] = ops[i].other; out[6 * i + 3] = ops[i].path;
+    out[6 * i + 4] = (long)ops[i].lo; out[6 * i + 5] = (long)ops[i].hi;
+  }
+  return (long)ops.size();
+}
 // measured transform errors (see GenEmu::transform_error_ratios) and the analysis' per-transform bounds g_f - 1, g_i - 1
 int rs_emu_gen_transform_errors(int logn, uint64_t seed, int amplitude, double* measured2, double* bounds2) {
   const double u = std::ldexp(1.0, -53), r2 = std::sqrt(2.0);

@@ -51,6 +51,57 @@ inline std::vector<SliceCopy> exchange_schedule(size_t rows, int n) {
   return out;
 }
 
+// How one slice travels from the context that computed it to a context that needs it. Peer access is asked for per device pair
+// (hipDeviceCanAccessPeer + hipDeviceEnablePeerAccess); where it is refused the slice is staged through pinned host memory by
+// this library itself -- source D2H once, every such destination H2D -- instead of relying on what the runtime does then.
+enum CopyPath { kPathSameDevice = 0, kPathPeer = 1, kPathHostStaged = 2 };
+inline CopyPath choose_copy_path(int dst_device, int src_device, bool peer_access, bool force_staged) {
+  if (force_staged) return kPathHostStaged;
+  if (dst_device == src_device) return kPathSameDevice;
+  return peer_access ? kPathPeer : kPathHostStaged;
+}
+// The exchange as the literal list of operations rs_allgather_rows issues, in issue order. Every context has one copy stream and
+// the events "slice" (recorded on its COMPUTE stream at the start of the call: everything queued there so far -- the kernels that
+// wrote its slice and the kernels that still read the block the gathered batch lands in), "staged" (its slice sits in its pinned
+// staging buffer) and "copied" (every copy INTO its buffer is done; recorded last on its copy stream).
+//   kOpWaitSlice  ctx's copy stream waits for other's "slice"        kOpStageOut    ctx: D2H of its own slice, then record "staged"
+//   kOpWaitCopied ctx's copy stream waits for other's "copied"       kOpWaitStaged  ctx's copy stream waits for other's "staged"
+//   (of the PREVIOUS call: its staging buffer may still be read)     kOpCopy        ctx pulls rows [lo, hi) of other by `path`
+//   kOpRecordCopied  record ctx's "copied"
+// Invariants (checked on the CPU by tests/test_sharding_gloo.py through the emulator library):
+//   * before its first copy a destination waits for its OWN "slice": its buffer may be a recycled block that kernels queued on
+//     its compute stream are still reading (round-3 advisor finding: a fast source could overwrite it);
+//   * every copy waits for the source's "slice" (direct paths) or "staged" (host path), and a source stages once per call,
+//     behind its own "slice" and behind every context's previous "copied".
+enum { kOpWaitSlice = 0, kOpWaitCopied = 1, kOpStageOut = 2, kOpWaitStaged = 3, kOpCopy = 4, kOpRecordCopied = 5 };
+struct ExchangeOp { int kind, ctx, other, path; size_t lo, hi; };
+// devices[i]: device of context i; peer[d * n + s] != 0: context d's device may read context s's device directly.
+inline std::vector<ExchangeOp> exchange_plan(size_t rows, int n, const int* devices, const unsigned char* peer, bool force_staged) {
+  std::vector<ExchangeOp> ops;
+  const std::vector<SliceCopy> copies = exchange_schedule(rows, n);
+  auto path_of = [&](const SliceCopy& c) { return choose_copy_path(devices[c.dst], devices[c.src], peer[c.dst * n + c.src] != 0, force_staged); };
+  for (int s = 0; s < n; ++s) {
+    bool staged = false;
+    size_t lo = 0, hi = 0;
+    for (const SliceCopy& c : copies) if (c.src == s && path_of(c) == kPathHostStaged) { staged = true; lo = c.lo; hi = c.hi; }
+    if (!staged) continue;
+    ops.push_back({kOpWaitSlice, s, s, 0, 0, 0});
+    for (int e = 0; e < n; ++e) ops.push_back({kOpWaitCopied, s, e, 0, 0, 0});
+    ops.push_back({kOpStageOut, s, s, kPathHostStaged, lo, hi});
+  }
+  for (int d = 0; d < n; ++d) {
+    ops.push_back({kOpWaitSlice, d, d, 0, 0, 0});
+    for (const SliceCopy& c : copies) {
+      if (c.dst != d) continue;
+      const CopyPath path = path_of(c);
+      ops.push_back({path == kPathHostStaged ? kOpWaitStaged : kOpWaitSlice, d, c.src, 0, 0, 0});
+      ops.push_back({kOpCopy, d, c.src, (int)path, c.lo, c.hi});
+    }
+    ops.push_back({kOpRecordCopied, d, d, 0, 0, 0});
+  }
+  return ops;
+}
+
 inline uint64_t mulmod_u64(uint64_t a, uint64_t b, uint64_t p) { return (uint64_t)((u128_t)a * b % p); }
 inline uint64_t powmod_u64(uint64_t b, uint64_t e, uint64_t p) {
   uint64_t r = 1;

@@ -255,10 +255,12 @@ namespace redsec_host {
 // A ciphertext array on the device(s): one full replica int32[rows][W] per context of the fleet (one context =
 // one GPU; a single GPU unless REDSEC_DEVICES lists several).
 // Device buffers come from a per-context cache instead of hipMalloc / hipFree per stage (hipFree waits for the whole device;
-// a layer chain allocates and frees a few hundred MB a dozen times per image, always the same few sizes). Every use of a
-// context's buffers is enqueued on its device's default stream in program order (launches, the synchronous host copies, and
-// rs_allgather_rows, which makes every default stream wait for all peer copies), so handing a block out again in stream order
-// is safe without waiting for anything.
+// a layer chain allocates and frees a few hundred MB a dozen times per image, always the same few sizes). Blocks are handed
+// out again in HOST order without waiting for anything, which is safe because every use of a context's buffers is ordered
+// against its device's default stream: launches and the synchronous host copies are enqueued there in program order, and
+// rs_allgather_rows -- the one user of OTHER streams (the per-context copy streams) -- makes every copy INTO a block wait for
+// an event recorded on the destination's default stream at the start of the call (so kernels still reading the block's
+// previous contents finish first) and makes every default stream wait for all copies before it continues.
 struct BufPool {
   std::mutex mu;
   std::multimap<size_t, void*> idle;     // size -> block

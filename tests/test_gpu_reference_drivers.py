@@ -113,17 +113,20 @@ def test_unmodified_cifar_binarynet_full_driver(tmp_path):
     assert np.corrcoef(dec, plain[i])[0, 1] > 0.5
 
 
-@pytest.mark.parametrize("family,net,devices,lazy", [("mnist", "sign1024x1", "0,0", False), ("mnist", "relu1024x1", "0,0,0", False),
-                                                     ("mnist", "sign1024x1", "0,0,0,0", True), ("cifar", "binarynet_small", "0,0", False),
-                                                     ("cifar", "binarynet_small", "0,0,0,0", True)])
-def test_driver_sharded_over_several_contexts_equals_single_device(tmp_path, monkeypatch, family, net, devices, lazy):
+@pytest.mark.parametrize("family,net,devices,lazy,staged", [("mnist", "sign1024x1", "0,0", False, False), ("mnist", "relu1024x1", "0,0,0", False, False),
+                                                            ("mnist", "sign1024x1", "0,0,0,0", True, False), ("cifar", "binarynet_small", "0,0", False, False),
+                                                            ("cifar", "binarynet_small", "0,0,0,0", True, False),
+                                                            ("mnist", "relu1024x1", "0,0,0", False, True), ("cifar", "binarynet_small", "0,0,0", True, True)])
+def test_driver_sharded_over_several_contexts_equals_single_device(tmp_path, monkeypatch, family, net, devices, lazy, staged):
     """Gate-parallel evaluation of ONE image inside the C++ layer mirror (the reference's shape: enc_segs[NUM_GPUS], one host
     thread per GPU, lib/GPU/BinFunc_gpu.cu:119-137): REDSEC_DEVICES lists the devices, every bootstrapped stage is split
     contiguously across one context per entry and the slices are exchanged device to device before the next linear stage.
     On a one-GPU box the same device is listed several times -- several contexts, the same code path, ragged slices with
     three -- and the unmodified driver's network_output.ctxt must equal the single-device run BYTE FOR BYTE. The exchange is
     rs_allgather_rows: one host thread per context, event-ordered asynchronous copies, no device-wide waits. `lazy` adds
-    REDSEC_LAZY_HOST=1 to the sharded run: intermediate host arrays stay unfilled, only the logits come down."""
+    REDSEC_LAZY_HOST=1 to the sharded run: intermediate host arrays stay unfilled, only the logits come down. `staged` adds
+    RS_FORCE_HOST_STAGED=1: every slice travels through pinned host memory (source D2H once, destinations H2D) -- the path a
+    device pair without peer access takes, which a one-GPU box cannot reach otherwise."""
     import shutil
     from redsec_amd import client
     exe = "%s_%s_enc.out" % (family, net)
@@ -153,6 +156,8 @@ def test_driver_sharded_over_several_contexts_equals_single_device(tmp_path, mon
             monkeypatch.setenv("REDSEC_DEVICES", dev)
             if lazy:
                 monkeypatch.setenv("REDSEC_LAZY_HOST", "1")
+            if staged:
+                monkeypatch.setenv("RS_FORCE_HOST_STAGED", "1")
         r = rd.run(exe, netdir)
         assert r.returncode == 0 and "Result ctxts loaded" in r.stdout, r.stdout + r.stderr
         outs.append(open(os.path.join(cdir, "network_output.ctxt"), "rb").read())

@@ -174,3 +174,61 @@ def test_sharded_bootstrap_stage_two_ranks_one_device():
         p.join(600)
         assert p.exitcode == 0
     assert ret.get(timeout=5) == 1
+
+
+def test_exchange_plan_orders_every_copy_and_falls_back_to_host_staging():
+    """The literal operation list rs_allgather_rows issues (csrc/rs_host.h::exchange_plan), for device sets with and without peer
+    access: (1) a destination's copy stream waits for the destination's OWN "slice" event before its first copy -- the block it
+    receives into may have been recycled while kernels on its compute stream still read it (round-3 advisor finding);
+    (2) every copy is preceded, on the same stream, by a wait for its source (the source's "slice" event on the direct paths,
+    its "staged" event on the host path); (3) the path is same-device / peer / host-staged exactly as hipDeviceCanAccessPeer
+    allows, and forcing host staging covers every pair; (4) a source stages once, behind its own slice and behind every
+    context's previous "copied" event (its pinned buffer may still be read), before anyone waits for it."""
+    import ctypes as C
+    import itertools
+    import emu_lib
+    L = emu_lib.lib()
+    L.rs_emu_exchange_plan.restype = C.c_long
+    WAIT_SLICE, WAIT_COPIED, STAGE_OUT, WAIT_STAGED, COPY, RECORD_COPIED = range(6)
+    SAME, PEER, STAGED = range(3)
+    cases = [([0, 0, 0], None, 0), ([0, 1, 2, 3], "all", 0), ([0, 1, 2, 3], "none", 0), ([0, 1, 2], "ring", 0), ([0, 0, 1, 1], "none", 0),
+             ([0, 0], None, 1), ([0, 1, 2, 3, 4, 5, 6, 7], "all", 0), ([0, 1, 2, 3, 4, 5, 6, 7], "all", 1)]
+    for devices, access, force in cases:
+        n = len(devices)
+        peer = [[1] * n for _ in range(n)]
+        if access == "none":
+            peer = [[1 if devices[d] == devices[s] else 0 for s in range(n)] for d in range(n)]
+        elif access == "ring":                                     # only neighbours see each other
+            peer = [[1 if abs(d - s) in (0, 1, n - 1) and not (n == 3 and {d, s} == {0, 2}) else 0 for s in range(n)] for d in range(n)]
+        flat = (C.c_ubyte * (n * n))(*itertools.chain.from_iterable(peer))
+        dev = (C.c_int * n)(*devices)
+        for rows in (5, 196, 131072):
+            cnt = L.rs_emu_exchange_plan(rows, n, dev, flat, force, None)
+            buf = (C.c_long * (6 * cnt))()
+            assert L.rs_emu_exchange_plan(rows, n, dev, flat, force, buf) == cnt
+            ops = [tuple(buf[6 * i:6 * i + 6]) for i in range(cnt)]
+            spans = [sharding.shard_range(rows, r, n) for r in range(n)]
+            waited = {c: set() for c in range(n)}                  # per copy stream: ("slice" | "staged" | "copied", ctx) seen so far
+            staged_at, copies = {}, set()
+            for pos, (kind, ctx, other, path, lo, hi) in enumerate(ops):
+                if kind == WAIT_SLICE:
+                    waited[ctx].add(("slice", other))
+                elif kind == WAIT_COPIED:
+                    waited[ctx].add(("copied", other))
+                elif kind == WAIT_STAGED:
+                    assert other in staged_at, "waiting for a staging copy that was never issued"
+                    waited[ctx].add(("staged", other))
+                elif kind == STAGE_OUT:
+                    assert ctx not in staged_at and (lo, hi) == spans[ctx]
+                    assert ("slice", ctx) in waited[ctx] and all(("copied", e) in waited[ctx] for e in range(n))
+                    staged_at[ctx] = pos
+                elif kind == COPY:
+                    assert ("slice", ctx) in waited[ctx], "destination did not wait for its own compute stream"
+                    want = STAGED if force else (SAME if devices[ctx] == devices[other] else (PEER if peer[ctx][other] else STAGED))
+                    assert path == want and (lo, hi) == spans[other] and hi > lo
+                    assert (("staged", other) if path == STAGED else ("slice", other)) in waited[ctx]
+                    copies.add((ctx, other))
+                elif kind == RECORD_COPIED:
+                    assert all((ctx, e) in copies for e in range(n) if e != ctx and spans[e][1] > spans[e][0])
+            assert copies == {(d, e) for d in range(n) for e in range(n) if d != e and spans[e][1] > spans[e][0]}
+            assert sum(1 for o in ops if o[0] == RECORD_COPIED) == n
