@@ -43,7 +43,10 @@ typedef enum rs_status {
   RS_ERR_HIP = -3,         /* a HIP runtime call failed */
   RS_ERR_STATE = -4,       /* keys not loaded, etc. */
   RS_ERR_INEXACT = -5      /* RS_MODE_FFT_SPLIT: the enforced rounding certificate failed (see rs_split_bound); sticky until
-                              rs_certify(..., reset = 1) */
+                              rs_certify(..., reset = 1). The check of call k on a stream is looked at by call k + 1 on that
+                              stream, rs_sync, rs_certify, rs_release_stream, rs_destroy and every host-pointer call -- NOT by
+                              the *_dev call itself (it is asynchronous): a device-pointer caller must pass one of those
+                              before trusting the LAST call's output (rs_destroy returns the error too) */
 } rs_status;
 
 /* Mirrors TFheGateBootstrappingParameterSet (ks_t, ks_basebit, in_out_params->n, tgsw_params->l,

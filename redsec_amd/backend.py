@@ -179,9 +179,11 @@ class Backend:
         self.h = h
 
     def close(self):
+        """rs_destroy; raises if the enforced split-mode certificate of some stream's last call had failed (nothing else would
+        look at it any more)."""
         if getattr(self, "h", None):
-            self.L.rs_destroy(self.h)
-            self.h = None
+            h, self.h = self.h, None
+            _check(self.L, self.L.rs_destroy(h))
 
     def __del__(self):
         try:

@@ -489,8 +489,16 @@ int rs_destroy(rs_ctx* c) {
   if (!c) return RS_OK;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
+  // the enforced split-mode certificate of every stream's LAST call: nothing looks at it after this point, so a device-pointer
+  // caller who never calls rs_sync / rs_certify still learns about a failed check here (the context is destroyed either way)
+  int rc = RS_OK;
+  {
+    std::lock_guard<std::mutex> g(c->lanes_mu);
+    for (auto& kv : c->lanes) { const int r = split_check_lane(c, kv.second.get()); if (r) rc = r; }
+  }
+  if (rc == RS_OK && c->inexact.load()) rc = inexact_error(c);
   destroy_ctx(c);
-  return RS_OK;
+  return rc;
 }
 
 // bk / ksk: host arrays, or both null for the synthetic key of `seed` generated on the device (rs_load_synthetic_keys)

@@ -33,6 +33,7 @@
 
 #include "rs_fft.h"
 #include "rs_kernels.h"
+#include "rs_lds_plan.h"
 #include "rs_ntt.h"
 
 // RS_BS_PART: redsec_amd/build.py compiles this file TWICE, because its kernels want different code-generation flags
@@ -551,7 +552,7 @@ __device__ __forceinline__ void mac_pair_stream(double (&s0)[kRegs], double (&s1
   }
 }
 
-#ifdef RS_STAMPS
+#if defined(RS_STAMPS) && (RS_BS_PART & 1)   // the stamped kernel lives in part 1: one definition of the symbol per library
 // Diagnostic build only (cdna_hip_programming.md section 7, in-kernel stamps): phase sums per wave, read back by
 // rs_debug_read_stamps. Phases: 0 step prologue, 1 digits + forward pair, 2 wait for the key rows + barrier, 3 multiply-
 // accumulate, 4 barrier + next rows requested, 5 accumulator pre-read + inverse pair, 6 rounding + accumulator update,
@@ -1099,8 +1100,8 @@ __global__ __launch_bounds__(512) void blind_rotate_duos_kernel(BlindRotateArgs 
 #define RS_DUOS_ROTATE 1
 #endif
   const int rot = RS_DUOS_ROTATE ? (int)(blockIdx.x % C::L) : 0;
-  const int kcomp = wave >> 2;
-  const size_t chunk_off = (size_t)((wave & 3) * 4) * 128;
+  const int kcomp = duos_fetch_comp(wave);                                 // placement: rs_lds_plan.h (checked on the host)
+  const size_t chunk_off = (size_t)duos_first_chunk(wave) * 128;
   long issued;
   int iss_i, iss_k;   // step and position (digit slot, half) of the next pair to request
   auto issue_reset = [&] { issued = 0; iss_i = 0; iss_k = 0; };
@@ -1109,7 +1110,7 @@ __global__ __launch_bounds__(512) void blind_rotate_duos_kernel(BlindRotateArgs 
     int q = (iss_k >> 1) + rot;
     if (q >= C::L) q -= C::L;
     const long hrow = (((long)iss_i * KPL + (long)kcomp * C::L + q) << 1) + (iss_k & 1);
-    glds_chunks<4>(a.bk_x + (size_t)hrow * kSlotDoubles + chunk_off, lane_off, s_key[2 * (int)(issued & 1) + kcomp] + chunk_off);
+    glds_chunks<4>(a.bk_x + (size_t)hrow * kSlotDoubles + chunk_off, lane_off, s_key[duos_pair_slot(issued, kcomp)] + chunk_off);
     ++issued;
     if (++iss_k == 2 * C::L) { iss_k = 0; ++iss_i; }
   };
@@ -1173,16 +1174,16 @@ __global__ __launch_bounds__(512) void blind_rotate_duos_kernel(BlindRotateArgs 
           ffwd_planar(lane, x, tw, buf, sync_w);
         }
         publish(false);
-        if (work) mac_cols(lo, glo, x, s_key[2 * (int)(p & 1) + h]);
+        if (work) mac_cols(lo, glo, x, s_key[duos_pair_slot(p, h)]);
         ++p;
         publish(q + 1 == C::L);
-        if (work) mac_cols(hi, ghi, x, s_key[2 * (int)(p & 1) + h]);
+        if (work) mac_cols(hi, ghi, x, s_key[duos_pair_slot(p, h)]);
         ++p;
       }
       // partial exchange through the key buffer (64 KB = 8 waves x 8 KB), low halves, then high halves: wave (c, h) hands over
       // its partials of column 1 - h and adds its partner's partials of column h to its own
-      double* mine_xchg = &s_key[0][0] + (size_t)wave * kN;
-      const double* theirs = &s_key[0][0] + (size_t)(wave ^ 1) * kN;
+      double* mine_xchg = &s_key[0][0] + duo_xchg_doubles(wave);
+      const double* theirs = &s_key[0][0] + duo_xchg_doubles(duo_partner(wave));
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave has consumed the last pair
       if (work) {
 #pragma unroll
@@ -1276,8 +1277,8 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coops_kernel(BlindRotateA
     if (row1) v += (uint32_t)a.c1 * (uint32_t)row1[i];
     return (int32_t)v;
   };
-  auto owner = [](int sum) { return G == 4 ? sum : (sum & 1); };
-  auto slot = [](int sum, int g) { return G == 4 ? (sum < g ? sum : sum - 1) : (sum >> 1); };   // index among the sums wave g does not own
+  auto owner = [](int sum) { return coops_owner<G>(sum); };              // placement: rs_lds_plan.h (checked on the host)
+  auto slot = [](int sum, int g) { return coops_slot<G>(sum, g); };      // index among the sums wave g does not own
   if (wave < 2) {
     const int32_t barb = modswitch_2N((int32_t)((uint32_t)word(n) + (uint32_t)a.bconst));
     const int rot = 2 * kN - barb;
@@ -1475,10 +1476,10 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
   auto prot = [&](int p) { const int v = p + prot0; return v >= C::L / 2 ? v - C::L / 2 : v; };
   // quad (i, p): rows i KPL + hh L + 2 p + k; this wave fetches half of slot (wave >> 1)
   auto issue_quad = [&](int i, int p) {
-    const int slot = wave >> 1;
+    const int slot = duo_quad_slot(wave), chunk0 = duo_quad_first_chunk(wave);   // placement: rs_lds_plan.h (checked on the host)
     const long R = (long)i * KPL + (slot >> 1) * C::L + 2 * p + (slot & 1);
-    const double* src = a.bk_x + (size_t)R * kRowDoubles + (size_t)((wave & 1) * 8) * 128;
-    double* dst = s_key[slot] + ((wave & 1) * 8) * 128;
+    const double* src = a.bk_x + (size_t)R * kRowDoubles + (size_t)chunk0 * 128;
+    double* dst = s_key[slot] + chunk0 * 128;
     glds_chunks<4>(src, lane_off, dst);
     glds_chunks<4>(src + 4 * 128, lane_off, dst + 4 * 128);
   };
@@ -1552,7 +1553,7 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
         if (p + 1 < C::L / 2) issue_quad(i, prot(p + 1));
       }
       // partial exchange through the idle quad buffer: wave (c, h) hands over its partial of column 1 - h
-      double* xchg = &s_key[0][0] + (size_t)wave * kN;
+      double* xchg = &s_key[0][0] + duo_xchg_doubles(wave);
       if (work) {
 #pragma unroll
         for (int u = 0; u < kRegs; ++u) xchg[u * 64 + lane] = h ? s0[u] : s1[u];
@@ -1560,7 +1561,7 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
       __syncthreads();
       double (&mine)[kRegs] = h ? s1 : s0;
       if (work) {
-        const double* theirs = &s_key[0][0] + (size_t)(wave ^ 1) * kN;
+        const double* theirs = &s_key[0][0] + duo_xchg_doubles(duo_partner(wave));
 #pragma unroll
         for (int u = 0; u < kRegs; ++u) mine[u] += theirs[u * 64 + lane];
       }
@@ -1807,9 +1808,8 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
   using C = typename Xf::Cfg;
   static_assert(Xf::kCertificate, "FFT policy only: the exact-NTT reduction schedule is validated for four partials");
   if (recompute_not_needed(a)) return;
-  constexpr int G = 8, H = 4, L = C::L, KPL = 2 * L;
-  constexpr int kInvA = 3, kInvB = 4;
-  constexpr int kBase = L / H, kRem = L % H;
+  constexpr int G = kCoop8Waves, L = C::L, KPL = 2 * L;
+  constexpr int kInvA = kCoop8InvA, kInvB = kCoop8InvB;   // placement: rs_lds_plan.h (checked on the host)
   __shared__ double s_tw[Xf::kTableDoubles + 1];
   __shared__ double s_buf[G][kBufDoubles];
   __shared__ double s_part[G][kN];
@@ -1830,10 +1830,8 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
   const int32_t* row0 = a.in0 + ct * a.W;
   const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
   const int n = a.n;
-  const int comp = wave / H, jw = wave % H;
   // rows [first, first + cnt) of this wave's component (digit index q = first + rr, TGSW row comp * L + q)
-  const int cnt = comp == 0 ? kBase + (jw < kRem ? 1 : 0) : kBase + (jw >= H - kRem ? 1 : 0);
-  const int first = comp == 0 ? jw * kBase + (jw < kRem ? jw : kRem) : jw * kBase + (jw > H - kRem ? jw - (H - kRem) : 0);
+  const int comp = coop8_comp(wave), cnt = coop8_row_count(L, wave), first = coop8_row_first(L, wave);
   double dev = 0.0;
   auto word = [&](int i) -> int32_t {
     uint32_t v = (uint32_t)a.c0 * (uint32_t)row0[i];
@@ -1882,12 +1880,13 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
     // partial sums: column 0 into the wave's own (now idle) exchange buffer, column 1 into its s_part slot; position
     // u * 64 + lane is conflict-free. kInvA / kInvB keep the column they will invert in registers.
     {
-      double* p0 = wave == kInvB ? s_part[kInvB] : buf;
-      if (wave != kInvA) {
+      const int home0 = coop8_partial_home(wave, 0), home1 = coop8_partial_home(wave, 1);
+      if (home0 != kHomeRegisters) {
+        double* p0 = home0 == kHomePartSlot ? s_part[wave] : buf;
 #pragma unroll
         for (int u = 0; u < kRegs; ++u) p0[u * 64 + lane] = s0[u];
       }
-      if (wave != kInvB) {
+      if (home1 != kHomeRegisters) {
 #pragma unroll
         for (int u = 0; u < kRegs; ++u) s_part[wave][u * 64 + lane] = s1[u];
       }
@@ -1901,7 +1900,7 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           if (g == kInvA) continue;
-          const double* src = g == kInvB ? s_part[kInvB] : s_buf[g];
+          const double* src = coop8_partial_home(g, 0) == kHomePartSlot ? s_part[g] : s_buf[g];
 #pragma unroll
           for (int u = 0; u < kRegs; ++u) x[u] += src[u * 64 + lane];
         }
@@ -2209,7 +2208,7 @@ hipError_t launch_polymul(int cfg, int mode, const int32_t* a_small, const int32
 
 }  // namespace rs
 
-#ifdef RS_STAMPS
+#if defined(RS_STAMPS) && (RS_BS_PART & 1)
 // diagnostic builds only (not part of include/redsec_hip.h): copy the per-wave phase sums to the host and clear them
 extern "C" int rs_debug_read_stamps(unsigned long long* host, size_t count) {
   const size_t all = sizeof(rs::g_rs_stamps) / sizeof(unsigned long long);

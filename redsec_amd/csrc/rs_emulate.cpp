@@ -12,6 +12,7 @@
 
 #include "rs_general.h"
 #include "rs_host.h"
+#include "rs_lds_plan.h"
 #include "rs_ntt.h"
 
 namespace {
@@ -541,6 +542,233 @@ long gen_wave_region_violations_xp() {
   return bad;
 }
 
+// ---- LDS protocol model of the N = 1024 blind-rotation forms (rs_lds_plan.h) --------------------------------------------
+// The waves of a workgroup advance from barrier to barrier; an EPOCH is what lies between two consecutive workgroup barriers.
+// Inside an epoch nothing orders the waves, so two accesses by DIFFERENT waves to overlapping bytes, at least one a write,
+// are a race (an LDS atomic against an LDS atomic is not). A direct global->LDS load is a write that may land at any moment
+// from its issue to the barrier behind the issuing wave's s_waitcnt: it is entered into every epoch of that span. Each form
+// below replays two CMUX steps of its kernel with the placement functions of rs_lds_plan.h -- the same functions the kernels
+// call -- and the checker counts conflicting pairs. `broken` != 0 perturbs ONE decision of the protocol (a placement, a slot
+// count, a hold) the way a plausible edit would: the count must then be positive, which shows the check can see such an edit.
+namespace {
+struct LdsAcc { int wave, epoch, kind; long lo, hi; };   // kind 0 read, 1 write, 2 atomic
+struct LdsModel {
+  std::vector<LdsAcc> v;
+  int epoch = 0;
+  enum : long { BUF = 1L << 24, PART = 2L << 24, ACC = 3L << 24, KEY = 4L << 24 };   // array bases (bytes); windows never cross
+  void acc(int w, int kind, long lo, long bytes, int e = -1) { v.push_back({w, e < 0 ? epoch : e, kind, lo, lo + bytes}); }
+  void rd(int w, long lo, long bytes) { acc(w, 0, lo, bytes); }
+  void wr(int w, long lo, long bytes) { acc(w, 1, lo, bytes); }
+  void rw(int w, long lo, long bytes) { rd(w, lo, bytes); wr(w, lo, bytes); }
+  void atomic(int w, long lo, long bytes) { acc(w, 2, lo, bytes); }
+  void dma(int w, long lo, long bytes, int first_epoch, int last_epoch) { for (int e = first_epoch; e <= last_epoch; ++e) acc(w, 1, lo, bytes, e); }
+  void barrier() { ++epoch; }
+  long conflicts() const {
+    long bad = 0;
+    for (size_t i = 0; i < v.size(); ++i)
+      for (size_t j = i + 1; j < v.size(); ++j) {
+        const LdsAcc &a = v[i], &b = v[j];
+        if (a.wave == b.wave || a.epoch != b.epoch || a.hi <= b.lo || b.hi <= a.lo) continue;
+        if (a.kind == 0 && b.kind == 0) continue;
+        if (a.kind == 2 && b.kind == 2) continue;
+        ++bad;
+      }
+    return bad;
+  }
+};
+constexpr long kBufBytes = (long)rs::kBufDoubles * 8, kPolyBytes = (long)rs::kN * 8, kAccBytes = (long)rs::kN * 4, kChunkBytes = 1024;
+long buf_of(int w) { return LdsModel::BUF + w * 0x10000L; }
+
+// blind_rotate_coop_kernel<G> (G = 2, 4): s_part[wave][col], waves 0 / 1 invert column 0 / 1
+long model_coop(int G, int broken) {
+  LdsModel m;
+  auto part = [&](int w, int col) { return LdsModel::PART + (w * 2 + col) * kPolyBytes; };
+  for (int step = 0; step < 2; ++step) {
+    for (int w = 0; w < G; ++w) {
+      const int comp = w / (G / 2);
+      m.rd(w, LdsModel::ACC + comp * kAccBytes, kAccBytes);
+      m.rw(w, buf_of(w), kBufBytes);
+      for (int col = 0; col < 2; ++col) m.wr(w, part(broken == 1 ? w / 2 : w, col), kPolyBytes);
+    }
+    m.barrier();
+    for (int w = 0; w < 2; ++w) {
+      for (int g = 0; g < G; ++g) m.rd(w, part(g, w), kPolyBytes);
+      m.rw(w, buf_of(w), kBufBytes);
+      m.rw(w, LdsModel::ACC + w * kAccBytes, kAccBytes);
+    }
+    if (broken != 2) m.barrier();
+  }
+  return m.conflicts();
+}
+// blind_rotate_coop8_kernel
+long model_coop8(int L, int broken) {
+  LdsModel m;
+  auto home = [&](int w, int col) {
+    int h = rs::coop8_partial_home(w, col);
+    if (broken == 1 && w == rs::kCoop8InvB && col == 0) h = rs::kHomeOwnBuffer;   // the tempting uniform rule: "column 0 into the own buffer"
+    return h;
+  };
+  auto home_addr = [&](int w, int col) { return home(w, col) == rs::kHomeOwnBuffer ? buf_of(w) : LdsModel::PART + w * kPolyBytes; };
+  for (int step = 0; step < 2; ++step) {
+    for (int w = 0; w < rs::kCoop8Waves; ++w) {
+      if (rs::coop8_row_count(L, w) > 0) {
+        m.rd(w, LdsModel::ACC + rs::coop8_comp(w) * kAccBytes, kAccBytes);
+        m.rw(w, buf_of(w), kBufBytes);
+      }
+      for (int col = 0; col < 2; ++col)
+        if (home(w, col) != rs::kHomeRegisters) m.wr(w, home_addr(w, col), kPolyBytes);
+    }
+    m.barrier();
+    for (int col = 0; col < 2; ++col) {
+      const int w = col == 0 ? rs::kCoop8InvA : rs::kCoop8InvB;
+      for (int g = 0; g < rs::kCoop8Waves; ++g)
+        if (g != w) m.rd(w, home_addr(g, col), kPolyBytes);
+      m.rw(w, buf_of(w), kBufBytes);
+      m.rw(w, LdsModel::ACC + col * kAccBytes, kAccBytes);
+    }
+    if (broken != 2) m.barrier();
+  }
+  return m.conflicts();
+}
+// blind_rotate_coops_kernel<G>: s_part[wave][slot of a sum the wave does not own]
+template <int G>
+long model_coops(int broken) {
+  LdsModel m;
+  constexpr int OWN = 4 / G;
+  auto part = [&](int w, int slot) { return LdsModel::PART + (w * (4 - OWN) + slot) * kPolyBytes; };
+  auto slot = [&](int sum, int g) { return broken == 1 ? sum % (4 - OWN) : rs::coops_slot<G>(sum, g); };
+  long same_wave_overwrites = 0;
+  for (int step = 0; step < 2; ++step) {
+    for (int w = 0; w < G; ++w) {
+      m.rd(w, LdsModel::ACC + (w / (G / 2)) * kAccBytes, kAccBytes);
+      m.rw(w, buf_of(w), kBufBytes);
+      bool used[4] = {false, false, false, false};
+      for (int k = 0; k < 4; ++k)
+        if (rs::coops_owner<G>(k) != w) {
+          const int sl = slot(k, w);
+          if (sl < 0 || sl >= 4 - OWN || used[sl]) ++same_wave_overwrites; else used[sl] = true;   // two sums of one wave in one slot
+          m.wr(w, part(w, sl < 0 ? 0 : sl % (4 - OWN)), kPolyBytes);
+        }
+    }
+    m.barrier();
+    for (int k = 0; k < 4; ++k) {
+      const int w = rs::coops_owner<G>(k);
+      for (int g = 0; g < G; ++g)
+        if (g != w) m.rd(w, part(g, rs::coops_slot<G>(k, g)), kPolyBytes);
+      m.rw(w, buf_of(w), kBufBytes);
+      if (G == 4) m.atomic(w, LdsModel::ACC + (k & 1) * kAccBytes, kAccBytes);
+      else m.rw(w, LdsModel::ACC + w * kAccBytes, kAccBytes);
+    }
+    if (broken != 2) m.barrier();
+  }
+  return m.conflicts() + same_wave_overwrites;
+}
+// blind_rotate_duo_kernel: quads of four 16 KB rows in the 64 KB key buffer, partials swapped through it
+long model_duo(int L, int broken) {
+  LdsModel m;
+  const long slot_bytes = 16 * kChunkBytes;
+  auto issue = [&](int first, int last) {
+    for (int w = 0; w < 8; ++w) m.dma(w, LdsModel::KEY + rs::duo_quad_slot(w) * slot_bytes + rs::duo_quad_first_chunk(w) * kChunkBytes, 8 * kChunkBytes, first, last);
+  };
+  auto xchg = [&](int w) { return LdsModel::KEY + (broken == 1 ? rs::duo_xchg_doubles(w) / 2 : rs::duo_xchg_doubles(w)) * 8L; };
+  issue(m.epoch, m.epoch);                                   // the first quad of the group, behind the group barrier
+  for (int step = 0; step < 2; ++step) {
+    for (int p = 0; p < L / 2; ++p) {
+      for (int w = 0; w < 8; ++w) { m.rw(w, buf_of(w), kBufBytes); if (p == 0) m.rw(w, LdsModel::ACC + w * kAccBytes, kAccBytes); }   // (inverse +) forward pair
+      m.barrier();                                           // s_waitcnt vmcnt(0); barrier: the quad is published
+      for (int w = 0; w < 8; ++w) { const int h = w & 1; m.rd(w, LdsModel::KEY + (2 * h) * slot_bytes, 2 * slot_bytes); }
+      if (!(broken == 2 && p + 1 < L / 2)) m.barrier();      // every wave has finished reading it
+      if (p + 1 < L / 2) issue(m.epoch, m.epoch);
+    }
+    if (broken == 3) issue(m.epoch, m.epoch + 1);            // the next step's first quad requested BEFORE the swap
+    for (int w = 0; w < 8; ++w) m.wr(w, xchg(w), kPolyBytes);
+    m.barrier();
+    for (int w = 0; w < 8; ++w) m.rd(w, xchg(rs::duo_partner(w)), kPolyBytes);
+    m.barrier();
+    if (broken != 3) issue(m.epoch, m.epoch);
+  }
+  return m.conflicts();
+}
+// blind_rotate_duos_kernel: pairs of half-rows (one per component) in slots 2 (p & 1) + comp; publish(hold)
+long model_duos(int L, int broken) {
+  LdsModel m;
+  const long slot_bytes = 16 * kChunkBytes;
+  long issued = 0;
+  // a request lands before the barrier of the next publish (s_waitcnt vmcnt(0) in front of it): in flight for the current
+  // epoch -- and for one more (`extra`) when the next barrier is the swap's "lgkmcnt(0); s_barrier", which waits for no load
+  auto issue_next = [&](int extra = 0) {
+    for (int w = 0; w < 8; ++w)
+      m.dma(w, LdsModel::KEY + rs::duos_pair_slot(issued, rs::duos_fetch_comp(w)) * slot_bytes + rs::duos_first_chunk(w) * kChunkBytes, 4 * kChunkBytes, m.epoch, m.epoch + extra);
+    ++issued;
+  };
+  long p = 0;
+  issue_next();
+  for (int step = 0; step < 2; ++step) {
+    for (int q = 0; q < L; ++q)
+      for (int half = 0; half < 2; ++half) {
+        const bool last = q + 1 == L && half == 1;
+        if (half == 0) for (int w = 0; w < 8; ++w) { m.rw(w, buf_of(w), kBufBytes); if (q == 0) m.rw(w, LdsModel::ACC + w * kAccBytes, kAccBytes); }
+        m.barrier();                                         // publish: waitcnt vmcnt(0) + barrier
+        if (!(last && broken != 1)) issue_next(last ? 1 : 0);   // hold at the last pair of a step: the swap needs the buffer first
+        for (int w = 0; w < 8; ++w) m.rd(w, LdsModel::KEY + rs::duos_pair_slot(p, w & 1) * slot_bytes, slot_bytes);
+        ++p;
+      }
+    m.barrier();                                             // every wave has consumed the last pair
+    for (int round = 0; round < 2; ++round) {                // low halves, then high halves
+      for (int w = 0; w < 8; ++w) m.wr(w, LdsModel::KEY + rs::duo_xchg_doubles(w) * 8L, kPolyBytes);
+      m.barrier();
+      for (int w = 0; w < 8; ++w) m.rd(w, LdsModel::KEY + rs::duo_xchg_doubles(rs::duo_partner(w)) * 8L, kPolyBytes);
+      if (!(broken == 2 && round == 0)) m.barrier();
+    }
+    if (broken != 1) issue_next();
+  }
+  return m.conflicts();
+}
+// blind_rotate_wgs_kernel<WPB>: three 16 KB slots, half-row h in slot h mod 3, requested two half-rows ahead
+long model_wgs(int WPB, int L, int broken) {
+  LdsModel m;
+  const long slot_bytes = 16 * kChunkBytes;
+  const int chunks = 16 / WPB, slots = broken == 1 ? 2 : 3;
+  const long total = 2L * 2 * L * 2;                        // two steps
+  long h_issue = 0;
+  auto issue_next = [&] {   // request of half-row x: in flight until the barrier that publishes x, i.e. this epoch and the next
+    if (h_issue >= total) return;
+    const int sl = slots == 3 ? rs::wgs_ring_slot(h_issue) : (int)(h_issue % 2);
+    for (int w = 0; w < WPB; ++w) m.dma(w, LdsModel::KEY + sl * slot_bytes + w * chunks * kChunkBytes, chunks * kChunkBytes, m.epoch, m.epoch + (h_issue < 2 ? (int)h_issue : 1));
+    ++h_issue;
+  };
+  issue_next();
+  issue_next();
+  for (long h = 0; h < total; ++h) {
+    for (int w = 0; w < WPB; ++w) m.rw(w, buf_of(w), 576 * 8L);
+    m.barrier();                                             // publish(h): own share landed, h + 1 may still be in flight
+    issue_next();                                            // h + 2 into the slot of h - 1
+    const int sl = slots == 3 ? rs::wgs_ring_slot(h) : (int)(h % 2);
+    for (int w = 0; w < WPB; ++w) m.rd(w, LdsModel::KEY + sl * slot_bytes, slot_bytes);
+  }
+  return m.conflicts();
+}
+// blind_rotate_wg_kernel<8>: rows in pairs through two slots; barrier 1 publishes the pair, barrier 2 frees it
+long model_wg(int L, int broken) {
+  LdsModel m;
+  const long slot_bytes = 16 * kChunkBytes;
+  long row = 0;
+  auto issue_pair = [&] {
+    for (int k = 0; k < 2; ++k, ++row)
+      for (int w = 0; w < 8; ++w) m.dma(w, LdsModel::KEY + rs::wg_ring_slot(row) * slot_bytes + w * 2 * kChunkBytes, 2 * kChunkBytes, m.epoch, m.epoch);
+  };
+  issue_pair();
+  for (int pair = 0; pair < 2 * L; ++pair) {                 // two steps of 2l rows
+    for (int w = 0; w < 8; ++w) m.rw(w, buf_of(w), 576 * 8L);
+    m.barrier();
+    for (int w = 0; w < 8; ++w) m.rd(w, LdsModel::KEY, 2 * slot_bytes);
+    if (broken != 2) m.barrier();
+    issue_pair();
+  }
+  return m.conflicts();
+}
+}  // namespace
+
 extern "C" {
 
 long rs_emu_gen_wave_region_violations(int logn) {
@@ -741,6 +969,40 @@ long rs_emu_exchange_schedule(long rows, int n, long* out) {
   }
   return (long)plan.size();
 }
+// form: 0 coop<2>, 1 coop<4>, 2 coop8 (l = 10), 3 coop8 (l = 3), 4 coops<2>, 5 coops<4>, 6 duo, 7 duos, 8 wgs<8>, 9 wgs<4>, 10 wg
+long rs_emu_lds_protocol_conflicts(int form, int broken) {
+  switch (form) {
+    case 0: return model_coop(2, broken);
+    case 1: return model_coop(4, broken);
+    case 2: return model_coop8(10, broken);
+    case 3: return model_coop8(3, broken);
+    case 4: return model_coops<2>(broken);
+    case 5: return model_coops<4>(broken);
+    case 6: return model_duo(10, broken);
+    case 7: return model_duos(10, broken);
+    case 8: return model_wgs(8, 3, broken);
+    case 9: return model_wgs(4, 10, broken);
+    case 10: return model_wg(3, broken);
+  }
+  return -1;
+}
+// coop8: every digit row of both components belongs to exactly one wave, and the two waves of a SIMD (s, s + 4) carry equal totals
+long rs_emu_coop8_row_split_violations(int L) {
+  long bad = 0;
+  std::vector<int> owner(2 * L, 0);
+  for (int w = 0; w < rs::kCoop8Waves; ++w)
+    for (int r = 0; r < rs::coop8_row_count(L, w); ++r) {
+      const int q = rs::coop8_row_first(L, w) + r;
+      if (q < 0 || q >= L) { ++bad; continue; }
+      ++owner[rs::coop8_comp(w) * L + q];
+    }
+  for (int v : owner) bad += v != 1;
+  const int per_simd = rs::coop8_row_count(L, 0) + rs::coop8_row_count(L, 4);
+  for (int s = 0; s < 4; ++s) bad += std::abs(rs::coop8_row_count(L, s) + rs::coop8_row_count(L, s + 4) - per_simd) > (2 * L % 4 ? 1 : 0);
+  bad += (rs::kCoop8InvA & 3) == (rs::kCoop8InvB & 3);      // the two inverse transforms on different SIMDs
+  return bad;
+}
+
 // the operation list of rs_allgather_rows for n contexts on `devices`, peer[d * n + s] = direct access allowed; rows of
 // (kind, ctx, other, path, lo, hi); returns the number of operations (out may be null)
 long rs_emu_exchange_plan(long rows, int n, const int* devices, const unsigned char* peer, int force_staged, long* out) {

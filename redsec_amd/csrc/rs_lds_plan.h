@@ -1,0 +1,57 @@
+// rs_lds_plan.h -- WHERE the N = 1024 blind-rotation kernels put the data that changes hands between wavefronts in LDS.
+//
+// The kernels of rs_bootstrap.hip exchange data between the waves of a workgroup in three ways: partial column sums
+// (cooperative forms), partials swapped between the two waves of a ciphertext through the idle key buffer (duo forms), and
+// key (half-)rows that arrive by direct global->LDS loads into ring slots while other waves still read the previous slots.
+// Every placement decision those protocols rest on is a function HERE, used by the kernels and -- on the host -- by the
+// protocol model of rs_emulate.cpp (rs_emu_lds_protocol_conflicts), which replays each form's barrier epochs and counts
+// pairs of accesses by DIFFERENT waves to overlapping bytes in one epoch with at least one write. A placement that breaks a
+// protocol is therefore a failing CPU test (tests/test_emulator.py), not a one-in-ten GPU failure.
+#pragma once
+
+#include "rs_ntt.h"
+
+namespace rs {
+
+// ---- blind_rotate_coop8_kernel: 8 waves, one ciphertext ------------------------------------------------------------------
+constexpr int kCoop8Waves = 8;
+constexpr int kCoop8InvA = 3;   // inverts column 0 (fewest rows of component 0)
+constexpr int kCoop8InvB = 4;   // inverts column 1 (fewest rows of component 1); another SIMD than kCoop8InvA
+RS_HD constexpr int coop8_comp(int wave) { return wave >> 2; }
+// the l digit rows of a component over its four waves: comp 0 gives the extra rows to its FIRST waves, comp 1 to its LAST,
+// so that the two waves of a SIMD (s and s + 4) carry the same total
+RS_HD constexpr int coop8_row_count(int L, int wave) {
+  return L / 4 + (coop8_comp(wave) == 0 ? ((wave & 3) < L % 4 ? 1 : 0) : ((wave & 3) >= 4 - L % 4 ? 1 : 0));
+}
+RS_HD constexpr int coop8_row_first(int L, int wave) {
+  const int j = wave & 3, rem = L % 4;
+  return j * (L / 4) + (coop8_comp(wave) == 0 ? (j < rem ? j : rem) : (j > 4 - rem ? j - (4 - rem) : 0));
+}
+// where wave `wave` leaves its partial of column `col` for the wave that inverts that column
+enum { kHomeRegisters = 0, kHomeOwnBuffer = 1, kHomePartSlot = 2 };
+RS_HD constexpr int coop8_partial_home(int wave, int col) {
+  if (col == 0) return wave == kCoop8InvA ? kHomeRegisters : (wave == kCoop8InvB ? kHomePartSlot : kHomeOwnBuffer);
+  return wave == kCoop8InvB ? kHomeRegisters : kHomePartSlot;
+}
+
+// ---- blind_rotate_coops_kernel<G>: four sums (2 key halves x 2 columns), one owner wave each -----------------------------
+template <int G> RS_HD constexpr int coops_owner(int sum) { return G == 4 ? sum : (sum & 1); }
+// index of `sum` among the sums wave g does NOT own (its slots of s_part)
+template <int G> RS_HD constexpr int coops_slot(int sum, int g) { return G == 4 ? (sum < g ? sum : sum - 1) : (sum >> 1); }
+
+// ---- duo forms: 4 ciphertexts x 2 waves, partials swapped through the key buffer (8 x kN doubles = 64 KB) ----------------
+RS_HD constexpr int duo_xchg_doubles(int wave) { return wave * kN; }   // offset of the wave's 8 KB window in the key buffer
+RS_HD constexpr int duo_partner(int wave) { return wave ^ 1; }
+// blind_rotate_duo_kernel: a "quad" = rows (comp, 2p + k) in slot 2 comp + k; wave fetches chunks [first, first + 8) of its slot
+RS_HD constexpr int duo_quad_slot(int wave) { return wave >> 1; }
+RS_HD constexpr int duo_quad_first_chunk(int wave) { return (wave & 1) * 8; }
+// blind_rotate_duos_kernel: pair p = the half-rows of both components in slots 2 (p & 1) + comp; wave fetches 4 chunks
+RS_HD constexpr int duos_pair_slot(long p, int comp) { return 2 * (int)(p & 1) + comp; }
+RS_HD constexpr int duos_fetch_comp(int wave) { return wave >> 2; }
+RS_HD constexpr int duos_first_chunk(int wave) { return (wave & 3) * 4; }
+
+// ---- lock-step rings ---------------------------------------------------------------------------------------------------
+RS_HD constexpr int wg_ring_slot(long row) { return (int)(row & 1); }       // blind_rotate_wg_kernel: rows in pairs, two slots
+RS_HD constexpr int wgs_ring_slot(long half_row) { return (int)(half_row % 3); }   // blind_rotate_wgs_kernel: three slots, two ahead
+
+}  // namespace rs

@@ -1,6 +1,8 @@
 """CPU parity of the kernel logic: the HIP phase functions (redsec_amd/csrc/rs_ntt.h) executed
 lane-by-lane on the host must reproduce the oracle bit-for-bit. This checks the transform's index
 mapping, the exactness of the FP64 field arithmetic and the CMUX bookkeeping without a GPU."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -269,3 +271,35 @@ def test_general_path_digits_equal_tfhe_decomposition(l, bgbit):
     f = emu_lib.lib().rs_emu_gen_digit_mismatches
     assert f(l, bgbit, 0x7ffffff0, 1, 64) == 0 and f(l, bgbit, 0xfffffff0, 1, 64) == 0      # the wrap-around boundaries
     assert f(l, bgbit, 12345, 2654435761, 1 << 18) == 0
+
+
+LDS_FORMS = ["coop<2>", "coop<4>", "coop8 (l = 10)", "coop8 (l = 3)", "coops<2>", "coops<4>", "duo", "duos", "wgs<8>", "wgs<4>", "wg<8>"]
+# perturbations every form's model knows (rs_emulate.cpp): 1 = one placement / slot-count / hold decision changed the way a
+# plausible edit would change it, 2 = one workgroup barrier dropped, 3 (duo only) = the next quad requested before the swap
+LDS_BROKEN = {0: (1, 2), 1: (1, 2), 2: (1, 2), 3: (1, 2), 4: (1, 2), 5: (1, 2), 6: (1, 2, 3), 7: (1, 2), 8: (1,), 9: (1,), 10: (2,)}
+
+
+@pytest.mark.parametrize("form", range(len(LDS_FORMS)), ids=LDS_FORMS)
+def test_lds_protocols_of_the_n1024_forms_have_no_cross_wave_conflict(form):
+    """Every place where the waves of an N = 1024 blind-rotation workgroup hand data to each other through LDS -- the partial
+    column sums of the cooperative forms (coop, coops, coop8), the partials the two waves of a ciphertext swap through the idle
+    key buffer (duo, duos), the key (half-)rows that arrive by direct global->LDS loads into ring slots (wg, wgs, duo, duos) --
+    replayed epoch by epoch (an epoch = between two workgroup barriers) with the placement functions the kernels themselves
+    call (csrc/rs_lds_plan.h): no two different waves touch overlapping bytes in one epoch unless both read (or both are LDS
+    atomics). Each model must ALSO see a deliberately broken protocol: the perturbed variants count > 0 (what the round-3
+    suite lacked: the general kernels' exchange race passed it nine runs in ten; its host check is
+    test_general_ring_exchanges_keep_every_wavefront_in_its_own_region). The planar exchange of a transform PAIR
+    (fft_exchange_over_keep: two transforms through one per-wave buffer) involves a single wavefront, whose LDS operations
+    execute in order; its addresses are covered by test_fft_planar_*."""
+    L = emu_lib.lib()
+    L.rs_emu_lds_protocol_conflicts.restype = ctypes.c_long
+    assert L.rs_emu_lds_protocol_conflicts(form, 0) == 0
+    for broken in LDS_BROKEN[form]:
+        assert L.rs_emu_lds_protocol_conflicts(form, broken) > 0, (LDS_FORMS[form], broken)
+
+
+def test_coop8_row_split_covers_every_row_once_and_balances_the_simds():
+    L = emu_lib.lib()
+    L.rs_emu_coop8_row_split_violations.restype = ctypes.c_long
+    for l in range(1, 17):
+        assert L.rs_emu_coop8_row_split_violations(l) == 0, l

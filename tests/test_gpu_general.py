@@ -443,5 +443,13 @@ def test_enforced_certificate_poisons_the_context(monkeypatch):
         be.bootstrap(ct, mu)                             # accepted again ...
         with pytest.raises(RedsecHipError, match="error -5"):
             be.sync()                                    # ... and trips again at this limit
+        with pytest.raises(RedsecHipError, match="error -5"):
+            be.certify(reset=True)
+        # a device-pointer caller whose LAST call trips the limit and who only reads the tensor back: rs_destroy is the one
+        # place left that looks at that call's check, and reports it (round-3 advisor finding)
+        out = be.bootstrap(ct, mu)
+        assert np.array_equal(out.cpu().numpy(), ref)
+        with pytest.raises(RedsecHipError, match="error -5"):
+            be.close()
     finally:
-        be.close()
+        be.close()                                       # second close: a no-op
