@@ -337,26 +337,48 @@ struct DevSlab {
 };
 
 // Device copies of the ciphertext arrays handed back to the caller, keyed by host pointer. A slab is
-// reused only if the host array still carries the ciphertexts it was published with (fingerprint over
-// sampled rows): an address recycled for other data, or samples edited between layers, are uploaded afresh.
-// Arrays the caller never feeds to another layer (the logits) would stay here for good, so the table keeps
-// the kMaxResident most recent slabs and releases the rest.
+// reused only if the host array still carries the ciphertexts it was published with -- EVERY word of every row, by a
+// 64-bit content hash: an address recycled for other data, or any sample edited between two stages (legal through the
+// BinFunc::* / IntFunc::* stage API and through plain field writes), is uploaded afresh. (Rounds 1-3 hashed 64 sampled rows;
+// an edit to any other row went unnoticed.) Arrays the caller never feeds to another layer (the logits) would stay here
+// for good, so the table keeps the kMaxResident most recent slabs and releases the rest.
 std::mutex g_lock;
 std::map<const void*, DevSlab> g_resident;
 uint64_t g_seq = 0;
 constexpr size_t kMaxResident = 16;
 
-// FNV-1a over up to 64 evenly spaced rows (first and last included) of a packed [rows][W] host copy
-uint64_t fingerprint(const int32_t* words, size_t rows, int W) {
-  uint64_t h = 1469598103934665603ull ^ (uint64_t)rows;
-  if (rows == 0) return h;
-  const size_t picks = rows < 64 ? rows : 64;
-  for (size_t k = 0; k < picks; ++k) {
-    const size_t r = picks == 1 ? 0 : k * (rows - 1) / (picks - 1);
-    const int32_t* row = words + r * (size_t)W;
-    for (int w = 0; w < W; ++w) { h ^= (uint32_t)row[w]; h *= 1099511628211ull; }
-  }
+// Hash of one ciphertext = its W = n + 1 words (a[0..n), b), two words per multiply. Rows are combined by a sum of
+// position-mixed row hashes, so the rows can be hashed in any order and in parallel (131,072 x 351 words per CIFAR stage:
+// a few milliseconds on the host threads, against ~100 ms for the array-of-structs copy the same stage performs anyway).
+inline uint64_t mix64(uint64_t x) { x ^= x >> 32; x *= 0xd6e8feb86659fd93ull; x ^= x >> 32; x *= 0xd6e8feb86659fd93ull; x ^= x >> 32; return x; }
+inline uint64_t row_hash(const int32_t* a, int n, int32_t b, size_t row) {
+  uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)row;
+  int w = 0;
+  for (; w + 1 < n; w += 2) { h = (h ^ ((uint64_t)(uint32_t)a[w] | ((uint64_t)(uint32_t)a[w + 1] << 32))) * 0x100000001b3ull; h ^= h >> 29; }
+  if (w < n) { h = (h ^ (uint64_t)(uint32_t)a[w]) * 0x100000001b3ull; h ^= h >> 29; }
+  h = (h ^ ((uint64_t)(uint32_t)b << 1 | 1ull)) * 0x100000001b3ull;
+  return mix64(h);
+}
+template <class RowFn>   // RowFn(row) -> row hash; summed over [0, rows) on up to 8 threads
+uint64_t hash_rows(size_t rows, RowFn fn) {
+  const size_t hw = std::thread::hardware_concurrency();
+  const size_t T = rows < 4096 ? 1 : std::min<size_t>(8, hw ? hw : 1);
+  std::vector<uint64_t> part(T, 0);
+  auto work = [&](size_t t) { uint64_t s = 0; for (size_t r = rows * t / T; r < rows * (t + 1) / T; ++r) s += fn(r); part[t] = s; };
+  std::vector<std::thread> th;
+  for (size_t t = 1; t < T; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+  uint64_t h = 0x243f6a8885a308d3ull ^ (uint64_t)rows;
+  for (uint64_t v : part) h += v;
   return h;
+}
+// ... of a packed [rows][W] host copy (what publish() downloads) and of the caller's LweSample array (what a stage receives)
+uint64_t fingerprint(const int32_t* words, size_t rows, int W) {
+  return hash_rows(rows, [&](size_t r) { const int32_t* row = words + r * (size_t)W; return row_hash(row, W - 1, row[W - 1], r); });
+}
+uint64_t fingerprint(const std::vector<const LweSample*>& samples, int n) {
+  return hash_rows(samples.size(), [&](size_t r) { return row_hash(samples[r]->a, n, samples[r]->b, r); });
 }
 
 void remember(const void* host, DevSlab s) {
@@ -911,17 +933,8 @@ DevSlab stage_input(LayerImpl* L, const void* key, const std::vector<const LweSa
     return s;   // the host arrays are placeholders (REDSEC_LAZY_HOST): the device copy is the only one there is
   }
   if (had && s.rows == samples.size() && (int)s.ctx.size() == D && std::equal(s.ctx.begin(), s.ctx.end(), fleet)) {
-    // same fingerprint as at publication: sampled rows only (packing 131,072 x 351 words per layer just to
-    // compare them would cost more than the check is worth)
-    const size_t rows = samples.size(), picks = rows < 64 ? rows : 64;
-    std::vector<int32_t> probe(picks * (size_t)W);
-    uint64_t h = 1469598103934665603ull ^ (uint64_t)rows;
-    for (size_t k = 0; k < picks; ++k) {
-      const size_t r = picks == 1 ? 0 : k * (rows - 1) / (picks - 1);
-      redsec_pack(&probe[k * W], samples[r], n);
-      for (int w = 0; w < W; ++w) { h ^= (uint32_t)probe[k * W + w]; h *= 1099511628211ull; }
-    }
-    if (h == s.tag) return s;
+    // the same content hash as at publication, over every word the caller now holds
+    if (fingerprint(samples, n) == s.tag) return s;
   }
   if (had) s.release();   // stale or foreign: release it and upload what the host holds
   s = DevSlab{};

@@ -7,6 +7,7 @@
 // and BinFunc::MaxPooling / IntFunc::Quantize::{add_bias, relu_shift} on their own must decrypt to the plaintext function.
 // Prints PASS/FAIL lines; exit code = number of failures.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -280,6 +281,106 @@ int main() {
     for (int c = 0; c < C; ++c) same3 = same3 && same(&y1[c].ctxt[0], &y3[c].ctxt[0], n);
     check("a re-initialised tDimensions object starts a further network at 1/4096 (same words as the first instance)", same3);
     fclose(fr); fclose(fs); fclose(fr2);
+  }
+  // ---- a ciphertext edited BETWEEN two stages must be seen by the second stage (lib/BinFunc.cpp:327-328,1073: a stage owns its
+  //      input array; the stage API hands the intermediate array to the caller, who may touch it) ----
+  {
+    // Convolution (FC 40 -> 100) hands back 100 pre-activations whose device copy stays resident; the caller then adds a constant
+    // to ONE of them -- row 2, which the sampled-row fingerprint of rounds 1-3 never looked at (it hashed rows 0, 1, 3, 4, 6, ...
+    // of 100) -- and Quantize::execute must bootstrap the edited value, not the stale device copy.
+    const int K2 = 40, M2 = 100, EDIT = 2;
+    std::vector<int> w2((size_t)K2 * M2), bits2(K2);
+    std::vector<int32_t> bias2(M2);
+    for (auto& x : w2) { const unsigned t = rnd() % 10; x = t < 2 ? 0 : (t < 6 ? 1 : -1); }
+    for (auto& b : bias2) b = (int32_t)(rnd() % 9) - 4;
+    for (auto& b : bits2) b = (rnd() & 1) ? 1 : -1;
+    std::vector<int> pre2(M2);
+    for (int m = 0; m < M2; ++m) { pre2[m] = bias2[m]; for (int k = 0; k < K2; ++k) pre2[m] += w2[(size_t)k * M2 + m] * bits2[k]; }
+    const int delta = pre2[EDIT] >= 0 ? -(pre2[EDIT] + 40) : (40 - pre2[EDIT]);     // moves the pre-activation to -40 / +40: the sign flips, far from 0
+    FILE* f2 = tmpfile();
+    put_ternary(f2, w2); put_ints(f2, bias2);
+    put_ternary(f2, w2); put_ints(f2, bias2);
+    rewind(f2);
+    auto enc2 = [&]() {
+      tBit* x = new_gate_bootstrapping_ciphertext_array(K2, params);
+      uint32_t s2[] = {21, 22, 23};
+      tfhe_random_generator_setSeed(s2, 3);
+      for (int i = 0; i < K2; ++i) lweSymEncrypt(&x[i], bits2[i] * u, 1.0 / 32768, g_sk->lwe_key);
+      return x;
+    };
+    tQParams qq; qq.shift_bits = 1;
+    auto chain = [&](bool edit) {
+      tDimensions dd = dims(1, 1, K2);
+      BinFunc::Convolution cv(M2, &np.conv);
+      BinFunc::Quantize qz(&qq);
+      std::vector<tMultiBit> pbq(M2);
+      cv.prep(f2, &dd, g_bk);
+      qz.prep(f2, &dd, pbq.data(), NULL, g_bk);
+      tMultiBit* mid = cv.execute(enc2());
+      if (edit) mid[EDIT].ctxt[0].b += delta * u;              // a plain field write, as REDsec code does all over lib/*.cpp
+      return qz.execute(mid, pbq.data());
+    };
+    tBit* plain = chain(false);
+    tBit* edited = chain(true);
+    bool others = true;
+    for (int m = 0; m < M2; ++m) if (m != EDIT) others = others && same(&plain[m], &edited[m], n);
+    const int want = pre2[EDIT] + delta >= 0 ? 1 : -1;
+    check("a row edited between Convolution and Quantize is bootstrapped as edited (every word of the array is fingerprinted)",
+          dec_int(&edited[EDIT], 4096) == want && dec_int(&plain[EDIT], 4096) == -want && !same(&plain[EDIT], &edited[EDIT], n));
+    check("  ... and every other row is unchanged, word for word", others);
+    fclose(f2);
+  }
+
+  // ---- IntFunc::Convolution with the reference's ENCRYPTED constants (lib/IntFunc.cpp:264-279; REDSEC_INTCONV=enc) ----
+  {
+    // 4x4x2 image, 3x3 same-padded convolution to 3 channels, ternary weights with zeros: a ternary-zero tap and a padding tap
+    // each contribute the trivial sample -1/4096 (lweNoiselessTrivial(-mu_dynamic), :268 and :277), a +1 tap the input, a -1 tap
+    // its negation (lweClear + lweSubTo, :219-220); Quantize::add_bias then adds trivial(bias/4096). The expected ciphertexts
+    // are built here with the shim's host-side word operations and must equal the layer's output word for word.
+    setenv("REDSEC_INTCONV", "enc", 1);
+    const int Hh = 4, Ci = 2, Co = 3, Fh = 3;
+    std::vector<int> wc((size_t)Fh * Fh * Ci * Co), px2(Hh * Hh * Ci);
+    for (auto& x : wc) { const unsigned t = rnd() % 3; x = t == 0 ? 0 : (t == 1 ? 1 : -1); }
+    for (auto& v : px2) v = (int)(rnd() % 61) - 30;
+    std::vector<int32_t> bc = {7, -11, 3};
+    FILE* f3 = tmpfile();
+    put_ternary(f3, wc); put_ints(f3, bc);
+    rewind(f3);
+    tNetParams nc = np;
+    nc.conv.window.h = nc.conv.window.w = Fh; nc.conv.stride.h = nc.conv.stride.w = 1; nc.conv.same_pad = true;
+    IntLayer cl(E_CONV, Co, E_NO_POOL, E_ACTIVATION_NONE, &nc, g_bk);
+    tDimensions dc = dims(Hh, Hh, Ci);
+    cl.prep(f3, &dc);
+    tMultiBit* xin = new tMultiBit[Hh * Hh * Ci];
+    std::vector<LweSample*> keep(Hh * Hh * Ci);
+    for (int i = 0; i < Hh * Hh * Ci; ++i) {
+      xin[i].size = 1; xin[i].ctxt = new_gate_bootstrapping_ciphertext_array(1, params);
+      lweSymEncrypt(&xin[i].ctxt[0], px2[i] * u, 1.0 / 32768, g_sk->lwe_key);
+      keep[i] = new_LweSample(params->in_out_params);          // execute() frees its input: the expectation needs its own copy
+      lweCopy(keep[i], &xin[i].ctxt[0], params->in_out_params);
+    }
+    tFixedPoint* y = (tFixedPoint*)cl.execute(xin);
+    unsetenv("REDSEC_INTCONV");
+    bool okc = true, decs = true;
+    LweSample* acc = new_LweSample(params->in_out_params);
+    for (int ph = 0; ph < Hh && okc; ++ph) for (int pw = 0; pw < Hh; ++pw) for (int od = 0; od < Co; ++od) {
+      lweNoiselessTrivial(acc, bc[od] * u, params->in_out_params);
+      int plain = bc[od];
+      for (int fh = 0; fh < Fh; ++fh) for (int fw = 0; fw < Fh; ++fw) for (int di = 0; di < Ci; ++di) {
+        const int ih = ph + fh - 1, iw = pw + fw - 1;
+        const int wv = wc[((size_t)(fh * Fh + fw) * Ci + di) * Co + od];                // get_filter_i, lib/IntFunc.cpp
+        if (ih < 0 || ih >= Hh || iw < 0 || iw >= Hh || wv == 0) { acc->b -= u; plain -= 1; continue; }   // padding / ternary zero: trivial -1/4096
+        const LweSample* in = keep[(ih * Hh + iw) * Ci + di];                            // get_input_i
+        if (wv > 0) { lweAddTo(acc, in, params->in_out_params); plain += px2[(ih * Hh + iw) * Ci + di]; }
+        else { lweSubTo(acc, in, params->in_out_params); plain -= px2[(ih * Hh + iw) * Ci + di]; }
+      }
+      const LweSample* got = &y[(ph * Hh + pw) * Co + od].ctxt[0];                       // get_output_i
+      okc = okc && same(got, acc, n);
+      decs = decs && dec_int(got, 4096) == plain;
+    }
+    check("IntLayer(E_CONV) under REDSEC_INTCONV=enc == the reference's ENCRYPTED branch restated with host word operations, word for word", okc);
+    check("  ... and decrypts to sum(w x) - #(zero or padding taps) + bias", decs);
+    fclose(f3);
   }
   printf("failures: %d\n", g_fail);
   return g_fail;
