@@ -64,6 +64,7 @@ struct Lane {
   size_t conv_scratch_words = 0;
   uint32_t* d_ks_scratch = nullptr;       // partial sums of the sliced (small-batch) keyswitch (grown on demand; <= ~50 MB)
   size_t ks_scratch_words = 0;
+  int* d_progress = nullptr;              // XCD cohort table of the split lock-step kernel: [8][kCohortSlots] step counts
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   bool ev_valid = false;
   rs::LaunchInfo last;
@@ -144,7 +145,7 @@ int use_device(rs_ctx* c) {
 void free_lane(Lane* ln) {
   if (ln->h_split_max) (void)hipHostFree(ln->h_split_max);
   (void)hipFree(ln->d_u0); (void)hipFree(ln->d_u1); (void)hipFree(ln->d_counter); (void)hipFree(ln->d_cert);
-  (void)hipFree(ln->d_conv_scratch); (void)hipFree(ln->d_ks_scratch);
+  (void)hipFree(ln->d_conv_scratch); (void)hipFree(ln->d_ks_scratch); (void)hipFree(ln->d_progress);
   for (auto& e : ln->ev) if (e) (void)hipEventDestroy(e);
 }
 
@@ -296,6 +297,8 @@ int run_bootstrap(rs_ctx* c, hipStream_t st, int32_t* out, const Combo* combos, 
         // N = 1024 with one of the reference's gadgets at throughput batch sizes: lock-step workgroups on the split key
         rs::BlindRotateArgs w = br_args(c, ln, 1, cs[k], mu, lut, B);
         w.bk_x = c->d_bk_gen; w.tw = c->d_tw_fft;
+        if (!ln->d_progress && hipMalloc(&ln->d_progress, 8 * rs::kCohortSlots * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); ln->d_progress = nullptr; }
+        w.progress = ln->d_progress;   // optional: without the table the workgroups run free
         const hipError_t e = rs::launch_blind_rotate_split_wg(c->wgs_cfg, w, c->num_cus, c->opts, st, &ln->last);
         if (e == hipSuccess) { split_wg = true; continue; }
         if (e != hipErrorNotSupported) return fail(RS_ERR_HIP, "split workgroup launch failed: %s", hipGetErrorString(e));
@@ -478,7 +481,7 @@ int rs_create(rs_ctx** out, const rs_params* p, int device) {
   if (const char* v = getenv("REDSEC_SPLIT_CERT_LIMIT")) { const double x = atof(v); if (x > 0.0 && x < 0.25) c->split_cert_limit = x; }   // test hook: can only tighten
   c->opts.no_coop = env_on("RS_NO_COOP"); c->opts.no_wg = env_on("RS_NO_WG"); c->opts.no_duo = env_on("RS_NO_DUO");
   c->opts.no_persist = env_on("RS_NO_PERSIST"); c->opts.no_conv_tiled = env_on("RS_NO_CONV_TILED");
-  c->opts.no_wg4 = env_on("RS_NO_WG4"); c->opts.no_tail = env_on("RS_NO_TAIL"); c->opts.no_coop8 = env_on("RS_NO_COOP8"); c->opts.ks_atomics = env_on("RS_KS_ATOMICS"); c->opts.force_host_staged = env_on("RS_FORCE_HOST_STAGED");
+  c->opts.no_wg4 = env_on("RS_NO_WG4"); c->opts.no_tail = env_on("RS_NO_TAIL"); c->opts.no_coop8 = env_on("RS_NO_COOP8"); c->opts.ks_atomics = env_on("RS_KS_ATOMICS"); c->opts.force_host_staged = env_on("RS_FORCE_HOST_STAGED"); c->opts.no_cohort = env_on("RS_NO_COHORT");
   Lane* ln = nullptr;
   if (lane_of(c, nullptr, &ln) != RS_OK) { destroy_ctx(c); return RS_ERR_HIP; }   // the default stream's lane
   *out = c;

@@ -878,6 +878,33 @@ __device__ __forceinline__ void mac_half_stream(double (&s0)[kRegs], double (&s1
   mac_half_stream_cols(s0, s1, x, k0, k0 + kN / 2, lane);
 }
 
+// XCD cohorts. The lock-step split kernel streams 2 x the key bytes of the unsplit one; the workgroups of an XCD share them
+// through that XCD's 4 MB L2 only while they are within a few CMUX steps of each other (one step = 2 l x 2 half-rows of 16 KB:
+// 192 KB default-128, 640 KB REDsec set), and nothing kept them there: counter traffic of a 65,536-gate launch was 58 GB in
+// round 2 and 106 GB in round 3 against 32 GB if every XCD fetched every half-row once per round. So every `every` steps wave 0
+// of a workgroup publishes its step count and looks at its XCD's table (workgroups are dealt to the XCDs round-robin:
+// xcd = blockIdx.x & 7); more than `lag` steps ahead of the slowest one it waits -- bounded: at most kCohortPolls polls, so a
+// workgroup that is not resident (a shared GPU) or a stale table can delay a launch but never hang it. The other waves of the
+// workgroup notice nothing: they wait for wave 0 at the next publish barrier, as they do anyway.
+constexpr int kCohortPolls = 48;
+__device__ __forceinline__ int cohort_slowest(const int* row, int lane) {
+  int v = __hip_atomic_load(row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // kCohortSlots = 64 = one wavefront
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off, 64); v = o < v ? o : v; }
+  return v;
+}
+__device__ __forceinline__ void cohort_wait(int* progress, int mine, int lag, int lane) {
+  int* row = progress + (blockIdx.x & 7) * kCohortSlots;
+  if (lane == 0) __hip_atomic_store(row + (blockIdx.x >> 3), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int poll = 0; poll < kCohortPolls; ++poll) {
+    if (cohort_slowest(row, lane) + lag >= mine) break;
+    __builtin_amdgcn_s_sleep(64);
+  }
+}
+__device__ __forceinline__ void cohort_leave(int* progress, int lane) {
+  if (lane == 0) __hip_atomic_store(progress + (blockIdx.x & 7) * kCohortSlots + (blockIdx.x >> 3), 0x7f7f7f7f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <class C, int WPB>
 __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateArgs a) {
   using Xf = XfFft<C>;
@@ -909,8 +936,9 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
   const long total_half = (long)n * KPL * 2;
   const unsigned lane_off = (unsigned)lane * 16u;
   auto sync_w = [] { wave_lds_sync(); };
+  long steps_done = 0;   // CMUX steps of the groups this workgroup has finished (XCD cohorts)
 
-  for (long group = blockIdx.x; group < n_groups; group += gridDim.x) {
+  for (long group = blockIdx.x; group < n_groups; group += gridDim.x, steps_done += n) {
     const long ct = group * WPB + wave;
     const bool active = ct < a.B;
     const int32_t* row0 = a.in0 + (active ? ct : 0) * a.W;
@@ -956,6 +984,9 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
           hsrc = (((long)iss_i * KPL + (long)comp * C::L + q) << 1) + (k & 1);
           if (++iss_k == 2 * KPL) { iss_k = 0; ++iss_i; }
         }
+#ifdef RS_T_WGS_NOKEY   // TIMING PROBE (results are wrong): every step reads the half-rows of step 0, which stay in the L2s
+        hsrc %= 2 * KPL;
+#endif
         glds_chunks<kChunks>(a.bk_x + (size_t)hsrc * kSlotDoubles + (size_t)(wave * kChunks) * 128, lane_off, s_key[slot_issue] + (wave * kChunks) * 128);
         ++h_issue;
         slot_issue = slot_issue == 2 ? 0 : slot_issue + 1;
@@ -982,6 +1013,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
 
     for (int i = 0; i < n; ++i) {
       if ((i & (kWin - 1)) == 0 && i > 0) { wave_lds_sync(); fill_window(i); }
+      if (a.progress && wave == 0 && i % a.cohort_every == 0) cohort_wait(a.progress, (int)(steps_done + i), a.cohort_lag, lane);
       wave_lds_sync();
       const int32_t bara = __builtin_amdgcn_readfirstlane((int)s_bara[wave][i & (kWin - 1)]);
       const bool work = bara != 0;   // tfhe_blindRotate_FFT skips the identity CMUX (the barriers still run)
@@ -1009,6 +1041,8 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
         if (work) mac_half_stream(sh0, sh1, x, s_key[slot], lane);
         consumed();
       };
+      // (the forward transforms stay single: run as software-pipelined pairs -- two transforms beside the four 32-register column
+      // sums -- the kernel does not fit 256 registers: 1,040 bytes of scratch per lane, compiled in round 4 and dropped)
       if (work) load_d(std::false_type{});
 #pragma unroll 1
       for (int q = 0; q < C::L; ++q) row(q);
@@ -1043,6 +1077,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
       if (lane == 0) out[kN] = acc1[0];
     }
   }
+  if (a.progress && wave == 0) cohort_leave(a.progress, lane);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -2160,10 +2195,21 @@ hipError_t launch_blind_rotate_split_wg(int cfg, const BlindRotateArgs& a, int n
   const int wpb = (a.B <= 4L * num_cus && !o.no_wg4) ? 4 : 8;
   const long groups = (a.B + wpb - 1) / wpb;
   const long grid = groups < num_cus ? groups : num_cus;
+  BlindRotateArgs w = a;
+  if (w.progress && !o.no_cohort && grid <= 8L * kCohortSlots && groups > grid) {
+    // XCD cohorts (see cohort_wait): only for launches whose workgroups walk several groups, i.e. sweep the key more than once.
+    // A CMUX step reads 2 * 2l half-rows of 16 KB; the lag keeps a cohort inside about a third of its 4 MB L2.
+    const long step_bytes = 4L * (cfg == 1 ? 10 : 3) * 16384;
+    w.cohort_lag = (int32_t)std::max<long>(1, (4L << 20) / 3 / step_bytes);
+    w.cohort_every = w.cohort_lag >= 4 ? 2 : 1;
+    if (hipError_t e = hipMemsetAsync(w.progress, 0x7f, 8 * kCohortSlots * sizeof(int), st); e != hipSuccess) return e;
+  } else {
+    w.progress = nullptr;
+  }
   auto go = [&](auto c) {
     using C = decltype(c);
-    if (wpb == 8) hipLaunchKernelGGL((blind_rotate_wgs_kernel<C, 8>), dim3((unsigned)grid), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((blind_rotate_wgs_kernel<C, 4>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    if (wpb == 8) hipLaunchKernelGGL((blind_rotate_wgs_kernel<C, 8>), dim3((unsigned)grid), dim3(512), 0, st, w);
+    else hipLaunchKernelGGL((blind_rotate_wgs_kernel<C, 4>), dim3((unsigned)grid), dim3(256), 0, st, w);
   };
   if (cfg == 0) go(CfgDefault128{});
   else if (cfg == 1) go(CfgRedsecV2{});

@@ -37,11 +37,18 @@ struct BlindRotateArgs {
   unsigned long long gate_limit_bits = 0;
   unsigned long long* running_flag = nullptr;
   unsigned long long* fallback_count = nullptr;
+  // XCD cohorts (blind_rotate_wgs_kernel): progress[xcd * kCohortSlots + slot] = CMUX steps workgroup (xcd, slot) has done,
+  // INT_MAX-like for a workgroup that is absent or finished (the launcher fills the table with 0x7f bytes). A workgroup that
+  // is more than `cohort_lag` steps ahead of the slowest workgroup on its XCD waits (bounded) every `cohort_every` steps, so
+  // the workgroups of an XCD stay within what their L2 holds of the key. nullptr: free-running.
+  int* progress = nullptr;
+  int32_t cohort_every = 0, cohort_lag = 0;
 };
+constexpr int kCohortSlots = 64;   // workgroups per XCD the table has room for (256 CUs / 8 XCDs = 32)
 
 // Launch policy switches, read from the environment ONCE at rs_create (A/B experiments only).
 struct LaunchOpts {
-  bool no_coop = false, no_wg = false, no_duo = false, no_persist = false, no_conv_tiled = false, no_wg4 = false, no_tail = false, no_coop8 = false, ks_atomics = false, force_host_staged = false;
+  bool no_coop = false, no_wg = false, no_duo = false, no_persist = false, no_conv_tiled = false, no_wg4 = false, no_tail = false, no_coop8 = false, ks_atomics = false, force_host_staged = false, no_cohort = false;
 };
 // What a blind-rotate launch actually ran: kernel form and how many ciphertexts share one sweep of the key
 // from L2/HBM (R of SURVEY.md section 8d).
