@@ -355,7 +355,7 @@ int main() {
     std::vector<LweSample*> keep(Hh * Hh * Ci);
     for (int i = 0; i < Hh * Hh * Ci; ++i) {
       xin[i].size = 1; xin[i].ctxt = new_gate_bootstrapping_ciphertext_array(1, params);
-      lweSymEncrypt(&xin[i].ctxt[0], px2[i] * u, 1.0 / 32768, g_sk->lwe_key);
+      lweSymEncrypt(&xin[i].ctxt[0], px2[i] * u, 1.0 / 4194304, g_sk->lwe_key);   // quiet samples: 18 of them sum per output and must still decode
       keep[i] = new_LweSample(params->in_out_params);          // execute() frees its input: the expectation needs its own copy
       lweCopy(keep[i], &xin[i].ctxt[0], params->in_out_params);
     }
