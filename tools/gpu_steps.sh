@@ -15,8 +15,7 @@ OUT=gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp
 for step in "$@"; do
   name="${step%%:*}"; arg=""; [[ "$step" == *:* ]] && arg="${step#*:}"; arg="${arg//+/ }"
-  tag="$LABEL_$(echo "$step" | tr -c 'A-Za-z0-9_.=\n' '_' | cut -c1-60)"
-  tag="${LABEL}_${tag#_}"
+  tag="${LABEL}_$(echo "$step" | tr -c 'A-Za-z0-9_.=\n' '_' | cut -c1-48)_$(echo "$step" | md5sum | cut -c1-5)"   # unique per step
   echo "=== $step ($(date +%T))"
   case "$name" in
     suite) timeout -k 10 900 python -m pytest tests -m gpu -x -q --durations=15 > $OUT/${LABEL}_suite.log 2>&1; rc=$?; tail -25 $OUT/${LABEL}_suite.log;;
