@@ -1043,12 +1043,46 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
       };
       // (the forward transforms stay single: run as software-pipelined pairs -- two transforms beside the four 32-register column
       // sums -- the kernel does not fit 256 registers: 1,040 bytes of scratch per lane, compiled in round 4 and dropped)
+#ifndef RS_WGS_PAIR
+#define RS_WGS_PAIR 0
+#endif
+#if RS_WGS_PAIR
+      auto row_pair = [&](int q) {
+        double xa[kRegs], xb[kRegs];
+        if (work) {
+          Xf::digits(xa, d, q);
+          Xf::digits(xb, d, q + 1);
+          Xf::fwd_pair_wg(lane, xa, xb, tw_kept, buf, FftNoSeg());
+        }
+        publish();
+        if (work) mac_half_stream(sl0, sl1, xa, s_key[slot], lane);
+        consumed();
+        publish();
+        if (work) mac_half_stream(sh0, sh1, xa, s_key[slot], lane);
+        consumed();
+        publish();
+        if (work) mac_half_stream(sl0, sl1, xb, s_key[slot], lane);
+        consumed();
+        publish();
+        if (work) mac_half_stream(sh0, sh1, xb, s_key[slot], lane);
+        consumed();
+      };
+      if (work) load_d(std::false_type{});
+#pragma unroll 1
+      for (int q = 0; q + 1 < C::L; q += 2) row_pair(q);
+      if (C::L & 1) row(C::L - 1);
+      if (work) load_d(std::true_type{});
+#pragma unroll 1
+      for (int q = 0; q + 1 < C::L; q += 2) row_pair(q);
+      if (C::L & 1) row(C::L - 1);
+#else
       if (work) load_d(std::false_type{});
 #pragma unroll 1
       for (int q = 0; q < C::L; ++q) row(q);
       if (work) load_d(std::true_type{});
 #pragma unroll 1
       for (int q = 0; q < C::L; ++q) row(q);
+#endif
 
       if (work) {
         Xf::inverse_pair_wg(lane, sl0, sl1, tw, buf);
