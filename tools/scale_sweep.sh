@@ -27,9 +27,23 @@ for N in 1 2 4 8; do
     [ "$N" = 1 ] && [ "$MODE" = strong ] && continue
     python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29550 + N)) bench.py --gpus $N $COMMON --scaling $MODE \
       > "$OUT/scale_${MODE}_$N.json" || exit 1
-    python -c "
-import json,sys
-d=json.loads(open('$OUT/scale_${MODE}_$N.json').read().strip().splitlines()[-1])
-print('N=%d %-6s %10.0f bootstraps/s  %8.3f ms/step  kernels per rank: %s' % (d['n_gpus'], d['scaling'], d['value'], d['ms_per_step'], [(k['rank'], k['blind_rotate']) for k in d['kernels_ms_per_rank']]))"
+    # every line is checked before it is believed: the size that ran, the collective that ran, the gathered batch, and that no
+    # rank's kernels were slower than the others' by 3 % (a slow rank sets the whole job's time)
+    python - "$OUT/scale_${MODE}_$N.json" $N $MODE <<'PY' || exit 1
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+N, mode = int(sys.argv[2]), sys.argv[3]
+br = [k["blind_rotate"] for k in d["kernels_ms_per_rank"]]
+spread = (max(br) - min(br)) / max(br)
+print("N=%d %-6s %10.0f bootstraps/s  %8.3f ms/step  kernel ms per rank: %s (spread %.1f %%)  gather alone %s ms"
+      % (d["n_gpus"], d["scaling"], d["value"], d["ms_per_step"], br, 100 * spread, d["collective"] and d["collective"]["ms_alone_unoverlapped"]))
+assert d["n_gpus"] == N and len(br) == N, "ran at another size than asked"
+assert d["scaling"] == mode
+if N > 1:
+    assert d["collective"] and d["collective"]["backend"].startswith("nccl"), "the output gather did not run over RCCL"
+    assert d["checks"]["gathered_batch_ok"], "the gathered batch is wrong"
+    assert spread < 0.03, "per-rank kernel times differ by %.1f %%" % (100 * spread)
+assert d["checks"]["all_outputs_decrypt_to_nand"]
+PY
   done
 done
