@@ -258,6 +258,10 @@ def cifar_leg(be, sk, device_index):
     return {"ms_per_image": round(ms, 1), "unit": "ms", "bootstraps": timer.bootstraps, "largest_launch": 131072, "maxpool": "fused",
             "blind_rotate_ms": round(timer.blind_rotate_ms, 1), "keyswitch_ms": round(timer.keyswitch_ms, 1), "linear_ms": round(timer.linear_ms, 1),
             "bootstraps_per_s": round(timer.bootstraps / (ms * 1e-3), 1), "argmax": int(np.argmax(logits)), "label": int(labels[i]),
+            "plaintext_argmax": int(np.argmax(pm.cifar_forward(net, pix[i]))),
+            "class_note": "kernel-level parity is exact (tests/test_gpu_cifar.py: every bootstrapped stage = the oracle word for word); the CLASS of one "
+                          "encrypted image is a property of the reference's parameter choice: 4096 message levels through a 2N = 2048 mod-switch flip weak-margin "
+                          "units in any TFHE implementation (tools/cifar_agreement.py, profiles/r04)",
             "params": "redsec_small_v2", "mode": "fft", "split_mode_ms_per_image": round(ms_s, 1),
             "logit_ciphertexts_equal_in_split_mode": bool(torch.equal(out, out_s)),
             "fft_rounding_certificate": round(be.rounding_certificate(), 6),
