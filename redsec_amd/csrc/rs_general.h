@@ -48,7 +48,7 @@ constexpr RS_HD int gen_idx(int t, int H, int r) { return ((t >> (H - 3)) << H) 
 // without workgroup barriers. (Until round 3's last day Hr >= 8 was left unpadded: the wave-local stores of exchange 1 then
 // landed in slots that ANOTHER wave could still be reading as exchange 0's data -- a write-after-read race seen as a rare
 // wrong product at N = 4096 / 8192, caught by the enforced rounding certificate.)
-#ifdef RS_GEN_UNPADDED_WIDE_EXCHANGE   // the racy form, kept only to reproduce the failure (tools/r03/r03_race_repro.py)
+#ifdef RS_GEN_UNPADDED_WIDE_EXCHANGE   // the racy form, kept only to reproduce the failure (24 fresh processes of a full-size batch run twice: profiles/r03/s_general_exchange_race_repro.txt; tests/first_launch_stress.py is that run as a test)
 constexpr RS_HD int gen_phys(int idx, int Hr) { return Hr < 8 ? idx + ((idx >> Hr) << (Hr - 3)) : idx; }
 #else
 constexpr RS_HD int gen_phys(int idx, int Hr) { return idx + ((idx >> Hr) << (Hr - 3)); }
