@@ -31,11 +31,8 @@ def test_binarynet_small_python_chain_matches_plaintext_model():
     assert be.rounding_certificate() < 0.2
     # unsharded call of the sharded entry point (no process group): identical ciphertexts
     assert torch.equal(enc.run(ct, shard=False), out)
-    # the OR-chain form of the max-pool computes the same bits: logits decrypt to the same class and stay
-    # close (the two forms differ only in noise, which moves weak-margin units of the following layers)
-    chain = sk.decrypt_ints(nets.EncryptedCifar(be, net, maxpool="chain").run(ct).cpu().numpy())
-    assert int(np.argmax(chain)) == int(labels[i])
-    assert np.corrcoef(chain, logits)[0, 1] > 0.5
+    # (the OR-chain form of the max-pool is checked stage by stage, at full size, by the test below)
+    be.close()
 
 
 # ---- BASELINE configs[3] itself, stage by stage against the oracle ---------------------------------------------------
@@ -147,6 +144,9 @@ def test_binarynet_full_every_bootstrapped_stage_against_the_oracle(maxpool):
         # OR-chain form re-randomises every pooled bit -- so the class is asserted for the default form only.
         plain = pm.cifar_forward(net, pix[i])
         assert int(np.argmax(logits)) == int(np.argmax(plain)) == int(labels[i])
+    if maxpool == "chain":          # (the split-mode repeat runs on the default form only: the OR stages are the same kernels, and the suite has a time budget)
+        be.close()
+        return
     # the split-key mode: every stage's whole slab, word for word
     be.set_mode("split")
     taps_s = []

@@ -116,7 +116,7 @@ def test_unmodified_cifar_binarynet_full_driver(tmp_path):
 @pytest.mark.parametrize("family,net,devices,lazy,staged", [("mnist", "sign1024x1", "0,0", False, False), ("mnist", "relu1024x1", "0,0,0", False, False),
                                                             ("mnist", "sign1024x1", "0,0,0,0", True, False), ("cifar", "binarynet_small", "0,0", False, False),
                                                             ("cifar", "binarynet_small", "0,0,0,0", True, False),
-                                                            ("mnist", "relu1024x1", "0,0,0", False, True), ("cifar", "binarynet_small", "0,0,0", True, True)])
+                                                            ("mnist", "relu1024x1", "0,0,0", False, True)])
 def test_driver_sharded_over_several_contexts_equals_single_device(tmp_path, monkeypatch, family, net, devices, lazy, staged):
     """Gate-parallel evaluation of ONE image inside the C++ layer mirror (the reference's shape: enc_segs[NUM_GPUS], one host
     thread per GPU, lib/GPU/BinFunc_gpu.cu:119-137): REDSEC_DEVICES lists the devices, every bootstrapped stage is split
