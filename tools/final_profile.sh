@@ -9,7 +9,7 @@ python bench.py --no-live-traffic --params redsec_small_v2 > $OUT/${P}_wg_fft_be
 python bench.py --no-live-traffic --mode exact --cpu-sample 0 > $OUT/${P}_exact_ntt_bench.json 2>> $OUT/bench_default.err
 python bench.py --no-live-traffic --mode exact --cpu-sample 0 --params redsec_small_v2 > $OUT/${P}_exact_ntt_bench_redsec_params.json 2>> $OUT/bench_default.err
 echo "benches done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-exact-check > $OUT/prof_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-exact-check --no-cifar > $OUT/prof_bench.log 2>&1
 find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/${P}_wg_fft_kernel_stats.csv \;
 head -4 $OUT/${P}_wg_fft_kernel_stats.csv
 python tools/mnist_latency.py > $OUT/${P}_mnist_latency.txt 2>&1; head -1 $OUT/${P}_mnist_latency.txt
