@@ -531,7 +531,7 @@ def main():
         kernel_name = {"workgroup": "blind_rotate_wg_kernel", "duo": "blind_rotate_duo_kernel", "per_wave": "blind_rotate_kernel",
                        "coop2": "blind_rotate_coop_kernel", "coop4": "blind_rotate_coop_kernel", "coop8": "blind_rotate_coop8_kernel",
                        "general": "gen_blind_rotate_kernel", "split_workgroup": "blind_rotate_wgs_kernel",
-                       "split_coop": "blind_rotate_coops_kernel", "split_coop8": "blind_rotate_coops8_kernel", "split_duo": "blind_rotate_duos_kernel"}[launch["form"]]
+                       "split_coop": "blind_rotate_coops_kernel", "split_duo": "blind_rotate_duos_kernel"}[launch["form"]]
         under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
         if world == 1 and not args.no_live_traffic and not under_profiler and not os.environ.get("REDSEC_BENCH_PMC_CHILD"):
             traffic = live_traffic(args, kernel_name)

@@ -1492,123 +1492,10 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coops_kernel(BlindRotateA
   }
 }
 
-// -------------------------------------------------------------------------------------------------
-// Cooperative blind rotation on the SPLIT key with EIGHT waves per ciphertext (B <= #CUs; round 4). As blind_rotate_coop8_kernel:
-// the digit rows of a step over 8 waves, two per SIMD, by coop8_row_count / coop8_row_first. Every wave multiplies its rows into
-// FOUR partial sums (low / high key half x two columns); 8 x 4 partials of 8 KB cannot be parked in LDS, so the sums meet by
-// LDS floating-point atomics (ds_add_f64, no return value) in s_sum[4][N] and the four waves with the fewest rows -- one per
-// SIMD -- each read one sum back, clear it for the next step, invert it and add the rounded result into the accumulator by
-// integer atomics (exact, order-independent), as the four-wave form does. The order of the floating-point additions is free:
-// the a-priori bound of rs_general.h holds for any order of a sum of 2l products (a gamma_{2l} term), and rounding then
-// returns the same integers. Key chunks stream L2 -> registers one chunk ahead (two waves per SIMD hide the rest).
-// LDS: 8 KB tables + 8 x 9 KB buffers + 32 KB sums + 8 KB accumulator = 120 KB.
-// -------------------------------------------------------------------------------------------------
-template <class C>
-__global__ __launch_bounds__(512) void blind_rotate_coops8_kernel(BlindRotateArgs a) {
-  using Xf = XfFft<C>;
-  constexpr int G = kCoop8Waves, L = C::L, KPL = 2 * L;
-  __shared__ double s_tw[Xf::kTableDoubles + 1];
-  __shared__ __attribute__((aligned(16))) double s_buf[G][kBufDoubles];
-  __shared__ double s_sum[4][kN];   // sum index = 2 * half + column
-  __shared__ int32_t s_acc[2][kN];
-  stage_tables(s_tw, a.tw, 64 * G, Xf::kTableDoubles);
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = threadIdx.x & 63;
-  const long ct = blockIdx.x;
-  const Field f = a.f;
-  double* buf = s_buf[wave];
-  typename Xf::State tw;
-  Xf::init(tw, lane, s_tw, a.tw);
-  const int32_t* row0 = a.in0 + ct * a.W;
-  const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
-  const int n = a.n;
-  const int comp = coop8_comp(wave), cnt = coop8_row_count(L, wave), first = coop8_row_first(L, wave);
-  const int own = coops8_owned_sum(wave);   // -1: this wave inverts nothing
-  auto word = [&](int i) -> int32_t {
-    uint32_t v = (uint32_t)a.c0 * (uint32_t)row0[i];
-    if (row1) v += (uint32_t)a.c1 * (uint32_t)row1[i];
-    return (int32_t)v;
-  };
-  for (int e = threadIdx.x; e < 4 * kN; e += 64 * G) (&s_sum[0][0])[e] = 0.0;
-  if (wave < 2) {
-    const int32_t barb = modswitch_2N((int32_t)((uint32_t)word(n) + (uint32_t)a.bconst));
-    const int rot = 2 * kN - barb;
-#pragma unroll
-    for (int r = 0; r < kRegs; ++r) {
-      const int j = lane + 64 * r;
-      s_acc[wave][j] = wave == 0 ? 0 : test_vector(a, ct, j, rot);
-    }
-  }
-  __syncthreads();
-  for (int i = 0; i < n; ++i) {
-    const int32_t bara = __builtin_amdgcn_readfirstlane(modswitch_2N(word(i)));
-    if (bara == 0) continue;   // uniform over the workgroup
-    if (cnt > 0) {
-      double s[4][kRegs];
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int u = 0; u < kRegs; ++u) s[k][u] = 0.0;
-      int32_t d[kRegs];
-#pragma unroll
-      for (int r = 0; r < kRegs; ++r) d[r] = gadget_prepare<C>(rotated_diff(s_acc[comp], lane + 64 * r, bara));
-#pragma unroll 1
-      for (int rr = 0; rr < cnt; ++rr) {
-        const int q = first + (int)((rr + blockIdx.x) % (unsigned)cnt);   // per-workgroup row order
-        const int row = comp * L + q;
-        // half-row (row, half) = [column 0: N doubles][column 1: N doubles], pairs (re, im) of position 8 lane + v at [v][lane]
-        const double2* lo0 = reinterpret_cast<const double2*>(a.bk_x + ((size_t)i * KPL + row) * 4 * kN);
-        const double2* lo1 = lo0 + kN / 2;
-        const double2* hi0 = lo0 + kN;
-        const double2* hi1 = hi0 + kN / 2;
-        auto load4 = [&](const double2* k0, const double2* k1, int v0, double2 (&w0)[4], double2 (&w1)[4]) {
-#pragma unroll
-          for (int v = 0; v < 4; ++v) { w0[v] = k0[(v0 + v) * 64 + lane]; w1[v] = k1[(v0 + v) * 64 + lane]; }
-        };
-        double x[kRegs];
-        double2 wa0[4], wa1[4], wb0[4], wb1[4];
-        load4(lo0, lo1, 0, wa0, wa1);
-        Xf::fwd_digits(lane, x, d, q, 0u, tw, buf, f);
-        load4(lo0, lo1, 4, wb0, wb1);
-        Xf::mac(s[0], s[1], x, wa0, wa1, 0, f);
-        load4(hi0, hi1, 0, wa0, wa1);
-        Xf::mac(s[0], s[1], x, wb0, wb1, 4, f);
-        load4(hi0, hi1, 4, wb0, wb1);
-        Xf::mac(s[2], s[3], x, wa0, wa1, 0, f);
-        Xf::mac(s[2], s[3], x, wb0, wb1, 4, f);
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int u = 0; u < kRegs; ++u) unsafeAtomicAdd(&s_sum[k][u * 64 + lane], s[k][u]);
-    }
-    __syncthreads();   // sums complete; every wave has finished reading the accumulator
-    if (own >= 0) {
-      double* sum = s_sum[own];
-      double x[kRegs];
-#pragma unroll
-      for (int u = 0; u < kRegs; ++u) x[u] = sum[u * 64 + lane];
-#pragma unroll
-      for (int u = 0; u < kRegs; ++u) sum[u * 64 + lane] = 0.0;   // for the next step (same lane, same address: in order)
-      Xf::inverse(lane, x, tw, buf, f);
-      const int sh = own >= 2 ? 16 : 0;
-      int32_t* acc = s_acc[own & 1];
-#pragma unroll
-      for (int r = 0; r < kRegs; ++r) atomicAdd(reinterpret_cast<unsigned*>(acc) + lane + 64 * r, (uint32_t)f_to_torus32(x[r]) << sh);
-    }
-    __syncthreads();   // accumulator updated, sums zero
-  }
-  int32_t* out = a.u_out + ct * (kN + 1);
-  if (wave == 0) {
-#pragma unroll
-    for (int r = 0; r < kRegs; ++r) {
-      const int j = lane + 64 * r;
-      out[j] = (j == 0) ? s_acc[0][0] : (int32_t)(0u - (uint32_t)s_acc[0][kN - j]);
-    }
-    if (lane == 0) out[kN] = s_acc[1][0];
-  }
-}
-
+// (An eight-wave form of this kernel -- blind_rotate_coops8_kernel, round 4: rows over 8 waves as in blind_rotate_coop8_kernel, the
+// four sums met by LDS f64 atomics -- was built, bit-exact, and is SLOWER: 4.90 / 6.93 ms against 4.08 ms for 196 sign bootstraps
+// (profiles/r04/i_ab_coop8_atomics_and_coops8.txt). Four 32-register sums beside a transform leave a wave of a two-wave SIMD (256
+// registers) no room to keep a key row in flight across the transform, which is what the four-wave form's 412 registers buy. Removed.)
 // -------------------------------------------------------------------------------------------------
 // Blind rotation, "duo" workgroup form (mid-size batches: 2 x #CUs < B < 8 x #CUs, even l).
 // One wave per ciphertext leaves half the wave slots empty there and every wave streams the whole key
@@ -1987,7 +1874,8 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateAr
 // sums are rounded to the exact integers, certificate-tracked as everywhere); two workgroup barriers per step.
 // -------------------------------------------------------------------------------------------------
 #ifndef RS_COOP8_ATOMICS
-#define RS_COOP8_ATOMICS 0   // 1: the partial column sums meet by LDS f64 atomics instead of one store + 7 x 16 reads per inverse wave
+#define RS_COOP8_ATOMICS 1   // the partial column sums meet by LDS f64 atomics (0: one store + 7 x 16 reads per inverse wave; 196 sign bootstraps
+                             // 2.92 -> 2.64 ms on one box, profiles/r04/i_ab_coop8_atomics.txt)
 #endif
 #ifndef RS_COOP8_KEEP_TW
 #define RS_COOP8_KEEP_TW 0   // 1: per-lane twiddles in registers (FftTwKept<3>) instead of LDS table reads
@@ -2356,12 +2244,7 @@ hipError_t launch_blind_rotate_split_wg(int cfg, const BlindRotateArgs& a, int n
     using C = decltype(c);
     LaunchInfo li;
     li.form = kFormSplitCoop; li.resident = 1;
-    if (!o.no_coop8 && a.B <= num_cus) {   // at most one ciphertext per CU: eight waves share it (two per SIMD)
-      hipLaunchKernelGGL((blind_rotate_coops8_kernel<C>), dim3((unsigned)a.B), dim3(512), 0, st, a);
-      li.form = kFormSplitCoop8; li.waves_per_block = 8;
-      if (info) *info = li;
-      return hipGetLastError();
-    }
+
     if constexpr ((2 * C::L) % 4 == 0) {
       if (a.B <= num_cus) {
         hipLaunchKernelGGL((blind_rotate_coops_kernel<C, 4>), dim3((unsigned)a.B), dim3(256), 0, st, a);

@@ -630,6 +630,31 @@ long model_coop8(int L, int broken) {
   }
   return m.conflicts();
 }
+// blind_rotate_coop8_kernel as shipped (RS_COOP8_ATOMICS): every wave adds its partials into s_sum[2][N] by LDS f64 atomics; after the
+// barrier the two inverse waves read their column's sum, clear it for the next step, transform, update the accumulator
+long model_coop8_atomics(int L, int broken) {
+  LdsModel m;
+  auto sum = [&](int col) { return LdsModel::PART + col * kPolyBytes; };
+  for (int step = 0; step < 2; ++step) {
+    for (int w = 0; w < rs::kCoop8Waves; ++w) {
+      if (rs::coop8_row_count(L, w) == 0) continue;
+      m.rd(w, LdsModel::ACC + rs::coop8_comp(w) * kAccBytes, kAccBytes);
+      m.rw(w, buf_of(w), kBufBytes);
+      for (int col = 0; col < 2; ++col) m.atomic(w, sum(col), kPolyBytes);
+    }
+    m.barrier();
+    for (int col = 0; col < 2; ++col) {
+      const int w = col == 0 ? rs::kCoop8InvA : rs::kCoop8InvB;
+      m.rd(w, sum(col), kPolyBytes);
+      if (broken != 1) m.wr(w, sum(col), kPolyBytes);     // cleared here, before the barrier ...
+      m.rw(w, buf_of(w), kBufBytes);
+      m.rw(w, LdsModel::ACC + col * kAccBytes, kAccBytes);
+    }
+    if (broken != 2) m.barrier();
+    if (broken == 1) for (int col = 0; col < 2; ++col) m.wr(col == 0 ? rs::kCoop8InvA : rs::kCoop8InvB, sum(col), kPolyBytes);   // ... not behind it
+  }
+  return m.conflicts();
+}
 // blind_rotate_coops_kernel<G>: s_part[wave][slot of a sum the wave does not own]
 template <int G>
 long model_coops(int broken) {
@@ -969,7 +994,8 @@ long rs_emu_exchange_schedule(long rows, int n, long* out) {
   }
   return (long)plan.size();
 }
-// form: 0 coop<2>, 1 coop<4>, 2 coop8 (l = 10), 3 coop8 (l = 3), 4 coops<2>, 5 coops<4>, 6 duo, 7 duos, 8 wgs<8>, 9 wgs<4>, 10 wg
+// form: 0 coop<2>, 1 coop<4>, 2 / 3 coop8 with the s_part exchange (-DRS_COOP8_ATOMICS=0; l = 10 / 3), 4 coops<2>, 5 coops<4>, 6 duo, 7 duos,
+//       8 wgs<8>, 9 wgs<4>, 10 wg, 11 / 12 coop8 as shipped (sums by LDS atomics; l = 10 / 3)
 long rs_emu_lds_protocol_conflicts(int form, int broken) {
   switch (form) {
     case 0: return model_coop(2, broken);
@@ -983,6 +1009,8 @@ long rs_emu_lds_protocol_conflicts(int form, int broken) {
     case 8: return model_wgs(8, 3, broken);
     case 9: return model_wgs(4, 10, broken);
     case 10: return model_wg(3, broken);
+    case 11: return model_coop8_atomics(10, broken);
+    case 12: return model_coop8_atomics(3, broken);
   }
   return -1;
 }

@@ -52,7 +52,7 @@ struct LaunchOpts {
 };
 // What a blind-rotate launch actually ran: kernel form and how many ciphertexts share one sweep of the key
 // from L2/HBM (R of SURVEY.md section 8d).
-enum { kFormPerWave = 0, kFormWorkgroup = 1, kFormDuo = 2, kFormCoop2 = 3, kFormCoop4 = 4, kFormGeneral = 5, kFormSplitWorkgroup = 6, kFormSplitCoop = 7, kFormSplitDuo = 8, kFormCoop8 = 9, kFormSplitCoop8 = 10 };
+enum { kFormPerWave = 0, kFormWorkgroup = 1, kFormDuo = 2, kFormCoop2 = 3, kFormCoop4 = 4, kFormGeneral = 5, kFormSplitWorkgroup = 6, kFormSplitCoop = 7, kFormSplitDuo = 8, kFormCoop8 = 9 };
 struct LaunchInfo { int form = -1; int waves_per_block = 0; long resident = 0; };
 
 struct KeyswitchArgs {

@@ -34,10 +34,6 @@ RS_HD constexpr int coop8_partial_home(int wave, int col) {
   return wave == kCoop8InvB ? kHomeRegisters : kHomePartSlot;
 }
 
-// blind_rotate_coops8_kernel (split key, 8 waves): which of the four sums (2 * half + column) a wave inverts, -1 for none. The
-// owners are the four waves with the fewest rows for every l (waves 2, 3 of component 0; 4, 5 of component 1): one per SIMD.
-RS_HD constexpr int coops8_owned_sum(int wave) { return wave == 2 ? 0 : (wave == 3 ? 1 : (wave == 4 ? 2 : (wave == 5 ? 3 : -1))); }
-
 // ---- blind_rotate_coops_kernel<G>: four sums (2 key halves x 2 columns), one owner wave each -----------------------------
 template <int G> RS_HD constexpr int coops_owner(int sum) { return G == 4 ? sum : (sum & 1); }
 // index of `sum` among the sums wave g does NOT own (its slots of s_part)

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 EXPECTED_FORMS = {"fft/coop8", "fft/coop2", "fft/duo", "fft/workgroup", "exact/per_wave", "exact/coop2", "exact/coop4",
-                  "split/split_coop8", "split/split_coop", "split/split_duo", "split/split_workgroup"}
+                  "split/split_coop", "split/split_duo", "split/split_workgroup"}
 
 
 def test_six_fresh_processes_differential_stress():

@@ -391,7 +391,7 @@ def test_split_mode_small_batch_forms(toy, name, seed):
     whole = be.bootstrap(d, e8)
     assert be.last_launch() == {"form": "split_workgroup", "waves_per_block": 8, "resident": 8 * cus}
     coop4 = (2 * l) % 4 == 0
-    cases = [(1, "split_coop8", 8), (cus, "split_coop8", 8), (cus + 1, "split_coop", 2),
+    cases = [(1, "split_coop", 4 if coop4 else 2), (cus, "split_coop", 4 if coop4 else 2), (cus + 1, "split_coop", 2),
              (2 * cus, "split_coop", 2), (2 * cus + 1, "split_duo", 8), (3 * cus + 2, "split_duo", 8), (4 * cus, "split_duo", 8),
              (4 * cus + 1, "split_workgroup", 8)]
     for b, form, waves in cases:
@@ -408,7 +408,7 @@ def test_split_mode_small_batch_forms(toy, name, seed):
     g_whole, m_whole, l_whole = be.gate("NAND", d, cb), be.mux(d, cb, cc), be.bootstrap_lut(d, luts)
     for b in (7, cus + 3, 2 * cus + 5):     # the last one through blind_rotate_duos_kernel (4 ciphertexts x 2 waves, ragged last group)
         assert torch.equal(be.gate("NAND", d[:b], cb[:b]), g_whole[:b])
-        assert be.last_launch()["form"] == ("split_coop8" if b <= cus else ("split_coop" if b <= 2 * cus else "split_duo"))
+        assert be.last_launch()["form"] == ("split_coop" if b <= 2 * cus else "split_duo")
         assert torch.equal(be.mux(d[:b], cb[:b], cc[:b]), m_whole[:b])
         assert torch.equal(be.bootstrap_lut(d[:b], luts), l_whole[:b])
     if name != "redsec_small":
