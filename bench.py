@@ -537,7 +537,7 @@ def main():
             traffic = live_traffic(args, kernel_name)
             if traffic is not None:
                 traffic_src = "measured_in_this_run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one child run each of one step of the same workload on this GPU"
-        for rnd in (() if traffic is not None else ("r03", "r02", "r01")):
+        for rnd in (() if traffic is not None else ("r04", "r03", "r02", "r01")):
             try:
                 path = os.path.join("profiles", rnd, "pmc_traffic.json")
                 pmc = json.load(open(os.path.join(ROOT, path)))
