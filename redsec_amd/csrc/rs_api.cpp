@@ -198,6 +198,12 @@ void attach_ks_scratch(const rs_ctx* c, Lane* ln, rs::KeyswitchArgs& k) {
   k.scratch_words = ln->ks_scratch_words;
 }
 
+// the lane's XCD cohort table (rs_kernels.h), allocated on first use; nullptr if that fails (the launch then runs free)
+int* lane_progress(Lane* ln) {
+  if (!ln->d_progress && hipMalloc(&ln->d_progress, 8 * rs::kCohortSlots * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); ln->d_progress = nullptr; }
+  return ln->d_progress;
+}
+
 int ensure_io(rs_ctx* c, size_t B) {
   if (B <= c->io_batch) return RS_OK;
   for (auto& p : c->d_io) { if (p) { (void)hipFree(p); p = nullptr; } }
@@ -297,8 +303,7 @@ int run_bootstrap(rs_ctx* c, hipStream_t st, int32_t* out, const Combo* combos, 
         // N = 1024 with one of the reference's gadgets at throughput batch sizes: lock-step workgroups on the split key
         rs::BlindRotateArgs w = br_args(c, ln, 1, cs[k], mu, lut, B);
         w.bk_x = c->d_bk_gen; w.tw = c->d_tw_fft;
-        if (!ln->d_progress && hipMalloc(&ln->d_progress, 8 * rs::kCohortSlots * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); ln->d_progress = nullptr; }
-        w.progress = ln->d_progress;   // optional: without the table the workgroups run free
+        w.progress = lane_progress(ln);   // optional: without the table the workgroups run free
         const hipError_t e = rs::launch_blind_rotate_split_wg(c->wgs_cfg, w, c->num_cus, c->opts, st, &ln->last);
         if (e == hipSuccess) { split_wg = true; continue; }
         if (e != hipErrorNotSupported) return fail(RS_ERR_HIP, "split workgroup launch failed: %s", hipGetErrorString(e));
@@ -322,6 +327,7 @@ int run_bootstrap(rs_ctx* c, hipStream_t st, int32_t* out, const Combo* combos, 
     for (int k = 0; k < count; ++k) {
       rs::BlindRotateArgs a = br_args(c, ln, 1, cs[k], mu, lut, B);
       a.dev_flag = slot;
+      a.progress = lane_progress(ln);   // used by the lock-step form only, and only when its workgroups sweep the key more than once
       RS_HIP(rs::launch_blind_rotate(c->cfg, 1, a, wpb, c->num_cus, c->opts, st, &ln->last));
     }
     unsigned long long limit_bits;

@@ -572,6 +572,42 @@ __device__ unsigned long long g_rs_stamps[256 * 8 * kStampPhases];
 #define RS_STAMP_FLUSH(wave) ((void)0)
 #endif
 
+// XCD cohorts. The lock-step split kernel streams 2 x the key bytes of the unsplit one; the workgroups of an XCD share them
+// through that XCD's 4 MB L2 only while they are within a few CMUX steps of each other (one step = 2 l x 2 half-rows of 16 KB:
+// 192 KB default-128, 640 KB REDsec set), and nothing kept them there: counter traffic of a 65,536-gate launch was 58 GB in
+// round 2 and 106 GB in round 3 against 32 GB if every XCD fetched every half-row once per round. So every `every` steps wave 0
+// of a workgroup publishes its step count and looks at its XCD's table (workgroups are dealt to the XCDs round-robin:
+// xcd = blockIdx.x & 7); more than `lag` steps ahead of the slowest one it waits -- bounded: at most kCohortPolls polls, so a
+// workgroup that is not resident (a shared GPU) or a stale table can delay a launch but never hang it. The other waves of the
+// workgroup notice nothing: they wait for wave 0 at the next publish barrier, as they do anyway.
+constexpr int kCohortPolls = 48;
+// Two halves, one CMUX step apart, so that the table's L2 round trip is never waited for: cohort_post publishes this workgroup's
+// step count and REQUESTS its XCD's row (lane L: entry L; kCohortSlots = 64 = one wavefront); cohort_check, a step later, looks
+// at what came back and only if some entry lags polls synchronously (bounded).
+__device__ __forceinline__ int cohort_post(int* progress, int mine, int lane) {
+  int* row = progress + (blockIdx.x & 7) * kCohortSlots;
+  if (lane == 0) __hip_atomic_store(row + (blockIdx.x >> 3), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load(row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void cohort_check(int* progress, int seen, int mine, int lag, int lane) {
+  if (__builtin_amdgcn_ballot_w64(seen + lag < mine) == 0) return;
+  const int* row = progress + (blockIdx.x & 7) * kCohortSlots;
+  for (int poll = 0; poll < kCohortPolls; ++poll) {
+    __builtin_amdgcn_s_sleep(64);
+    const int v = __hip_atomic_load(row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__builtin_amdgcn_ballot_w64(v + lag < mine) == 0) break;
+  }
+}
+// one call per CMUX step and workgroup (wave 0): check what the previous post brought back, post again every `every` steps
+struct CohortState { int seen = 0x7f7f7f7f, mine = 0; bool armed = false; };
+__device__ __forceinline__ void cohort_step(const BlindRotateArgs& a, CohortState& st, long step, int i, int lane) {
+  if (st.armed) { cohort_check(a.progress, st.seen, st.mine, a.cohort_lag, lane); st.armed = false; }
+  if (i % a.cohort_every == 0) { st.mine = (int)step; st.seen = cohort_post(a.progress, st.mine, lane); st.armed = true; }
+}
+__device__ __forceinline__ void cohort_leave(int* progress, int lane) {
+  if (lane == 0) __hip_atomic_store(progress + (blockIdx.x & 7) * kCohortSlots + (blockIdx.x >> 3), 0x7f7f7f7f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <class Xf, int WPB>
 __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateArgs a) {
   using C = typename Xf::Cfg;
@@ -649,7 +685,9 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
     }
   };
 
-  for (long group = blockIdx.x; group < n_groups; group += gridDim.x) {
+  long steps_done = 0;   // CMUX steps of the groups this workgroup has finished (XCD cohorts)
+  CohortState cohort;
+  for (long group = blockIdx.x; group < n_groups; group += gridDim.x, steps_done += n) {
     const long ct = group * WPB + wave;
     const bool active = ct < a.B;
     const int32_t* row0 = a.in0 + (active ? ct : 0) * a.W;
@@ -709,6 +747,9 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
     long R = 0;
     unsigned bara_next = s_bara[wave][0];   // read one step ahead: its LDS latency is not exposed
     for (int i = 0; i < n; ++i) {
+      // XCD cohorts (cohort_step above): with l = 10 a step reads 320 KB of key per CU and an XCD's L2 keeps 12 steps; launches of the REDsec
+      // set were seen at twice the 8-XCD floor of fabric traffic (60.8 GB, profiles/r04/pmc) when workgroups drifted further apart
+      if (a.progress && wave == 0) cohort_step(a, cohort, steps_done + i, i, lane);
       const int32_t bara = __builtin_amdgcn_readfirstlane((int)bara_next);
       if (((i + 1) & (kWin - 1)) == 0 && i + 1 < n) { wave_lds_sync(); fill_window(i + 1); wave_lds_sync(); }
       bara_next = (i + 1 < n) ? s_bara[wave][(i + 1) & (kWin - 1)] : 0;
@@ -833,6 +874,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
     RS_STAMP(7);
   }
   RS_STAMP_FLUSH(wave);
+  if (a.progress && wave == 0) cohort_leave(a.progress, lane);
   if (Xf::kCertificate) publish_certificate(dev, a.dev_flag, lane);
 }
 
@@ -878,33 +920,6 @@ __device__ __forceinline__ void mac_half_stream(double (&s0)[kRegs], double (&s1
   mac_half_stream_cols(s0, s1, x, k0, k0 + kN / 2, lane);
 }
 
-// XCD cohorts. The lock-step split kernel streams 2 x the key bytes of the unsplit one; the workgroups of an XCD share them
-// through that XCD's 4 MB L2 only while they are within a few CMUX steps of each other (one step = 2 l x 2 half-rows of 16 KB:
-// 192 KB default-128, 640 KB REDsec set), and nothing kept them there: counter traffic of a 65,536-gate launch was 58 GB in
-// round 2 and 106 GB in round 3 against 32 GB if every XCD fetched every half-row once per round. So every `every` steps wave 0
-// of a workgroup publishes its step count and looks at its XCD's table (workgroups are dealt to the XCDs round-robin:
-// xcd = blockIdx.x & 7); more than `lag` steps ahead of the slowest one it waits -- bounded: at most kCohortPolls polls, so a
-// workgroup that is not resident (a shared GPU) or a stale table can delay a launch but never hang it. The other waves of the
-// workgroup notice nothing: they wait for wave 0 at the next publish barrier, as they do anyway.
-constexpr int kCohortPolls = 48;
-__device__ __forceinline__ int cohort_slowest(const int* row, int lane) {
-  int v = __hip_atomic_load(row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // kCohortSlots = 64 = one wavefront
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off, 64); v = o < v ? o : v; }
-  return v;
-}
-__device__ __forceinline__ void cohort_wait(int* progress, int mine, int lag, int lane) {
-  int* row = progress + (blockIdx.x & 7) * kCohortSlots;
-  if (lane == 0) __hip_atomic_store(row + (blockIdx.x >> 3), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int poll = 0; poll < kCohortPolls; ++poll) {
-    if (cohort_slowest(row, lane) + lag >= mine) break;
-    __builtin_amdgcn_s_sleep(64);
-  }
-}
-__device__ __forceinline__ void cohort_leave(int* progress, int lane) {
-  if (lane == 0) __hip_atomic_store(progress + (blockIdx.x & 7) * kCohortSlots + (blockIdx.x >> 3), 0x7f7f7f7f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 template <class C, int WPB>
 __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateArgs a) {
   using Xf = XfFft<C>;
@@ -937,6 +952,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
   const unsigned lane_off = (unsigned)lane * 16u;
   auto sync_w = [] { wave_lds_sync(); };
   long steps_done = 0;   // CMUX steps of the groups this workgroup has finished (XCD cohorts)
+  CohortState cohort;
 
   for (long group = blockIdx.x; group < n_groups; group += gridDim.x, steps_done += n) {
     const long ct = group * WPB + wave;
@@ -1013,7 +1029,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
 
     for (int i = 0; i < n; ++i) {
       if ((i & (kWin - 1)) == 0 && i > 0) { wave_lds_sync(); fill_window(i); }
-      if (a.progress && wave == 0 && i % a.cohort_every == 0) cohort_wait(a.progress, (int)(steps_done + i), a.cohort_lag, lane);
+      if (a.progress && wave == 0) cohort_step(a, cohort, steps_done + i, i, lane);
       wave_lds_sync();
       const int32_t bara = __builtin_amdgcn_readfirstlane((int)s_bara[wave][i & (kWin - 1)]);
       const bool work = bara != 0;   // tfhe_blindRotate_FFT skips the identity CMUX (the barriers still run)
@@ -2112,6 +2128,17 @@ static hipError_t launch_br(const BlindRotateArgs& a, long max_blocks, hipStream
   return hipGetLastError();
 }
 
+// XCD cohorts of the unsplit lock-step kernel (cohort_step): only for launches whose workgroups sweep the key more than once. A CMUX step
+// reads 2l rows of 16 KB; the lag keeps a cohort inside about a third of its XCD's 4 MB L2.
+template <class C>
+static hipError_t cohort_setup(BlindRotateArgs& w, long groups, long grid, const LaunchOpts& o, hipStream_t st) {
+  if (!w.progress || o.no_cohort || grid > 8L * kCohortSlots || groups <= grid) { w.progress = nullptr; return hipSuccess; }
+  const long step_bytes = 2L * C::L * 16384;
+  w.cohort_lag = (int32_t)std::max<long>(1, (4L << 20) / 3 / step_bytes);
+  w.cohort_every = w.cohort_lag >= 4 ? 2 : 1;
+  return hipMemsetAsync(w.progress, 0x7f, 8 * kCohortSlots * sizeof(int), st);
+}
+
 template <class Xf>
 static hipError_t launch_br_xf(const BlindRotateArgs& a, int wpb, long num_cus, bool coop4, const LaunchOpts& o, hipStream_t st, LaunchInfo* info) {
   LaunchInfo li;
@@ -2165,8 +2192,10 @@ static hipError_t launch_br_xf(const BlindRotateArgs& a, int wpb, long num_cus, 
         if (a.in1) t.in1 = a.in1 + m.B * a.W;
         t.u_out = a.u_out + m.B * (kN + 1);
         if (a.lut) t.lut_first = (int32_t)((a.lut_first + m.B) % a.lut_count);
+        if (hipError_t ce = cohort_setup<typename Xf::Cfg>(m, m.B / 8, num_cus, o, st); ce != hipSuccess) return ce;
         hipLaunchKernelGGL((blind_rotate_wg_kernel<Xf, 8>), dim3((unsigned)num_cus), dim3(512), 0, st, m);
         hipError_t e = hipGetLastError();
+        t.progress = nullptr;   // the cut-off last round runs in a form without cohorts
         if (e != hipSuccess) return e;
         e = launch_br_xf<Xf>(t, wpb, num_cus, coop4, o, st, nullptr);
         if (e != hipSuccess) return e;
@@ -2174,7 +2203,9 @@ static hipError_t launch_br_xf(const BlindRotateArgs& a, int wpb, long num_cus, 
       }
       const long groups = (a.B + 7) / 8;
       const long grid = groups < num_cus ? groups : num_cus;
-      hipLaunchKernelGGL((blind_rotate_wg_kernel<Xf, 8>), dim3((unsigned)grid), dim3(512), 0, st, a);
+      BlindRotateArgs w = a;
+      if (hipError_t e = cohort_setup<typename Xf::Cfg>(w, groups, grid, o, st); e != hipSuccess) return e;
+      hipLaunchKernelGGL((blind_rotate_wg_kernel<Xf, 8>), dim3((unsigned)grid), dim3(512), 0, st, w);
       return done(kFormWorkgroup, 8, 8 * grid);   // the workgroups sweep the key together: 8 x grid ciphertexts per sweep
     }
   }
@@ -2275,7 +2306,7 @@ hipError_t launch_blind_rotate_split_wg(int cfg, const BlindRotateArgs& a, int n
   const long grid = groups < num_cus ? groups : num_cus;
   BlindRotateArgs w = a;
   if (w.progress && !o.no_cohort && grid <= 8L * kCohortSlots && groups > grid) {
-    // XCD cohorts (see cohort_wait): only for launches whose workgroups walk several groups, i.e. sweep the key more than once.
+    // XCD cohorts (see cohort_step): only for launches whose workgroups walk several groups, i.e. sweep the key more than once.
     // A CMUX step reads 2 * 2l half-rows of 16 KB; the lag keeps a cohort inside about a third of its 4 MB L2.
     const long step_bytes = 4L * (cfg == 1 ? 10 : 3) * 16384;
     w.cohort_lag = (int32_t)std::max<long>(1, (4L << 20) / 3 / step_bytes);

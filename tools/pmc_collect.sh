@@ -13,7 +13,7 @@ for P in default128 redsec_small_v2; do
              "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
     TAG=$(echo $SET | cut -d' ' -f1)
     rm -rf $OUT/tmp
-    rocprofv3 --pmc $SET --output-format csv -d $OUT/tmp -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-exact-check --params $P --mode $M > $OUT/${P}_${M}_${TAG}.log 2>&1
+    rocprofv3 --pmc $SET --output-format csv -d $OUT/tmp -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-exact-check --no-mnist --no-cifar --no-live-traffic --params $P --mode $M > $OUT/${P}_${M}_${TAG}.log 2>&1
     f=$(find $OUT/tmp -name "*counter_collection.csv" | head -1)
     if [ -n "$f" ]; then grep -E "Counter_Name|blind_rotate|keyswitch" "$f" > $OUT/${P}_${M}_${TAG}.csv; echo "$P $M $TAG: $(wc -l < $OUT/${P}_${M}_${TAG}.csv) rows"; else echo "$P $M $TAG: no counter file"; tail -3 $OUT/${P}_${M}_${TAG}.log; fi
   done
