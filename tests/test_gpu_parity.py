@@ -507,3 +507,43 @@ def test_rccl_gather_world_size_one():
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_world1.py")], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "rccl world-1 ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_sliced_keyswitch_two_step_equals_the_atomics_form_and_the_oracle(monkeypatch):
+    """lweKeySwitch at the batch sizes of the latency forms, on REDsec's shipped shape at its full size (N = 1024, t = 9,
+    basebit = 3, W = 351: 11 word blocks, 64 ... 4 input slices): the two-step form (every slice leaves its partial sums in a
+    per-stream scratch laid out [slice][word][ciphertext], keyswitch_reduce_kernel adds them up and transposes) against the
+    round-1 form (RS_KS_ATOMICS=1: the slices meet by integer atomics in a zeroed output) on WHOLE batches, and against the
+    oracle's lweKeySwitch on sampled rows. Batch sizes on both sides of every slice-count change, ragged against the 256-lane
+    workgroups and the 16 x 16 reduce tiles. Synthetic keys (generated on the device; the oracle restates the generator)."""
+    import torch
+    import redsec_amd
+    seed = 0xabc123
+    p = ol.params("redsec_small_v2")
+    W, N = p.n + 1, p.N
+
+    def backend():
+        be = redsec_amd.Backend(redsec_amd.params("redsec_small_v2"), device=0)
+        be.load_synthetic_keys(seed)
+        return be
+    be = backend()
+    monkeypatch.setenv("RS_KS_ATOMICS", "1")          # read once, in rs_create
+    be_atomics = backend()
+    monkeypatch.delenv("RS_KS_ATOMICS")
+
+    class K:
+        pass
+    ks = K(); ks.p = p
+    ks.bk = np.zeros(ol.lib().ro_bk_words(ol.C.byref(p)), np.int32)        # never read: only the keyswitch runs on the oracle
+    ks.ksk = ol.synthetic_key_words(seed ^ 0x6b73, N * p.ks_t * (1 << p.ks_basebit) * W)
+    ctx = ol.Ctx(ks)
+    rng = np.random.default_rng(3)
+    for B in (1, 15, 17, 196, 255, 257, 600, 1024, 1500, 2048, 3000, 6000):
+        u = rng.integers(-2**31, 2**31, (B, N + 1), dtype=np.int32)
+        u[0, :7] = 0                                   # zero digits select the resident zero row
+        d = _dev(u)
+        got = be.keyswitch(d)
+        assert torch.equal(got, be_atomics.keyswitch(d)), B
+        rows = np.unique(np.r_[0, B // 2, B - 1, rng.integers(0, B, 5)])
+        assert np.array_equal(got.cpu().numpy()[rows], ctx.keyswitch(u[rows])), B
+    be.close(); be_atomics.close(); ctx.close()
