@@ -1031,6 +1031,9 @@ long rs_emu_coop8_row_split_violations(int L) {
   return bad;
 }
 
+// slices of a small-batch keyswitch launch and the scratch they need (rs_host.h)
+long rs_emu_keyswitch_slices(long B, int W, int N) { return (long)rs::keyswitch_slices(B, W, N); }
+long rs_emu_keyswitch_scratch_words(long B, int W, int N) { return (long)rs::keyswitch_scratch_words_for(B, W, N); }
 // the operation list of rs_allgather_rows for n contexts on `devices`, peer[d * n + s] = direct access allowed; rows of
 // (kind, ctx, other, path, lo, hi); returns the number of operations (out may be null)
 long rs_emu_exchange_plan(long rows, int n, const int* devices, const unsigned char* peer, int force_staged, long* out) {

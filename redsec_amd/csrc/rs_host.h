@@ -51,6 +51,22 @@ inline std::vector<SliceCopy> exchange_schedule(size_t rows, int n) {
   return out;
 }
 
+// ---- sliced keyswitch of small batches (rs_kernels.hip: keyswitch_tiled_kernel + keyswitch_reduce_kernel) ----
+// A tiled keyswitch launch is (ceil(B / 256) ciphertext blocks) x (ceil(W / 32) word blocks) workgroups; a small batch cuts the N
+// input coefficients into `slices` (a power of two, at most 64, at least 4 staging groups... coefficients each) until about 1,024
+// workgroups exist. Each slice leaves its partial sums in a scratch of slices x W x B words, which the reduce kernel adds up.
+inline unsigned keyswitch_slices(long B, int W, int N) {
+  if (B <= 0) return 1;
+  const unsigned gx = (unsigned)((B + 255) / 256), gy = (unsigned)((W + 31) / 32);
+  unsigned split = 1;
+  while (split < 64 && gx * gy * split < 1024 && N / (int)(2 * split) >= 4) split *= 2;
+  return split;
+}
+inline size_t keyswitch_scratch_words_for(long B, int W, int N) {
+  const unsigned split = keyswitch_slices(B, W, N);
+  return split > 1 ? (size_t)split * (size_t)W * (size_t)B : 0;
+}
+
 // How one slice travels from the context that computed it to a context that needs it. Peer access is asked for per device pair
 // (hipDeviceCanAccessPeer + hipDeviceEnablePeerAccess); where it is refused the slice is staged through pinned host memory by
 // this library itself -- source D2H once, every such destination H2D -- instead of relying on what the runtime does then.

@@ -7,6 +7,7 @@
 
 #include <cstdlib>
 
+#include "rs_host.h"
 #include "rs_kernels.h"
 #include "rs_ntt.h"
 
@@ -437,12 +438,10 @@ __global__ __launch_bounds__(256) void sumpool_kernel(int32_t* __restrict__ out,
 static bool ks_tiled_shape(const KeyswitchArgs& a) {
   return (a.t == 8 && a.basebit == 2) || (a.t == 9 && a.basebit == 3) || (a.t == 18 && a.basebit == 1);
 }
+static_assert(KS_TILE_THREADS == 256 && KS_CH == 32, "rs_host.h keyswitch_slices() restates this grid");
 static unsigned ks_slices(const KeyswitchArgs& a) {
   if (!ks_tiled_shape(a) || a.B <= 0) return 1;
-  const unsigned gx = (unsigned)((a.B + KS_TILE_THREADS - 1) / KS_TILE_THREADS), gy = (unsigned)((a.W + KS_CH - 1) / KS_CH);
-  unsigned split = 1;
-  while (split < 64 && gx * gy * split < 1024 && a.N / (int)(2 * split) >= 4) split *= 2;
-  return split;
+  return keyswitch_slices(a.B, a.W, a.N);   // host logic (rs_host.h), CPU-tested through the emulator library
 }
 size_t keyswitch_scratch_words(const KeyswitchArgs& a) {
   const unsigned split = ks_slices(a);

@@ -304,3 +304,27 @@ def test_coop8_row_split_covers_every_row_once_and_balances_the_simds():
     L.rs_emu_coop8_row_split_violations.restype = ctypes.c_long
     for l in range(1, 17):
         assert L.rs_emu_coop8_row_split_violations(l) == 0, l
+
+
+def test_keyswitch_slicing_rule():
+    """rs_host.h keyswitch_slices: how a small batch's keyswitch is cut into input-coefficient slices (each slice stores its partial
+    sums to a scratch of slices x W x B words; keyswitch_reduce_kernel adds them). Properties the kernels rely on: a power of two
+    that divides the N / IG staging groups of every tiled shape (IG = 2 or 4), at most 64, never more slices than needed for
+    ~1,024 workgroups, one slice (the plain-store throughput form, no scratch) for the large batches, monotone in B."""
+    L = emu_lib.lib()
+    L.rs_emu_keyswitch_slices.restype = ctypes.c_long
+    L.rs_emu_keyswitch_scratch_words.restype = ctypes.c_long
+    for W, N in ((351, 1024), (631, 1024), (501, 1024), (3073, 4096), (6145, 8192), (25, 1024)):
+        prev = 64
+        for B in (1, 2, 15, 196, 256, 257, 600, 1024, 2048, 4096, 8192, 20000, 32768, 65536, 131072):
+            s = L.rs_emu_keyswitch_slices(B, W, N)
+            gx, gy = (B + 255) // 256, (W + 31) // 32
+            assert s in (1, 2, 4, 8, 16, 32, 64) and (N // 4) % s == 0 and N // (2 * s) >= 2
+            assert s == 1 or gx * gy * (s // 2) < 1024                       # the last doubling was needed
+            assert s == 64 or gx * gy * s >= 1024 or N // (2 * s) < 4       # and it stopped for a reason
+            assert s <= prev
+            prev = s
+            assert L.rs_emu_keyswitch_scratch_words(B, W, N) == (s * W * B if s > 1 else 0)
+        if W >= 351:                                                          # (a toy width has a single word block: even 65,536 ciphertexts are sliced)
+            assert L.rs_emu_keyswitch_slices(65536, W, N) == 1
+    assert L.rs_emu_keyswitch_slices(196, 351, 1024) == 64 and L.rs_emu_keyswitch_slices(1024, 351, 1024) == 32
