@@ -19,7 +19,7 @@ HIP_LIB = os.path.join(HERE, "libredsec_hip.so")
 EMU_LIB = os.path.join(HERE, "librs_emulate.so")
 
 HIP_SOURCES = ["rs_bootstrap.hip", "rs_general.hip", "rs_kernels.hip", "rs_api.cpp"]
-HIP_DEPS = HIP_SOURCES + ["rs_kernels.h", "rs_lds_plan.h", "rs_ntt.h", "rs_fft.h", "rs_general.h", "rs_host.h", os.path.join(INCLUDE, "redsec_hip.h")]
+HIP_DEPS = HIP_SOURCES + ["rs_kernels.h", "rs_cohort.h", "rs_lds_plan.h", "rs_ntt.h", "rs_fft.h", "rs_general.h", "rs_host.h", os.path.join(INCLUDE, "redsec_hip.h")]
 # Objects of the product library: (object name, source, extra flags). rs_bootstrap.hip is compiled twice (its RS_BS_PART
 # switch): part 1 -- the FFT / exact-NTT blind-rotation kernels and the split duo form -- with LLVM's post-register-allocation
 # scheduler off: its in-block reordering of the hand-laid-out LDS / FP64 sequences costs these kernels 1-3 % (same-box A/B,

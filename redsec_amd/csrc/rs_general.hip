@@ -188,6 +188,10 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
   }
 #endif
 
+  // (XCD cohorts, rs_cohort.h, were tried here in round 4 -- wave 0 posting the step count and waiting for its XCD's slowest workgroup -- and
+  // cost 7 % at N = 4096 and 3 % at N = 8192 whether switched on or off: the few registers of the cohort state spill 21-40 more dwords in
+  // kernels that were full (profiles/r04/x_ab_general_cohorts_and_xcd_rotation.txt). The fabric traffic of these kernels sits at the 8-XCD
+  // floor without them.)
   for (long ct = blockIdx.x; ct < a.B; ct += gridDim.x) {
     const int32_t* row0 = a.in0 + ct * a.W;
     const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
@@ -369,6 +373,8 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
 #else
         constexpr int kRot = LOGN >= 13 ? 1 : 3;
 #endif
+        // (round 4: the order taken from the XCD, blockIdx.x & 7, instead of the workgroup -- same rows at the same time inside an L2, different
+        // rows in different XCDs -- measured: N = 4096 +-0, N = 8192 -3.7 % against mode 1; profiles/r04/x_ab_general_cohorts_and_xcd_rotation.txt)
         const int qrot = (kRot == 1 || kRot == 2) ? (int)(blockIdx.x % (unsigned)l) : 0;
         const int cfirst = kRot == 1 ? (int)((blockIdx.x / (unsigned)l) & 1u) : (kRot == 3 ? (int)(blockIdx.x & 1u) : 0);
 #pragma unroll 1
