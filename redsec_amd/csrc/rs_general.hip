@@ -189,7 +189,7 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
 #endif
 
   // (XCD cohorts, rs_cohort.h, were tried here in round 4 -- wave 0 posting the step count and waiting for its XCD's slowest workgroup -- and
-  // cost 7 % at N = 4096 and 3 % at N = 8192 whether switched on or off: the few registers of the cohort state spill 21-40 more dwords in
+  // cost 7 % at N = 4096 and 3 % at N = 8192 whether switched on or off: the few registers of the cohort state spill 10-20 more dwords per lane in
   // kernels that were full (profiles/r04/x_ab_general_cohorts_and_xcd_rotation.txt). The fabric traffic of these kernels sits at the 8-XCD
   // floor without them.)
   for (long ct = blockIdx.x; ct < a.B; ct += gridDim.x) {
