@@ -59,7 +59,10 @@ inline unsigned keyswitch_slices(long B, int W, int N) {
   if (B <= 0) return 1;
   const unsigned gx = (unsigned)((B + 255) / 256), gy = (unsigned)((W + 31) / 32);
   unsigned split = 1;
-  while (split < 64 && gx * gy * split < 1024 && N / (int)(2 * split) >= 4) split *= 2;
+#ifndef RS_KS_WANT_WGS
+#define RS_KS_WANT_WGS 1024   // workgroups a sliced launch aims for (A/B: 2048, 4096)
+#endif
+  while (split < 64 && gx * gy * split < RS_KS_WANT_WGS && N / (int)(2 * split) >= 4) split *= 2;
   return split;
 }
 inline size_t keyswitch_scratch_words_for(long B, int W, int N) {
