@@ -272,25 +272,11 @@ __global__ __launch_bounds__(FC_WORDS * FC_KL) void linear_fc_kernel(int32_t* __
   uint32_t acc = 0;
   uint32_t nzero = 0;
   if (w < W) {
-    // eight taps per trip: their weight bytes (wave-uniform: scalar loads) and input words are all requested before any is used --
-    // written tap by tap, every iteration waited for its own byte and then for its own word (49 serial round trips for the
-    // 196 -> 1,024 layer of sign1024x1: 0.10 ms for 70 M additions)
-    constexpr int UN = 8;
-    for (int k = k0 + kl; k < k1; k += UN * FC_KL) {
-      uint32_t v[UN], nz[UN], pos[UN];
-#pragma unroll
-      for (int j = 0; j < UN; ++j) {
-        const int kk = k + j * FC_KL;
-        const bool valid = kk < k1;
-        const size_t fi = (size_t)(valid ? kk : k) * M + m;
-        const bool z = zero && zero[fi];
-        nz[j] = valid && !z;
-        pos[j] = sign[fi];
-        nzero += (valid && z) ? 1u : 0u;
-        v[j] = (uint32_t)in[(size_t)(valid ? kk : k) * W + w];
-      }
-#pragma unroll
-      for (int j = 0; j < UN; ++j) acc += nz[j] ? (pos[j] ? v[j] : (0u - v[j])) : 0u;
+    for (int k = k0 + kl; k < k1; k += FC_KL) {
+      const size_t fi = (size_t)k * M + m;
+      if (zero && zero[fi]) { ++nzero; continue; }
+      const uint32_t v = (uint32_t)in[(size_t)k * W + w];
+      acc += sign[fi] ? v : (0u - v);
     }
   }
   s_acc[kl][wl] = acc;
