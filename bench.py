@@ -580,7 +580,7 @@ def main():
             # the CPU baseline is an N=1 figure (torch.distributed.run also pins OMP_NUM_THREADS=1);
             # multi-rank runs only keep a small in-run parity sample
             timed_baseline = world == 1
-            sample = args.cpu_sample if args.cpu_sample > 0 else (max(32, 2 * cores) if timed_baseline else 4)
+            sample = args.cpu_sample if args.cpu_sample > 0 else (max(256, 16 * cores) if timed_baseline else 4)   # exact product path: ~7 gates per second and core
             sample = min(sample, G)
             op = ol.params(args.params)
 
