@@ -45,6 +45,9 @@
 #ifndef RS_BS_PART
 #define RS_BS_PART 3
 #endif
+#ifndef RS_COHORT_LAG_ADJ
+#define RS_COHORT_LAG_ADJ 1   // steps taken off the XCD cohort lag because the check runs one step behind its post (0: same throughput on one box, REDsec-set split traffic 67.5 instead of 58.5 GB; profiles/r04/ag_*)
+#endif
 
 namespace rs {
 
@@ -2099,7 +2102,7 @@ template <class C>
 static hipError_t cohort_setup(BlindRotateArgs& w, long groups, long grid, const LaunchOpts& o, hipStream_t st) {
   if (!w.progress || o.no_cohort || grid > 8L * kCohortSlots || groups <= grid) { w.progress = nullptr; return hipSuccess; }
   const long step_bytes = 2L * C::L * 16384;
-  w.cohort_lag = (int32_t)std::max<long>(1, (4L << 20) / 3 / step_bytes);   // (one step tighter -- the check runs a step behind its post -- costs 5-7 %: profiles/r04/af_*)
+  w.cohort_lag = (int32_t)std::max<long>(1, (4L << 20) / 3 / step_bytes - RS_COHORT_LAG_ADJ);
   w.cohort_every = w.cohort_lag >= 4 ? 2 : 1;
   return hipMemsetAsync(w.progress, 0x7f, 8 * kCohortSlots * sizeof(int), st);
 }
@@ -2274,7 +2277,7 @@ hipError_t launch_blind_rotate_split_wg(int cfg, const BlindRotateArgs& a, int n
     // XCD cohorts (see cohort_step): only for launches whose workgroups walk several groups, i.e. sweep the key more than once.
     // A CMUX step reads 2 * 2l half-rows of 16 KB; the lag keeps a cohort inside about a third of its 4 MB L2.
     const long step_bytes = 4L * (cfg == 1 ? 10 : 3) * 16384;
-    w.cohort_lag = (int32_t)std::max<long>(1, (4L << 20) / 3 / step_bytes);   // (one step tighter -- the check runs a step behind its post -- costs 5-7 %: profiles/r04/af_*)
+    w.cohort_lag = (int32_t)std::max<long>(1, (4L << 20) / 3 / step_bytes - RS_COHORT_LAG_ADJ);
     w.cohort_every = w.cohort_lag >= 4 ? 2 : 1;
     if (hipError_t e = hipMemsetAsync(w.progress, 0x7f, 8 * kCohortSlots * sizeof(int), st); e != hipSuccess) return e;
   } else {
