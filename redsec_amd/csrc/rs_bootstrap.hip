@@ -590,6 +590,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
   __shared__ __attribute__((aligned(16))) double s_key[2][kRowDoubles];
   constexpr int kWin = 64;                       // mask words live in a 64-step window, as in the split kernel (leaves LDS for the tables of -DRS_WG_DIT)
   __shared__ uint16_t s_bara[WPB][kWin];
+  __shared__ int s_mail[kCohortSlots];   // XCD cohorts: the progress row requested a step ago (wave 0 only; rs_cohort.h)
   stage_tables(s_tw, a.tw, 64 * WPB, Xf::kWgTableDoubles);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
@@ -653,8 +654,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
     }
   };
 
-  long steps_done = 0;   // CMUX steps of the groups this workgroup has finished (XCD cohorts)
-  CohortState cohort;
+  int steps_done = 0;   // CMUX steps of the groups this workgroup has finished (XCD cohorts, rs_cohort.h)
   for (long group = blockIdx.x; group < n_groups; group += gridDim.x, steps_done += n) {
     const long ct = group * WPB + wave;
     const bool active = ct < a.B;
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
     for (int i = 0; i < n; ++i) {
       // XCD cohorts (cohort_step above): with l = 10 a step reads 320 KB of key per CU and an XCD's L2 keeps 12 steps; launches of the REDsec
       // set were seen at twice the 8-XCD floor of fabric traffic (60.8 GB, profiles/r04/pmc) when workgroups drifted further apart
-      if (a.progress && wave == 0) cohort_step(a, cohort, steps_done + i, i, lane);
+      if (wave == 0) cohort_step<BlindRotateArgs>(steps_done + i, s_mail);
       const int32_t bara = __builtin_amdgcn_readfirstlane((int)bara_next);
       if (((i + 1) & (kWin - 1)) == 0 && i + 1 < n) { wave_lds_sync(); fill_window(i + 1); wave_lds_sync(); }
       bara_next = (i + 1 < n) ? s_bara[wave][(i + 1) & (kWin - 1)] : 0;
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
     RS_STAMP(7);
   }
   RS_STAMP_FLUSH(wave);
-  if (a.progress && wave == 0) cohort_leave(a.progress, lane);
+  if (wave == 0) cohort_leave<BlindRotateArgs>();
   if (Xf::kCertificate) publish_certificate(dev, a.dev_flag, lane);
 }
 
@@ -901,6 +901,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
   __shared__ int32_t s_acc[WPB][2][kN];
   __shared__ __attribute__((aligned(16))) double s_key[3][kSlotDoubles];
   __shared__ uint16_t s_bara[WPB][kWin];
+  __shared__ int s_mail[kCohortSlots];   // XCD cohorts: the progress row requested a step ago (wave 0 only; rs_cohort.h)
   stage_tables(s_tw, a.tw, 64 * WPB, Xf::kTableDoubles);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
@@ -919,8 +920,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
   const long total_half = (long)n * KPL * 2;
   const unsigned lane_off = (unsigned)lane * 16u;
   auto sync_w = [] { wave_lds_sync(); };
-  long steps_done = 0;   // CMUX steps of the groups this workgroup has finished (XCD cohorts)
-  CohortState cohort;
+  int steps_done = 0;   // CMUX steps of the groups this workgroup has finished (XCD cohorts, rs_cohort.h)
 
   for (long group = blockIdx.x; group < n_groups; group += gridDim.x, steps_done += n) {
     const long ct = group * WPB + wave;
@@ -997,7 +997,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
 
     for (int i = 0; i < n; ++i) {
       if ((i & (kWin - 1)) == 0 && i > 0) { wave_lds_sync(); fill_window(i); }
-      if (a.progress && wave == 0) cohort_step(a, cohort, steps_done + i, i, lane);
+      if (wave == 0) cohort_step<BlindRotateArgs>(steps_done + i, s_mail);
       wave_lds_sync();
       const int32_t bara = __builtin_amdgcn_readfirstlane((int)s_bara[wave][i & (kWin - 1)]);
       const bool work = bara != 0;   // tfhe_blindRotate_FFT skips the identity CMUX (the barriers still run)
@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
       if (lane == 0) out[kN] = acc1[0];
     }
   }
-  if (a.progress && wave == 0) cohort_leave(a.progress, lane);
+  if (wave == 0) cohort_leave<BlindRotateArgs>();
 }
 
 // -------------------------------------------------------------------------------------------------
