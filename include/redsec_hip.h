@@ -180,6 +180,11 @@ int rs_keyswitch_dev(rs_ctx* ctx, int32_t* out, const int32_t* u, size_t B, void
 /* Debug/parity tap: negacyclic product of a small-coefficient polynomial with a torus polynomial
  * through exactly the device transform path used by the external product (HOST pointers). */
 int rs_debug_polymul(rs_ctx* ctx, int32_t* out, const int32_t* a_small, const int32_t* b_torus, size_t count);
+/* Debug tap of the XCD cohort protocol of the lock-step kernels (no reference counterpart: the reference has no batch kernel):
+ * copies the progress table of `stream`'s last cohort launch to out[8 * 64] (HOST) after synchronising the stream. Entry
+ * [xcd * 64 + slot] of workgroup (blockIdx & 7, blockIdx >> 3) reads 0x40000000 + the CMUX steps that workgroup walked once it
+ * has left; entries no workgroup owned read 0x7f7f7f7f. RS_ERR_STATE before the first such launch. */
+int rs_debug_cohort_table(rs_ctx* ctx, void* stream, int32_t* out);
 
 /* ---- linear stage on LWE words (no bootstrap), DEVICE pointers ---------------------------------
  * out[m] = bias_b[m % bias_depth] (on the b word, optional) + zero_tap_b * (#zero taps of m)

@@ -1093,6 +1093,17 @@ int rs_last_launch(rs_ctx* c, void* stream, int32_t* form, int32_t* waves_per_bl
   return RS_OK;
 }
 
+int rs_debug_cohort_table(rs_ctx* c, void* stream, int32_t* out) {
+  if (!c || !out) return fail(RS_ERR_INVALID, "null argument");
+  Lane* ln = nullptr;
+  int rc = lane_of(c, (hipStream_t)stream, &ln);
+  if (rc) return rc;
+  if (!ln->d_progress) return fail(RS_ERR_STATE, "no lock-step launch with XCD cohorts on this stream yet");
+  RS_HIP(hipStreamSynchronize(ln->stream));
+  RS_HIP(hipMemcpy(out, ln->d_progress, 8 * rs::kCohortSlots * sizeof(int), hipMemcpyDeviceToHost));
+  return RS_OK;
+}
+
 int rs_info(rs_ctx* c, int64_t* bk_bytes, int64_t* ksk_bytes, int32_t* wpb, int32_t* cus) {
   if (!c) return fail(RS_ERR_INVALID, "null context");
   if (bk_bytes) *bk_bytes = (int64_t)c->bk_bytes;

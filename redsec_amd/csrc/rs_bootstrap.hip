@@ -842,7 +842,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
     RS_STAMP(7);
   }
   RS_STAMP_FLUSH(wave);
-  if (wave == 0) cohort_leave<BlindRotateArgs>();
+  if (wave == 0) cohort_leave<BlindRotateArgs>(steps_done);
   if (Xf::kCertificate) publish_certificate(dev, a.dev_flag, lane);
 }
 
@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
       if (lane == 0) out[kN] = acc1[0];
     }
   }
-  if (wave == 0) cohort_leave<BlindRotateArgs>();
+  if (wave == 0) cohort_leave<BlindRotateArgs>(steps_done);
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -101,9 +101,12 @@ __device__ __forceinline__ void cohort_step(int g, int* mail) {
         [o_lag] "n"(__builtin_offsetof(Args, cohort_lag)), [polls] "n"(kCohortPolls)
       : "memory", "vcc", "scc");
 }
-// a finished workgroup holds nobody back (wave 0, EXEC full)
+// a finished workgroup holds nobody back: its entry becomes kCohortGone + the CMUX steps it walked (beyond every step count a
+// launch can reach; the sum is also what rs_debug_cohort_table lets a test read back: which entries a launch wrote, and with
+// what). Wave 0, EXEC full.
+constexpr int kCohortGone = 0x40000000;
 template <class Args>
-__device__ __forceinline__ void cohort_leave() {
+__device__ __forceinline__ void cohort_leave(int steps) {
   const unsigned long long ka = (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
   unsigned long long row, ex;
   unsigned tmp, xoff, t0, t2;
@@ -115,7 +118,7 @@ __device__ __forceinline__ void cohort_leave() {
       "s_lshl_b32 %[tmp], %[tmp], 2\n\t"
       "s_add_u32 %[tmp], %[tmp], %[xoff]\n\t"
       "v_mov_b32 %[t0], %[tmp]\n\t"
-      "v_mov_b32 %[t2], 0x7f7f7f7f\n\t"
+      "v_mov_b32 %[t2], %[gone]\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
       "s_cmp_eq_u64 %[row], 0\n\t"
       "s_cbranch_scc1 .Lcoh_left_%=\n\t"
@@ -125,7 +128,7 @@ __device__ __forceinline__ void cohort_leave() {
       "s_mov_b64 exec, %[ex]\n"
       ".Lcoh_left_%=:"
       : [row] "=&s"(row), [ex] "=&s"(ex), [tmp] "=&s"(tmp), [xoff] "=&s"(xoff), [t0] "=&v"(t0), [t2] "=&v"(t2)
-      : [ka] "s"(ka), [bid] "s"((unsigned)blockIdx.x), [o_prog] "n"(__builtin_offsetof(Args, progress))
+      : [ka] "s"(ka), [bid] "s"((unsigned)blockIdx.x), [gone] "s"(kCohortGone | steps), [o_prog] "n"(__builtin_offsetof(Args, progress))
       : "memory", "scc");
 }
 

@@ -124,3 +124,37 @@ def test_kernel_form_is_reported_per_launch(toy_redsec):
     assert seen[8 * cus]["form"] == "workgroup" and seen[8 * cus]["resident"] == 8 * cus and seen[8 * cus]["waves_per_block"] == 8
     assert be.info()["waves_per_block"] == 8
     be.close()
+
+
+@pytest.mark.parametrize("mode", ["fft", "split"])
+@pytest.mark.parametrize("fix,name", [("toy_default", "default128"), ("toy_redsec", "redsec_small_v2")])
+def test_xcd_cohort_table_after_a_lock_step_launch(fix, name, mode, request, monkeypatch):
+    """The XCD cohort step of the lock-step kernels is one asm block (rs_cohort.h) that computes the table addresses itself:
+    after a launch every workgroup must have left kCohortGone + the CMUX steps it walked in ITS entry (xcd = blockIdx & 7,
+    slot = blockIdx >> 3) and no other entry may have been touched; the words must equal those of a context that runs without
+    cohorts (RS_NO_COHORT) and, on a sample, the oracle's."""
+    import torch
+    ks, ctx = request.getfixturevalue(fix)
+    be = _backend(ks, name)
+    be.set_mode(mode)
+    cus, n = be.info()["num_cus"], ks.p.n
+    B = 16 * cus + 40   # FFT mode: the 40 are cut off into a form of their own; split mode: five workgroups walk a third group
+    _, ct = _bits(ks, B, 77)
+    mu = ol.to_torus(1, 8)
+    got = be.bootstrap(_dev(ct), mu)
+    assert be.last_launch()["form"] == ("workgroup" if mode == "fft" else "split_workgroup")
+    table = be.cohort_table()
+    expected = np.full((8, 64), 0x7F7F7F7F, np.int32)
+    groups = 2 * cus if mode == "fft" else 2 * cus + 5
+    for b in range(cus):
+        expected[b & 7, b >> 3] = 0x40000000 + n * len(range(b, groups, cus))
+    assert np.array_equal(table, expected)
+    monkeypatch.setenv("RS_NO_COHORT", "1")
+    be2 = _backend(ks, name)
+    monkeypatch.delenv("RS_NO_COHORT")
+    be2.set_mode(mode)
+    assert torch.equal(be2.bootstrap(_dev(ct), mu), got)
+    sample = np.r_[0:4, 8 * cus - 2:8 * cus + 2, B - 4:B]
+    assert np.array_equal(got.cpu().numpy()[sample], ctx.bootstrap_batch(ct[sample], mu))
+    be2.close()
+    be.close()
