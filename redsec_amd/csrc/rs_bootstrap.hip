@@ -1845,10 +1845,13 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateAr
 // Cooperative blind rotation, EIGHT waves per ciphertext (latency form for B <= #CUs, FFT mode; round 4).
 // The four-wave form above runs one wave per SIMD: a lone wave issues its FP64 and LDS instructions one behind
 // the other (78 % of a two-wave SIMD's rate per wave-slot), and its critical path per CMUX step is
-// R = 2l/4 forward transforms plus one inverse. Here the 2l digit rows of a step go to 8 waves -- waves 0-3 the
-// rows of accumulator component 0, waves 4-7 those of component 1, split so that every SIMD (waves s and s + 4)
-// carries the same number of rows (l = 10: 3+2, 3+2, 2+3, 2+3; l = 3: 1+0, 1+1, 1+1, 0+1) -- and the two inverse
-// transforms to the two waves with the fewest rows, on different SIMDs (kInvA = 3: column 0, kInvB = 4: column 1).
+// R = 2l/4 forward transforms plus one inverse. Here the 2l digit rows of a step go to 8 waves -- the components
+// alternate (wave & 1), and of the four waves of a component the OLDER ones (waves 0-3, which win the issue
+// arbitration against their SIMD partners 4-7) take the extra rows, so that every SIMD (waves s and s + 4) carries
+// the same number of rows and finishes them together (l = 10: 3+2 on every SIMD; l = 3: 1+1, 1+1, 1+0, 1+0;
+// rs_lds_plan.h; round-4 phase stamps: with the extra rows on younger waves two SIMDs finished 1,100 cycles late,
+// 196 ciphertexts 2.53 -> 2.43 ms) -- and the two inverse transforms to two waves with the fewest rows, on
+// different SIMDs (kInvA = 6: column 0, kInvB = 7: column 1).
 // Partial column sums meet in LDS in ONE exchange: 14 partials of 8 KB need homes, and every wave's transform
 // buffer is idle by then, so wave w leaves its column-0 partial in its own exchange buffer and its column-1
 // partial in slot w of s_part -- except that kInvA keeps column 0 and kInvB column 1 in registers, and kInvB's
@@ -1860,6 +1863,15 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateAr
 #ifndef RS_COOP8_ATOMICS
 #define RS_COOP8_ATOMICS 1   // the partial column sums meet by LDS f64 atomics (0: one store + 7 x 16 reads per inverse wave; 196 sign bootstraps
                              // 2.92 -> 2.64 ms on one box, profiles/r04/i_ab_coop8_atomics.txt)
+#endif
+#if defined(RS_STAMPS) && defined(RS_STAMPS_COOP8)   // diagnostic build: the phase stamps of the lock-step kernel, in this kernel
+#define RS_C8_STAMP_DECL RS_STAMP_DECL
+#define RS_C8_STAMP(k) RS_STAMP(k)
+#define RS_C8_STAMP_FLUSH(wave) RS_STAMP_FLUSH(wave)
+#else
+#define RS_C8_STAMP_DECL ((void)0)
+#define RS_C8_STAMP(k) ((void)0)
+#define RS_C8_STAMP_FLUSH(wave) ((void)0)
 #endif
 #ifndef RS_COOP8_KEEP_TW
 #define RS_COOP8_KEEP_TW 0   // 1: per-lane twiddles in registers (FftTwKept<3>) instead of LDS table reads
@@ -1901,6 +1913,8 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
   // rows [first, first + cnt) of this wave's component (digit index q = first + rr, TGSW row comp * L + q)
   const int comp = coop8_comp(wave), cnt = coop8_row_count(L, wave), first = coop8_row_first(L, wave);
   double dev = 0.0;
+  RS_C8_STAMP_DECL;   // -DRS_STAMPS -DRS_STAMPS_COOP8 (tools/stamp_profile.py coop8): 0 mask word, 1 rotated difference, 2 rows (forward +
+                      // multiply-accumulate), 3 atomics issued, 4 barrier 1, 5 inverse + accumulator update, 6 barrier 2, 7 prologue / extract
   auto word = [&](int i) -> int32_t {
     uint32_t v = (uint32_t)a.c0 * (uint32_t)row0[i];
     if (row1) v += (uint32_t)a.c1 * (uint32_t)row1[i];
@@ -1917,8 +1931,11 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
   }
   __syncthreads();
   constexpr uint32_t offset = gadget_offset<C>();
+  RS_C8_STAMP(7);
   for (int i = 0; i < n; ++i) {
+    // (requesting the mask word of step i + 1 here, a step ahead, was measured: 2.43 -> 2.47 ms for 196 ciphertexts; the load hits the L1)
     const int32_t bara = __builtin_amdgcn_readfirstlane(modswitch_2N(word(i)));
+    RS_C8_STAMP(0);
     if (bara == 0) continue;   // uniform over the workgroup
     double s0[kRegs], s1[kRegs];
 #pragma unroll
@@ -1932,6 +1949,7 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
       int32_t d[kRegs];
 #pragma unroll
       for (int r = 0; r < kRegs; ++r) d[r] = gadget_prepare<C>(rotated_diff(s_acc[comp], lane + 64 * r, bara));
+      RS_C8_STAMP(1);
 #pragma unroll 1
       for (int rr = 0; rr < cnt; ++rr) {
         const int q = first + (int)((rr + blockIdx.x) % (unsigned)cnt);   // per-workgroup row order, as in the four-wave form
@@ -1944,6 +1962,7 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
         Xf::fwd_digits(lane, x, d, q, offset, tw, buf, f);
         Xf::mac8(s0, s1, x, w0, w1, f);
       }
+      RS_C8_STAMP(2);
     }
 #if RS_COOP8_ATOMICS
     // every wave adds its two partial sums into the column sums with ds_add_f64 (no return value: 32 instructions that overlap
@@ -1953,7 +1972,9 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
 #pragma unroll
       for (int u = 0; u < kRegs; ++u) { unsafeAtomicAdd(&s_sum[0][u * 64 + lane], s0[u]); unsafeAtomicAdd(&s_sum[1][u * 64 + lane], s1[u]); }
     }
+    RS_C8_STAMP(3);
     __syncthreads();   // sums complete; every wave has finished reading the accumulator
+    RS_C8_STAMP(4);
     if (wave == kInvA || wave == kInvB) {
       double* sum = s_sum[wave == kInvA ? 0 : 1];
       double x[kRegs];
@@ -1969,7 +1990,9 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
         acc[j] = (int32_t)((uint32_t)acc[j] + (uint32_t)Xf::to_torus(x[r], dev));
       }
     }
+    RS_C8_STAMP(5);
     __syncthreads();   // accumulator updated, sums zero
+    RS_C8_STAMP(6);
     continue;
 #else
     // partial sums: column 0 into the wave's own (now idle) exchange buffer, column 1 into its s_part slot; position
@@ -2030,6 +2053,8 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
     }
     if (lane == 0) out[kN] = s_acc[1][0];
   }
+  RS_C8_STAMP(7);
+  RS_C8_STAMP_FLUSH(wave);
   if (wave == kInvA || wave == kInvB) publish_certificate(dev, a.dev_flag, lane);
 }
 

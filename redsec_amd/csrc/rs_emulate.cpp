@@ -1014,7 +1014,8 @@ long rs_emu_lds_protocol_conflicts(int form, int broken) {
   }
   return -1;
 }
-// coop8: every digit row of both components belongs to exactly one wave, and the two waves of a SIMD (s, s + 4) carry equal totals
+// coop8: every digit row of both components belongs to exactly one wave; the SIMDs (waves s and s + 4) carry totals within one
+// row of each other; on no SIMD does the younger wave (s + 4) carry more rows than the older one (rs_lds_plan.h: it would finish last)
 long rs_emu_coop8_row_split_violations(int L) {
   long bad = 0;
   std::vector<int> owner(2 * L, 0);
@@ -1025,9 +1026,15 @@ long rs_emu_coop8_row_split_violations(int L) {
       ++owner[rs::coop8_comp(w) * L + q];
     }
   for (int v : owner) bad += v != 1;
-  const int per_simd = rs::coop8_row_count(L, 0) + rs::coop8_row_count(L, 4);
-  for (int s = 0; s < 4; ++s) bad += std::abs(rs::coop8_row_count(L, s) + rs::coop8_row_count(L, s + 4) - per_simd) > (2 * L % 4 ? 1 : 0);
+  int lo = 1 << 30, hi = 0;
+  for (int s = 0; s < 4; ++s) {
+    const int older = rs::coop8_row_count(L, s), younger = rs::coop8_row_count(L, s + 4);
+    bad += younger > older;
+    lo = std::min(lo, older + younger); hi = std::max(hi, older + younger);
+  }
+  bad += hi - lo > 1;
   bad += (rs::kCoop8InvA & 3) == (rs::kCoop8InvB & 3);      // the two inverse transforms on different SIMDs
+  for (int w = 0; w < rs::kCoop8Waves; ++w) bad += rs::coop8_row_count(L, w) < rs::coop8_row_count(L, rs::kCoop8InvA) || rs::coop8_row_count(L, w) < rs::coop8_row_count(L, rs::kCoop8InvB);
   return bad;
 }
 

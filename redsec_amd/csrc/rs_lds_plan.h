@@ -14,18 +14,20 @@
 namespace rs {
 
 // ---- blind_rotate_coop8_kernel: 8 waves, one ciphertext ------------------------------------------------------------------
+// Wave w runs on SIMD w & 3, and of the two waves of a SIMD (s and s + 4) the OLDER one (s) wins the issue arbitration: in the
+// phase stamps of round 4 (profiles/r04/am_coop8_phase_stamps.json) the older wave ran its rows at 2,900 cycles each whatever
+// its partner did, the younger one at 3,600-4,600 while they overlapped. So the extra rows go to the older waves: every SIMD
+// then finishes its five rows (l = 10) together, instead of two SIMDs waiting for a younger wave that had three.
+// Components alternate (wave & 1), j = wave >> 1 is the wave's place among the four of its component: j = 0, 1 are the older
+// waves of SIMDs 0/1 and 2/3, j = 2, 3 the younger ones.
 constexpr int kCoop8Waves = 8;
-constexpr int kCoop8InvA = 3;   // inverts column 0 (fewest rows of component 0)
-constexpr int kCoop8InvB = 4;   // inverts column 1 (fewest rows of component 1); another SIMD than kCoop8InvA
-RS_HD constexpr int coop8_comp(int wave) { return wave >> 2; }
-// the l digit rows of a component over its four waves: comp 0 gives the extra rows to its FIRST waves, comp 1 to its LAST,
-// so that the two waves of a SIMD (s and s + 4) carry the same total
-RS_HD constexpr int coop8_row_count(int L, int wave) {
-  return L / 4 + (coop8_comp(wave) == 0 ? ((wave & 3) < L % 4 ? 1 : 0) : ((wave & 3) >= 4 - L % 4 ? 1 : 0));
-}
+constexpr int kCoop8InvA = 6;   // inverts column 0 (a wave with the fewest rows)
+constexpr int kCoop8InvB = 7;   // inverts column 1 (likewise; another SIMD than kCoop8InvA)
+RS_HD constexpr int coop8_comp(int wave) { return wave & 1; }
+RS_HD constexpr int coop8_row_count(int L, int wave) { return L / 4 + ((wave >> 1) < L % 4 ? 1 : 0); }
 RS_HD constexpr int coop8_row_first(int L, int wave) {
-  const int j = wave & 3, rem = L % 4;
-  return j * (L / 4) + (coop8_comp(wave) == 0 ? (j < rem ? j : rem) : (j > 4 - rem ? j - (4 - rem) : 0));
+  const int j = wave >> 1, rem = L % 4;
+  return j * (L / 4) + (j < rem ? j : rem);
 }
 // where wave `wave` leaves its partial of column `col` for the wave that inverts that column
 enum { kHomeRegisters = 0, kHomeOwnBuffer = 1, kHomePartSlot = 2 };

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Where the eight waves of blind_rotate_coop8_kernel spend a CMUX step (196 REDsec-set sign bootstraps = MNIST layer 0).
+
+  tools/build_variant.sh stamps8 . -DRS_STAMPS -DRS_STAMPS_COOP8
+  REDSEC_HIP_LIB=$PWD/variants/lib_stamps8.so python tools/stamp_coop8.py [B]
+
+Diagnostic build only (every stamp drains the wave's LDS reads): read the SHARES and the per-wave differences.
+Cycles are s_memtime ticks (100 MHz constant clock on this chip: 10 ns each), per wave, summed over the steps of the launch."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import redsec_amd  # noqa: E402
+from redsec_amd import client  # noqa: E402
+
+PHASES = ["mask word", "rotated difference", "rows: forward + mac", "atomics issued", "barrier 1", "inverse + update", "barrier 2", "prologue / extract"]
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 196
+    lib = redsec_amd.load_library()
+    if not hasattr(lib, "rs_debug_read_stamps"):
+        raise SystemExit("not a -DRS_STAMPS build: set REDSEC_HIP_LIB to variants/lib_stamps8.so")
+    sk = client.SecretKeySet("redsec_small_v2", seed=7)
+    be = redsec_amd.Backend(redsec_amd.params("redsec_small_v2"), device=0)
+    be.load_keys(sk.bk, sk.ksk)
+    x = torch.randint(-2**31, 2**31 - 1, (B, be.W), dtype=torch.int64).to(torch.int32).cuda()
+    n_words = 256 * 8 * len(PHASES)
+    host = (C.c_ulonglong * n_words)()
+    mu = 1 << 20
+    be.set_timing(True)
+    for _ in range(2):
+        be.bootstrap(x, mu)
+        torch.cuda.synchronize()
+        assert lib.rs_debug_read_stamps(host, C.c_size_t(n_words)) == 0
+    ms = be.last_kernel_ms()
+    a = np.frombuffer(host, dtype=np.uint64).reshape(256, 8, len(PHASES)).astype(np.float64)[:B]
+    n = be.p.n
+    res = {"B": B, "form": be.last_launch(), "blind_rotate_ms_stamped_build": ms[0], "ticks_per_step_per_wave": {}}
+    for w in range(8):
+        res["ticks_per_step_per_wave"]["wave %d" % w] = {ph: round(float(a[:, w, k].mean() / n), 1) for k, ph in enumerate(PHASES)}
+        res["ticks_per_step_per_wave"]["wave %d" % w]["total"] = round(float(a[:, w, :].sum(axis=1).mean() / n), 1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
