@@ -575,6 +575,24 @@ __device__ unsigned long long g_rs_stamps[256 * 8 * kStampPhases];
 #define RS_STAMP(k) ((void)0)
 #define RS_STAMP_FLUSH(wave) ((void)0)
 #endif
+#if defined(RS_STAMPS) && defined(RS_STAMPS_DUO)   // diagnostic build: the phase stamps, in blind_rotate_duo_kernel
+#define RS_DUO_STAMP_DECL RS_STAMP_DECL
+#define RS_DUO_STAMP(k) RS_STAMP(k)
+#define RS_DUO_STAMP_FLUSH(wave) RS_STAMP_FLUSH(wave)
+#else
+#define RS_DUO_STAMP_DECL ((void)0)
+#define RS_DUO_STAMP(k) ((void)0)
+#define RS_DUO_STAMP_FLUSH(wave) ((void)0)
+#endif
+#if defined(RS_STAMPS) && defined(RS_STAMPS_COOP8)   // diagnostic build: the phase stamps of the lock-step kernel, in this kernel
+#define RS_C8_STAMP_DECL RS_STAMP_DECL
+#define RS_C8_STAMP(k) RS_STAMP(k)
+#define RS_C8_STAMP_FLUSH(wave) RS_STAMP_FLUSH(wave)
+#else
+#define RS_C8_STAMP_DECL ((void)0)
+#define RS_C8_STAMP(k) ((void)0)
+#define RS_C8_STAMP_FLUSH(wave) ((void)0)
+#endif
 
 template <class Xf, int WPB>
 __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateArgs a) {
@@ -1522,6 +1540,8 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
   constexpr uint32_t offset = gadget_offset<C>();
   double dev = 0.0;
   const long n_groups = (a.B + kCts - 1) / kCts;
+  RS_DUO_STAMP_DECL;   // -DRS_STAMPS -DRS_STAMPS_DUO (tools/stamp_coop8.py duo): 0 step prologue + rotated difference, 1 digits + forward pair,
+                       // 2 key wait + barrier 1, 3 multiply-accumulate, 4 barrier 2 + next quad, 5 partial exchange (2 barriers), 6 inverse + update, 7 group prologue / extract
 
   const unsigned lane_off = (unsigned)lane * 16u;
   // Workgroup b walks the row pairs of a step in the order rotated by b (they are independent), so that the workgroups of a launch
@@ -1574,6 +1594,7 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
     }
     __syncthreads();   // bara complete; previous group's last reads of the quad buffer are over
     issue_quad(0, prot(0));
+    RS_DUO_STAMP(7);
 
     unsigned bara_next = active ? s_bara[c][0] : 0;   // read one step ahead
     for (int i = 0; i < n; ++i) {
@@ -1588,6 +1609,7 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
 #pragma unroll
         for (int r = 0; r < kRegs; ++r) d[r] = gadget_prepare<C>(rotated_diff(acc, lane + 64 * r, bara));
       }
+      RS_DUO_STAMP(0);
 #pragma unroll 1
       for (int p = 0; p < C::L / 2; ++p) {
         double xa[kRegs], xb[kRegs];
@@ -1596,8 +1618,10 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
           Xf::digits(xb, d, 2 * prot(p) + 1);
           Xf::fwd_pair_wg(lane, xa, xb, tw_kept, buf, FftNoSeg());
         }
+        RS_DUO_STAMP(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                         // quad (i, p) published
+        RS_DUO_STAMP(2);
         if (work) {
 #ifdef RS_NO_MAC_STREAM
           mac_row(s0, s1, xa, 2 * h);
@@ -1606,8 +1630,10 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
           mac_pair_stream(s0, s1, xa, xb, s_key[2 * h], s_key[2 * h + 1], lane);
 #endif
         }
+        RS_DUO_STAMP(3);
         __syncthreads();                         // every wave has finished reading it
         if (p + 1 < C::L / 2) issue_quad(i, prot(p + 1));
+        RS_DUO_STAMP(4);
       }
       // partial exchange through the idle quad buffer: wave (c, h) hands over its partial of column 1 - h
       double* xchg = &s_key[0][0] + duo_xchg_doubles(wave);
@@ -1624,6 +1650,7 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
       }
       __syncthreads();                           // partials consumed: the quad buffer may be refilled
       if (i + 1 < n) issue_quad(i + 1, prot(0));
+      RS_DUO_STAMP(5);
       if (work) {
         uint32_t a0[kRegs];   // accumulator words read ahead of the inverse transform (see the workgroup kernel)
 #pragma unroll
@@ -1634,6 +1661,7 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
         for (int r = 0; r < kRegs; ++r) acc[lane + 64 * r] = (int32_t)(a0[r] + (uint32_t)Xf::to_torus(mine[r], dev));
         wave_lds_sync();
       }
+      RS_DUO_STAMP(6);
     }
 
     if (active) {
@@ -1650,6 +1678,8 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
       }
     }
   }
+  RS_DUO_STAMP(7);
+  RS_DUO_STAMP_FLUSH(wave);
   if (Xf::kCertificate) publish_certificate(dev, a.dev_flag, lane);
 }
 
@@ -1863,15 +1893,6 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateAr
 #ifndef RS_COOP8_ATOMICS
 #define RS_COOP8_ATOMICS 1   // the partial column sums meet by LDS f64 atomics (0: one store + 7 x 16 reads per inverse wave; 196 sign bootstraps
                              // 2.92 -> 2.64 ms on one box, profiles/r04/i_ab_coop8_atomics.txt)
-#endif
-#if defined(RS_STAMPS) && defined(RS_STAMPS_COOP8)   // diagnostic build: the phase stamps of the lock-step kernel, in this kernel
-#define RS_C8_STAMP_DECL RS_STAMP_DECL
-#define RS_C8_STAMP(k) RS_STAMP(k)
-#define RS_C8_STAMP_FLUSH(wave) RS_STAMP_FLUSH(wave)
-#else
-#define RS_C8_STAMP_DECL ((void)0)
-#define RS_C8_STAMP(k) ((void)0)
-#define RS_C8_STAMP_FLUSH(wave) ((void)0)
 #endif
 #ifndef RS_COOP8_KEEP_TW
 #define RS_COOP8_KEEP_TW 0   // 1: per-lane twiddles in registers (FftTwKept<3>) instead of LDS table reads

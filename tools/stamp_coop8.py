@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Where the eight waves of blind_rotate_coop8_kernel spend a CMUX step (196 REDsec-set sign bootstraps = MNIST layer 0).
+"""Where the eight waves of a latency-form workgroup spend a CMUX step (REDsec set, MNIST layer sizes).
 
-  tools/build_variant.sh stamps8 . -DRS_STAMPS -DRS_STAMPS_COOP8
+  tools/build_variant.sh stamps8 . -DRS_STAMPS -DRS_STAMPS_COOP8     blind_rotate_coop8_kernel, B = 196 (one ciphertext per workgroup)
+  tools/build_variant.sh stampsduo . -DRS_STAMPS -DRS_STAMPS_DUO     blind_rotate_duo_kernel, B = 1024 (four ciphertexts x two waves)
   REDSEC_HIP_LIB=$PWD/variants/lib_stamps8.so python tools/stamp_coop8.py [B]
 
 Diagnostic build only (every stamp drains the wave's LDS reads): read the SHARES and the per-wave differences.
@@ -19,7 +20,9 @@ sys.path.insert(0, ROOT)
 import redsec_amd  # noqa: E402
 from redsec_amd import client  # noqa: E402
 
-PHASES = ["mask word", "rotated difference", "rows: forward + mac", "atomics issued", "barrier 1", "inverse + update", "barrier 2", "prologue / extract"]
+PHASES_COOP8 = ["mask word", "rotated difference", "rows: forward + mac", "atomics issued", "barrier 1", "inverse + update", "barrier 2", "prologue / extract"]
+PHASES_DUO = ["prologue + rotated difference", "digits + forward pair", "key wait + barrier 1", "multiply-accumulate", "barrier 2 + next quad",
+              "partial exchange (2 barriers)", "inverse + update", "group prologue / extract"]
 
 
 def main():
@@ -31,7 +34,7 @@ def main():
     be = redsec_amd.Backend(redsec_amd.params("redsec_small_v2"), device=0)
     be.load_keys(sk.bk, sk.ksk)
     x = torch.randint(-2**31, 2**31 - 1, (B, be.W), dtype=torch.int64).to(torch.int32).cuda()
-    n_words = 256 * 8 * len(PHASES)
+    n_words = 256 * 8 * 8
     host = (C.c_ulonglong * n_words)()
     mu = 1 << 20
     be.set_timing(True)
@@ -40,9 +43,12 @@ def main():
         torch.cuda.synchronize()
         assert lib.rs_debug_read_stamps(host, C.c_size_t(n_words)) == 0
     ms = be.last_kernel_ms()
-    a = np.frombuffer(host, dtype=np.uint64).reshape(256, 8, len(PHASES)).astype(np.float64)[:B]
+    form = be.last_launch()
+    PHASES = PHASES_DUO if form["form"] == "duo" else PHASES_COOP8
+    blocks = min(256, -(-B // 4)) if form["form"] == "duo" else B
+    a = np.frombuffer(host, dtype=np.uint64).reshape(256, 8, 8).astype(np.float64)[:blocks]
     n = be.p.n
-    res = {"B": B, "form": be.last_launch(), "blind_rotate_ms_stamped_build": ms[0], "ticks_per_step_per_wave": {}}
+    res = {"B": B, "form": form, "blind_rotate_ms_stamped_build": ms[0], "ticks_per_step_per_wave": {}}
     for w in range(8):
         res["ticks_per_step_per_wave"]["wave %d" % w] = {ph: round(float(a[:, w, k].mean() / n), 1) for k, ph in enumerate(PHASES)}
         res["ticks_per_step_per_wave"]["wave %d" % w]["total"] = round(float(a[:, w, :].sum(axis=1).mean() / n), 1)
