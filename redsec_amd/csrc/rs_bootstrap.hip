@@ -1560,6 +1560,8 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
     glds_chunks<4>(src, lane_off, dst);
     glds_chunks<4>(src + 4 * 128, lane_off, dst + 4 * 128);
   };
+  // (The eight 1 KB requests of a wave's share of the next quad spread over the six segments of the next forward pair instead of one burst
+  // behind the barrier: 7.96 -> 9.97 ms at 1,024 ciphertexts, profiles/r04/aq_*: the rows arrive late and the asm statements cut the pair's schedule.)
   auto mac_row = [&](double (&s0)[kRegs], double (&s1)[kRegs], const double (&x)[kRegs], int slot) {
     const double2* k0 = reinterpret_cast<const double2*>(s_key[slot]);
     const double2* k1 = k0 + kN / 2;
