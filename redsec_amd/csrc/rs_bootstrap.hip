@@ -556,7 +556,12 @@ __device__ __forceinline__ void mac_pair_stream(double (&s0)[kRegs], double (&s1
   }
 }
 
-#if defined(RS_STAMPS) && (RS_BS_PART & 1)   // the stamped kernel lives in part 1: one definition of the symbol per library
+#ifdef RS_STAMPS_WGS   // diagnostic builds: which half of the file owns the stamp array (one definition of the symbol per library)
+#define RS_STAMP_PART 2   // blind_rotate_wgs_kernel is launched from part 2
+#else
+#define RS_STAMP_PART 1   // the lock-step, duo and coop8 kernels from part 1
+#endif
+#if defined(RS_STAMPS) && (RS_BS_PART & RS_STAMP_PART)
 // Diagnostic build only (cdna_hip_programming.md section 7, in-kernel stamps): phase sums per wave, read back by
 // rs_debug_read_stamps. Phases: 0 step prologue, 1 digits + forward pair, 2 wait for the key rows + barrier, 3 multiply-
 // accumulate, 4 barrier + next rows requested, 5 accumulator pre-read + inverse pair, 6 rounding + accumulator update,
@@ -574,6 +579,15 @@ __device__ unsigned long long g_rs_stamps[256 * 8 * kStampPhases];
 #define RS_STAMP_DECL ((void)0)
 #define RS_STAMP(k) ((void)0)
 #define RS_STAMP_FLUSH(wave) ((void)0)
+#endif
+#if defined(RS_STAMPS) && defined(RS_STAMPS_WGS) && (RS_BS_PART & 2)   // diagnostic build: the phase stamps, in blind_rotate_wgs_kernel
+#define RS_WGS_STAMP_DECL RS_STAMP_DECL
+#define RS_WGS_STAMP(k) RS_STAMP(k)
+#define RS_WGS_STAMP_FLUSH(wave) RS_STAMP_FLUSH(wave)
+#else
+#define RS_WGS_STAMP_DECL ((void)0)
+#define RS_WGS_STAMP(k) ((void)0)
+#define RS_WGS_STAMP_FLUSH(wave) ((void)0)
 #endif
 #if defined(RS_STAMPS) && defined(RS_STAMPS_DUO)   // diagnostic build: the phase stamps, in blind_rotate_duo_kernel
 #define RS_DUO_STAMP_DECL RS_STAMP_DECL
@@ -938,6 +952,9 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
   const long total_half = (long)n * KPL * 2;
   const unsigned lane_off = (unsigned)lane * 16u;
   auto sync_w = [] { wave_lds_sync(); };
+  RS_WGS_STAMP_DECL;   // -DRS_STAMPS -DRS_STAMPS_WGS (tools/stamp_profile.py --split): 0 step prologue + rotated differences, 1 digits + forward transform,
+                       // 2 key wait + barrier (low half), 3 multiply-accumulate low, 4 key wait + barrier (high half), 5 multiply-accumulate high,
+                       // 6 two inverse pairs + update, 7 group prologue / extract
   int steps_done = 0;   // CMUX steps of the groups this workgroup has finished (XCD cohorts, rs_cohort.h)
 
   for (long group = blockIdx.x; group < n_groups; group += gridDim.x, steps_done += n) {
@@ -1013,6 +1030,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
     };
     auto consumed = [&]() { ++h; slot = slot == 2 ? 0 : slot + 1; };
 
+    RS_WGS_STAMP(7);
     for (int i = 0; i < n; ++i) {
       if ((i & (kWin - 1)) == 0 && i > 0) { wave_lds_sync(); fill_window(i); }
       if (wave == 0) cohort_step<BlindRotateArgs>(steps_done + i, s_mail);
@@ -1036,12 +1054,17 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
           Xf::digits(x, d, qd);
           ffwd_planar(lane, x, tw_kept, buf, sync_w);
         }
+        RS_WGS_STAMP(1);
         publish();
+        RS_WGS_STAMP(2);
         if (work) mac_half_stream(sl0, sl1, x, s_key[slot], lane);
         consumed();
+        RS_WGS_STAMP(3);
         publish();
+        RS_WGS_STAMP(4);
         if (work) mac_half_stream(sh0, sh1, x, s_key[slot], lane);
         consumed();
+        RS_WGS_STAMP(5);
       };
       // (the forward transforms stay single: run as software-pipelined pairs -- two transforms beside the four 32-register column
       // sums -- the kernel does not fit 256 registers: 1,040 bytes of scratch per lane, compiled in round 4 and dropped)
@@ -1079,9 +1102,11 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
       if (C::L & 1) row(C::L - 1);
 #else
       if (work) load_d(std::false_type{});
+      RS_WGS_STAMP(0);
 #pragma unroll 1
       for (int q = 0; q < C::L; ++q) row(q);
       if (work) load_d(std::true_type{});
+      RS_WGS_STAMP(0);
 #pragma unroll 1
       for (int q = 0; q < C::L; ++q) row(q);
 #endif
@@ -1100,6 +1125,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
         }
         wave_lds_sync();
       }
+      RS_WGS_STAMP(6);
     }
 
     if (active) {
@@ -1113,6 +1139,8 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
       if (lane == 0) out[kN] = acc1[0];
     }
   }
+  RS_WGS_STAMP(7);
+  RS_WGS_STAMP_FLUSH(wave);
   if (wave == 0) cohort_leave<BlindRotateArgs>(steps_done);
 }
 
@@ -2379,7 +2407,7 @@ hipError_t launch_polymul(int cfg, int mode, const int32_t* a_small, const int32
 
 }  // namespace rs
 
-#if defined(RS_STAMPS) && (RS_BS_PART & 1)
+#if defined(RS_STAMPS) && (RS_BS_PART & RS_STAMP_PART)
 // diagnostic builds only (not part of include/redsec_hip.h): copy the per-wave phase sums to the host and clear them
 extern "C" int rs_debug_read_stamps(unsigned long long* host, size_t count) {
   const size_t all = sizeof(rs::g_rs_stamps) / sizeof(unsigned long long);

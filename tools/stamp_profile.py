@@ -3,6 +3,8 @@
 
   tools/build_variant.sh stamps . -DRS_STAMPS
   REDSEC_HIP_LIB=$PWD/variants/lib_stamps.so python tools/stamp_profile.py [default128|redsec_small_v2] [gates]
+  tools/build_variant.sh stampswgs . -DRS_STAMPS -DRS_STAMPS_WGS       (the split lock-step kernel instead)
+  REDSEC_HIP_LIB=$PWD/variants/lib_stampswgs.so python tools/stamp_profile.py default128 16384 --split
 
 Diagnostic build only: every stamp drains the wave's LDS reads, so the run is slower than the product; read the SHARES.
 Cycles are shader cycles (s_memtime), per wave, summed over the CMUX steps of every ciphertext group the wave walked.
@@ -24,7 +26,16 @@ PHASES = ["step prologue", "digits + forward pair", "key wait + barrier 1", "mul
           "acc pre-read + inverse pair", "rounding + acc update", "group prologue / extract"]
 
 
+PHASES_SPLIT = ["step prologue + rotated differences", "digits + forward transform", "key wait + barrier (low half)", "multiply-accumulate low",
+                "key wait + barrier (high half)", "multiply-accumulate high", "two inverse pairs + update", "group prologue / extract"]
+
+
 def main():
+    global PHASES
+    split = "--split" in sys.argv
+    if split:
+        sys.argv.remove("--split")
+        PHASES = PHASES_SPLIT
     name = sys.argv[1] if len(sys.argv) > 1 else "default128"
     gates = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
     lib = redsec_amd.load_library()
@@ -33,6 +44,8 @@ def main():
     sk = client.SecretKeySet(name, seed=7)
     be = redsec_amd.Backend(redsec_amd.params(name), device=0)
     be.load_keys(sk.bk, sk.ksk)
+    if split:
+        be.set_mode("split")
     rng = np.random.default_rng(3)
     ba, bb = rng.integers(0, 2, gates), rng.integers(0, 2, gates)
     ca = torch.from_numpy(sk.encrypt_bits(ba, seed=1)).cuda()
@@ -61,6 +74,11 @@ def main():
     for k, ph in enumerate(PHASES):
         res["phases"][ph] = {"share": round(float(per_wave[:, k].sum() / tot.sum()), 4),
                              "cycles_per_cmux_step": round(float(per_wave[:, k].mean() / steps), 1)}
+    # the two halves of a workgroup separately: waves 4-7 lose the issue arbitration to their SIMD partners 0-3 and set the pace
+    for name_, sl in (("waves_0_3", slice(0, 4)), ("waves_4_7", slice(4, 8))):
+        sel = a[:, sl, :][used[:, sl]]
+        if sel.size:
+            res["cycles_per_cmux_step_" + name_] = {ph: round(float(sel[:, k].mean() / steps), 1) for k, ph in enumerate(PHASES)}
     # spread between the two halves of a workgroup (waves 0-3 dispatched first, 4-7 second)
     first = a[:, :4, :][used[:, :4]].sum(axis=0) if used[:, :4].any() else None
     second = a[:, 4:, :][used[:, 4:]].sum(axis=0) if used[:, 4:].any() else None
