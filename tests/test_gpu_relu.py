@@ -39,8 +39,10 @@ def test_lut_bootstrap_equals_oracle(fix, name, mode, request):
         got = be.bootstrap_lut(_dev(ct), _dev(luts)).cpu().numpy()
         sample = np.r_[0:min(B, 12), max(0, B - 12):B] if B > 24 else np.arange(B)
         # ciphertext b uses luts[b % 5]: keep the sample's own table assignment
-        ref = np.stack([ctx.bootstrap_lut_batch(ct[i:i + 1], luts[i % 5:i % 5 + 1])[0] for i in sample])
-        assert np.array_equal(got[sample], ref), B
+        for t in range(5):   # one oracle call per table (its batch runs under OpenMP)
+            rows = sample[sample % 5 == t]
+            if rows.size:
+                assert np.array_equal(got[rows], ctx.bootstrap_lut_batch(ct[rows], luts[t:t + 1])), (B, t)
     if mode == "fft":
         assert be.rounding_certificate() < 0.2 and be.fft_fallbacks() == 0
     be.close()
