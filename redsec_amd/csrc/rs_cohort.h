@@ -1,5 +1,5 @@
 // rs_cohort.h -- XCD cohorts: keeping the workgroups that share an L2 within reach of each other (device code; used by the
-// lock-step kernels of rs_bootstrap.hip and by the general ring kernels of rs_general.hip).
+// two lock-step kernels of rs_bootstrap.hip. The general ring kernels of rs_general.hip sit at the 8-XCD traffic floor without it).
 #pragma once
 
 #include <hip/hip_runtime.h>
