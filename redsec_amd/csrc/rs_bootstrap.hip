@@ -1908,10 +1908,11 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateAr
 // R = 2l/4 forward transforms plus one inverse. Here the 2l digit rows of a step go to 8 waves -- the components
 // alternate (wave & 1), and of the four waves of a component the OLDER ones (waves 0-3, which win the issue
 // arbitration against their SIMD partners 4-7) take the extra rows, so that every SIMD (waves s and s + 4) carries
-// the same number of rows and finishes them together (l = 10: 3+2 on every SIMD; l = 3: 1+1, 1+1, 1+0, 1+0;
-// rs_lds_plan.h; round-4 phase stamps: with the extra rows on younger waves two SIMDs finished 1,100 cycles late,
-// 196 ciphertexts 2.53 -> 2.43 ms) -- and the two inverse transforms to two waves with the fewest rows, on
-// different SIMDs (kInvA = 6: column 0, kInvB = 7: column 1).
+// the same number of rows and finishes them together (l = 10: 3+2 on every SIMD; rs_lds_plan.h; round-4 phase stamps:
+// with the extra rows on younger waves two SIMDs finished 1,100 cycles late, 196 ciphertexts 2.53 -> 2.43 ms) -- and the
+// two inverse transforms to two waves with the fewest rows, on different SIMDs (waves 6 and 7). For l < 4 (six rows for
+// eight waves) the first form's deal stays -- waves 0-3 component 0, waves 4-7 component 1, inverse transforms on the
+// two waves without rows (3 and 4): measured faster there (2.66 against 2.73 ms).
 // Partial column sums meet in LDS in ONE exchange: 14 partials of 8 KB need homes, and every wave's transform
 // buffer is idle by then, so wave w leaves its column-0 partial in its own exchange buffer and its column-1
 // partial in slot w of s_part -- except that kInvA keeps column 0 and kInvB column 1 in registers, and kInvB's
@@ -1933,7 +1934,7 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
   static_assert(Xf::kCertificate, "FFT policy only: the exact-NTT reduction schedule is validated for four partials");
   if (recompute_not_needed(a)) return;
   constexpr int G = kCoop8Waves, L = C::L, KPL = 2 * L;
-  constexpr int kInvA = kCoop8InvA, kInvB = kCoop8InvB;   // placement: rs_lds_plan.h (checked on the host)
+  constexpr int kInvA = coop8_inv_a(L), kInvB = coop8_inv_b(L);   // placement: rs_lds_plan.h (checked on the host)
   __shared__ double s_tw[Xf::kTableDoubles + 1];
   __shared__ double s_buf[G][kBufDoubles];
 #if RS_COOP8_ATOMICS
@@ -1962,7 +1963,7 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
   const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
   const int n = a.n;
   // rows [first, first + cnt) of this wave's component (digit index q = first + rr, TGSW row comp * L + q)
-  const int comp = coop8_comp(wave), cnt = coop8_row_count(L, wave), first = coop8_row_first(L, wave);
+  const int comp = coop8_comp(L, wave), cnt = coop8_row_count(L, wave), first = coop8_row_first(L, wave);
   double dev = 0.0;
   RS_C8_STAMP_DECL;   // -DRS_STAMPS -DRS_STAMPS_COOP8 (tools/stamp_profile.py coop8): 0 mask word, 1 rotated difference, 2 rows (forward +
                       // multiply-accumulate), 3 atomics issued, 4 barrier 1, 5 inverse + accumulator update, 6 barrier 2, 7 prologue / extract
@@ -2049,7 +2050,7 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
     // partial sums: column 0 into the wave's own (now idle) exchange buffer, column 1 into its s_part slot; position
     // u * 64 + lane is conflict-free. kInvA / kInvB keep the column they will invert in registers.
     {
-      const int home0 = coop8_partial_home(wave, 0), home1 = coop8_partial_home(wave, 1);
+      const int home0 = coop8_partial_home(L, wave, 0), home1 = coop8_partial_home(L, wave, 1);
       if (home0 != kHomeRegisters) {
         double* p0 = home0 == kHomePartSlot ? s_part[wave] : buf;
 #pragma unroll
@@ -2069,7 +2070,7 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           if (g == kInvA) continue;
-          const double* src = coop8_partial_home(g, 0) == kHomePartSlot ? s_part[g] : s_buf[g];
+          const double* src = coop8_partial_home(L, g, 0) == kHomePartSlot ? s_part[g] : s_buf[g];
 #pragma unroll
           for (int u = 0; u < kRegs; ++u) x[u] += src[u * 64 + lane];
         }

@@ -604,15 +604,15 @@ long model_coop(int G, int broken) {
 long model_coop8(int L, int broken) {
   LdsModel m;
   auto home = [&](int w, int col) {
-    int h = rs::coop8_partial_home(w, col);
-    if (broken == 1 && w == rs::kCoop8InvB && col == 0) h = rs::kHomeOwnBuffer;   // the tempting uniform rule: "column 0 into the own buffer"
+    int h = rs::coop8_partial_home(L, w, col);
+    if (broken == 1 && w == rs::coop8_inv_b(L) && col == 0) h = rs::kHomeOwnBuffer;   // the tempting uniform rule: "column 0 into the own buffer"
     return h;
   };
   auto home_addr = [&](int w, int col) { return home(w, col) == rs::kHomeOwnBuffer ? buf_of(w) : LdsModel::PART + w * kPolyBytes; };
   for (int step = 0; step < 2; ++step) {
     for (int w = 0; w < rs::kCoop8Waves; ++w) {
       if (rs::coop8_row_count(L, w) > 0) {
-        m.rd(w, LdsModel::ACC + rs::coop8_comp(w) * kAccBytes, kAccBytes);
+        m.rd(w, LdsModel::ACC + rs::coop8_comp(L, w) * kAccBytes, kAccBytes);
         m.rw(w, buf_of(w), kBufBytes);
       }
       for (int col = 0; col < 2; ++col)
@@ -620,7 +620,7 @@ long model_coop8(int L, int broken) {
     }
     m.barrier();
     for (int col = 0; col < 2; ++col) {
-      const int w = col == 0 ? rs::kCoop8InvA : rs::kCoop8InvB;
+      const int w = col == 0 ? rs::coop8_inv_a(L) : rs::coop8_inv_b(L);
       for (int g = 0; g < rs::kCoop8Waves; ++g)
         if (g != w) m.rd(w, home_addr(g, col), kPolyBytes);
       m.rw(w, buf_of(w), kBufBytes);
@@ -638,20 +638,20 @@ long model_coop8_atomics(int L, int broken) {
   for (int step = 0; step < 2; ++step) {
     for (int w = 0; w < rs::kCoop8Waves; ++w) {
       if (rs::coop8_row_count(L, w) == 0) continue;
-      m.rd(w, LdsModel::ACC + rs::coop8_comp(w) * kAccBytes, kAccBytes);
+      m.rd(w, LdsModel::ACC + rs::coop8_comp(L, w) * kAccBytes, kAccBytes);
       m.rw(w, buf_of(w), kBufBytes);
       for (int col = 0; col < 2; ++col) m.atomic(w, sum(col), kPolyBytes);
     }
     m.barrier();
     for (int col = 0; col < 2; ++col) {
-      const int w = col == 0 ? rs::kCoop8InvA : rs::kCoop8InvB;
+      const int w = col == 0 ? rs::coop8_inv_a(L) : rs::coop8_inv_b(L);
       m.rd(w, sum(col), kPolyBytes);
       if (broken != 1) m.wr(w, sum(col), kPolyBytes);     // cleared here, before the barrier ...
       m.rw(w, buf_of(w), kBufBytes);
       m.rw(w, LdsModel::ACC + col * kAccBytes, kAccBytes);
     }
     if (broken != 2) m.barrier();
-    if (broken == 1) for (int col = 0; col < 2; ++col) m.wr(col == 0 ? rs::kCoop8InvA : rs::kCoop8InvB, sum(col), kPolyBytes);   // ... not behind it
+    if (broken == 1) for (int col = 0; col < 2; ++col) m.wr(col == 0 ? rs::coop8_inv_a(L) : rs::coop8_inv_b(L), sum(col), kPolyBytes);   // ... not behind it
   }
   return m.conflicts();
 }
@@ -1023,18 +1023,18 @@ long rs_emu_coop8_row_split_violations(int L) {
     for (int r = 0; r < rs::coop8_row_count(L, w); ++r) {
       const int q = rs::coop8_row_first(L, w) + r;
       if (q < 0 || q >= L) { ++bad; continue; }
-      ++owner[rs::coop8_comp(w) * L + q];
+      ++owner[rs::coop8_comp(L, w) * L + q];
     }
   for (int v : owner) bad += v != 1;
   int lo = 1 << 30, hi = 0;
   for (int s = 0; s < 4; ++s) {
     const int older = rs::coop8_row_count(L, s), younger = rs::coop8_row_count(L, s + 4);
-    bad += younger > older;
+    bad += rs::coop8_by_age(L) && younger > older;
     lo = std::min(lo, older + younger); hi = std::max(hi, older + younger);
   }
   bad += hi - lo > 1;
-  bad += (rs::kCoop8InvA & 3) == (rs::kCoop8InvB & 3);      // the two inverse transforms on different SIMDs
-  for (int w = 0; w < rs::kCoop8Waves; ++w) bad += rs::coop8_row_count(L, w) < rs::coop8_row_count(L, rs::kCoop8InvA) || rs::coop8_row_count(L, w) < rs::coop8_row_count(L, rs::kCoop8InvB);
+  bad += (rs::coop8_inv_a(L) & 3) == (rs::coop8_inv_b(L) & 3);      // the two inverse transforms on different SIMDs
+  for (int w = 0; w < rs::kCoop8Waves; ++w) bad += rs::coop8_row_count(L, w) < rs::coop8_row_count(L, rs::coop8_inv_a(L)) || rs::coop8_row_count(L, w) < rs::coop8_row_count(L, rs::coop8_inv_b(L));
   return bad;
 }
 

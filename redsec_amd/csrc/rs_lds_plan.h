@@ -21,19 +21,28 @@ namespace rs {
 // Components alternate (wave & 1), j = wave >> 1 is the wave's place among the four of its component: j = 0, 1 are the older
 // waves of SIMDs 0/1 and 2/3, j = 2, 3 the younger ones.
 constexpr int kCoop8Waves = 8;
-constexpr int kCoop8InvA = 6;   // inverts column 0 (a wave with the fewest rows)
-constexpr int kCoop8InvB = 7;   // inverts column 1 (likewise; another SIMD than kCoop8InvA)
-RS_HD constexpr int coop8_comp(int wave) { return wave & 1; }
-RS_HD constexpr int coop8_row_count(int L, int wave) { return L / 4 + ((wave >> 1) < L % 4 ? 1 : 0); }
-RS_HD constexpr int coop8_row_first(int L, int wave) {
-  const int j = wave >> 1, rem = L % 4;
-  return j * (L / 4) + (j < rem ? j : rem);
+// l >= 4 (the REDsec set: l = 10): the deal by wave age described above. l < 4 (default-128: l = 3, six rows for eight waves)
+// keeps the deal of the kernel's first form -- waves 0-3 component 0, waves 4-7 component 1, the extra rows to the first waves of
+// component 0 and the last of component 1, inverse transforms on the two waves without rows (3 and 4): measured 2.66 ms against
+// 2.73 ms for the deal by age at 196 default-128 ciphertexts (profiles/r04/aw_*).
+RS_HD constexpr bool coop8_by_age(int L) { return L >= 4; }
+RS_HD constexpr int coop8_inv_a(int L) { return coop8_by_age(L) ? 6 : 3; }   // inverts column 0: a wave with the fewest rows
+RS_HD constexpr int coop8_inv_b(int L) { return coop8_by_age(L) ? 7 : 4; }   // inverts column 1: likewise, on another SIMD
+RS_HD constexpr int coop8_comp(int L, int wave) { return coop8_by_age(L) ? (wave & 1) : (wave >> 2); }
+RS_HD constexpr int coop8_row_count(int L, int wave) {
+  if (coop8_by_age(L)) return L / 4 + ((wave >> 1) < L % 4 ? 1 : 0);
+  return L / 4 + ((wave >> 2) == 0 ? ((wave & 3) < L % 4 ? 1 : 0) : ((wave & 3) >= 4 - L % 4 ? 1 : 0));
 }
-// where wave `wave` leaves its partial of column `col` for the wave that inverts that column
+RS_HD constexpr int coop8_row_first(int L, int wave) {
+  const int j = coop8_by_age(L) ? (wave >> 1) : (wave & 3), rem = L % 4;
+  if (coop8_by_age(L) || (wave >> 2) == 0) return j * (L / 4) + (j < rem ? j : rem);
+  return j * (L / 4) + (j > 4 - rem ? j - (4 - rem) : 0);
+}
+// where wave `wave` leaves its partial of column `col` for the wave that inverts that column (RS_COOP8_ATOMICS=0 form)
 enum { kHomeRegisters = 0, kHomeOwnBuffer = 1, kHomePartSlot = 2 };
-RS_HD constexpr int coop8_partial_home(int wave, int col) {
-  if (col == 0) return wave == kCoop8InvA ? kHomeRegisters : (wave == kCoop8InvB ? kHomePartSlot : kHomeOwnBuffer);
-  return wave == kCoop8InvB ? kHomeRegisters : kHomePartSlot;
+RS_HD constexpr int coop8_partial_home(int L, int wave, int col) {
+  if (col == 0) return wave == coop8_inv_a(L) ? kHomeRegisters : (wave == coop8_inv_b(L) ? kHomePartSlot : kHomeOwnBuffer);
+  return wave == coop8_inv_b(L) ? kHomeRegisters : kHomePartSlot;
 }
 
 // ---- blind_rotate_coops_kernel<G>: four sums (2 key halves x 2 columns), one owner wave each -----------------------------
