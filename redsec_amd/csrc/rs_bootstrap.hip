@@ -517,6 +517,27 @@ __device__ __forceinline__ void glds_chunks(const double* gsrc_wave_base, unsign
   }
 }
 
+// The same with the LDS side given as a byte address (a workgroup-uniform unsigned: no generic-pointer cast, whose null check
+// costs three scalar instructions per call) and the global side as a wave-uniform pointer the caller keeps running.
+template <int NCHUNK>
+__device__ __forceinline__ void glds_chunks_at(const double* gsrc_wave_base, unsigned lane_off, unsigned lds_byte_addr) {
+  static_assert(NCHUNK == 1 || NCHUNK == 2 || NCHUNK == 4, "1, 2 or 4 chunks of 1 KB per wave");
+  unsigned keep;
+  if constexpr (NCHUNK == 1) {
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(gsrc_wave_base), "s"(lds_byte_addr) : "memory");
+  } else if constexpr (NCHUNK == 2) {
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(gsrc_wave_base), "s"(lds_byte_addr) : "memory");
+  } else {
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:3072\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(gsrc_wave_base), "s"(lds_byte_addr) : "memory");
+  }
+}
+
 // Pointwise multiply-accumulate of a transform PAIR against its two key rows in LDS (FFT policies), as one
 // stream: 8 steps of two complex positions (4 ds_read_b128: both columns), the reads of step k+1 issued
 // before the FMAs of step k. Read in four blocks of 8 with the FMAs after each block (mac_row), every
@@ -641,7 +662,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
   constexpr uint32_t offset = gadget_offset<C>();
   double dev = 0.0;
   const long n_groups = (a.B + WPB - 1) / WPB;
-  const long total_rows = (long)n * KPL;
+  const int total_rows = n * KPL;   // key rows of one blind rotation (n <= 1024 steps x 2 l: far inside an int; scalar compares)
   RS_STAMP_DECL;
 #ifdef RS_WG_SETPRIO   // A/B: static priority for the second-dispatched half of the workgroup (the arbitration loser)
   if (wave >= WPB / 2) __builtin_amdgcn_s_setprio(RS_WG_SETPRIO);
@@ -731,9 +752,24 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
       if (pp >= C::L / 2) pp -= C::L / 2;
       return i * KPL + (long)comp * C::L + 2 * pp;
     };
-    long kk = 0;
-    issue_row(pair_row(0));
-    issue_row(pair_row(0) + 1);
+    int kk = 0;
+    // !kRotate: the pairs are requested in storage order, row R into slot 0 and R + 1 into slot 1: a running pointer and two
+    // fixed LDS byte addresses instead of a 64-bit row index, its compare, a multiply-add and a generic-pointer cast per row
+    // (the same change took the split lock-step kernel from 137 k to 145 k/s, profiles/r04/az_*)
+    [[maybe_unused]] const double* src_next = a.bk_x + (size_t)(wave * kChunksPerWave) * 128;
+    [[maybe_unused]] const unsigned key_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&s_key[0][0]) +
+                                              (unsigned)(wave * kChunksPerWave) * 1024u;
+    auto issue_pair = [&](int kk_) {
+      if constexpr (kRotate) {
+        const long Rn = pair_row(kk_);
+        issue_row(Rn); issue_row(Rn + 1);
+      } else {
+        glds_chunks_at<kChunksPerWave>(src_next, lane_off, key_lds);
+        glds_chunks_at<kChunksPerWave>(src_next + kRowDoubles, lane_off, key_lds + (unsigned)(kRowDoubles * sizeof(double)));
+        src_next += 2 * kRowDoubles;
+      }
+    };
+    issue_pair(0);
     RS_STAMP(7);
 #ifdef RS_T_STAGGER   // timing experiments only: start the waves RS_T_STAGGER x 64 cycles apart
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -744,7 +780,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
     // Barrier 1 of a pair publishes both rows (each wave first waits for its own shares); barrier 2
     // says every wave has finished reading them, after which the next pair's loads are issued and
     // have the whole next transform pair to land.
-    long R = 0;
+    int R = 0;
     unsigned bara_next = s_bara[wave][0];   // read one step ahead: its LDS latency is not exposed
     for (int i = 0; i < n; ++i) {
       // XCD cohorts (cohort_step above): with l = 10 a step reads 320 KB of key per CU and an XCD's L2 keeps 12 steps; launches of the REDsec
@@ -809,7 +845,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
 #endif
         R += 2;
         ++kk;
-        if (R < total_rows) { const long Rn = pair_row(kk); issue_row(Rn); issue_row(Rn + 1); }
+        if (R < total_rows) issue_pair(kk);
 #endif
         RS_STAMP(4);
       };
@@ -949,7 +985,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
   fft_kept_load(tw_kept, tw);
   const int n = a.n;
   const long n_groups = (a.B + WPB - 1) / WPB;
-  const long total_half = (long)n * KPL * 2;
+  const int total_half = n * KPL * 2;   // half-rows of one blind rotation (n <= 1024 steps x 4 l: far inside an int; scalar compares)
   const unsigned lane_off = (unsigned)lane * 16u;
   auto sync_w = [] { wave_lds_sync(); };
   RS_WGS_STAMP_DECL;   // -DRS_STAMPS -DRS_STAMPS_WGS (tools/stamp_profile.py --split): 0 step prologue + rotated differences, 1 digits + forward transform,
@@ -984,7 +1020,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
     fill_window(0);
     // every wave has left the previous group's last multiply-accumulate before the ring is refilled
     __syncthreads();
-    long h_issue = 0;        // next half-row to request
+    int h_issue = 0;         // next half-row to request
     int slot_issue = 0;      // its slot, h_issue mod 3
 #ifndef RS_WGS_ROTATE
 #define RS_WGS_ROTATE 0   // workgroup b walks the l digits of a component in the order rotated by b: measured -11 % / -9 % (default-128 /
@@ -993,9 +1029,12 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
 #endif
     const int wrot = RS_WGS_ROTATE ? (int)(blockIdx.x % C::L) : 0;
     int iss_i = 0, iss_k = 0;   // step and position (component, digit slot, half) of the next half-row to request
+    const double* src_next = a.bk_x + (size_t)(wave * kChunks) * 128;   // this wave's share of the next half-row
+    const unsigned key_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&s_key[0][0]) +
+                             (unsigned)(wave * kChunks) * 1024u;
     auto issue_next = [&]() {
       if (h_issue < total_half) {
-        long hsrc = h_issue;
+        [[maybe_unused]] long hsrc = h_issue;
         if (RS_WGS_ROTATE) {
           const int comp = iss_k / (2 * C::L), k = iss_k - comp * 2 * C::L;
           int q = (k >> 1) + wrot;
@@ -1006,14 +1045,21 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
 #ifdef RS_T_WGS_NOKEY   // TIMING PROBE (results are wrong): every step reads the half-rows of step 0, which stay in the L2s
         hsrc %= 2 * KPL;
 #endif
+#if RS_WGS_ROTATE || defined(RS_T_WGS_NOKEY)
         glds_chunks<kChunks>(a.bk_x + (size_t)hsrc * kSlotDoubles + (size_t)(wave * kChunks) * 128, lane_off, s_key[slot_issue] + (wave * kChunks) * 128);
+#else
+        // half-rows are requested in storage order: a running pointer and the slot's byte address, seven scalar instructions
+        // instead of the twenty-two of the general form (a 64-bit index compare, a shift-and-add pair, a pointer cast)
+        glds_chunks_at<kChunks>(src_next, lane_off, key_lds + (unsigned)slot_issue * (unsigned)(kSlotDoubles * sizeof(double)));
+        src_next += kSlotDoubles;
+#endif
         ++h_issue;
         slot_issue = slot_issue == 2 ? 0 : slot_issue + 1;
       }
     };
     issue_next();
     issue_next();
-    long h = 0;              // half-row consumed next
+    int h = 0;               // half-row consumed next
     int slot = 0;
     // publishes half-row h (every wave first waits for its own share: at most the next half-row's two loads may still
     // be in flight) and frees the slot of h - 1 for h + 2
