@@ -1229,7 +1229,7 @@ __global__ __launch_bounds__(512) void blind_rotate_duos_kernel(BlindRotateArgs 
   Xf::init(tw, lane, s_tw, a.tw);
   const int n = a.n;
   const long n_groups = (a.B + kCts - 1) / kCts;
-  const long total_pairs = (long)n * C::L * 2;
+  const int total_pairs = n * C::L * 2;   // 32-bit counters: scalar compares (see blind_rotate_wgs_kernel)
   const unsigned lane_off = (unsigned)lane * 16u;
   auto sync_w = [] { wave_lds_sync(); };
   // own += x * column h, given += x * column 1 - h of the half-row in `slot`
@@ -1247,15 +1247,18 @@ __global__ __launch_bounds__(512) void blind_rotate_duos_kernel(BlindRotateArgs 
   const int rot = RS_DUOS_ROTATE ? (int)(blockIdx.x % C::L) : 0;
   const int kcomp = duos_fetch_comp(wave);                                 // placement: rs_lds_plan.h (checked on the host)
   const size_t chunk_off = (size_t)duos_first_chunk(wave) * 128;
-  long issued;
+  const unsigned key_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&s_key[0][0]) + (unsigned)chunk_off * 8u;
+  int issued;
   int iss_i, iss_k;   // step and position (digit slot, half) of the next pair to request
   auto issue_reset = [&] { issued = 0; iss_i = 0; iss_k = 0; };
   auto issue_next = [&] {
     if (issued >= total_pairs) return;
     int q = (iss_k >> 1) + rot;
     if (q >= C::L) q -= C::L;
-    const long hrow = (((long)iss_i * KPL + (long)kcomp * C::L + q) << 1) + (iss_k & 1);
-    glds_chunks<4>(a.bk_x + (size_t)hrow * kSlotDoubles + chunk_off, lane_off, s_key[duos_pair_slot(issued, kcomp)] + chunk_off);
+    // the half-row's byte offset fits 32 bits (at most n * 4 l half-rows of 16 KB: 229 MB for the REDsec set); the slot as an LDS byte address
+    const unsigned hrow = (unsigned)(((iss_i * KPL + kcomp * C::L + q) << 1) + (iss_k & 1));
+    glds_chunks_at<4>(reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.bk_x) + (size_t)(hrow * (unsigned)(kSlotDoubles * sizeof(double)))) + chunk_off, lane_off,
+                      key_lds + (unsigned)duos_pair_slot(issued, kcomp) * (unsigned)(kSlotDoubles * sizeof(double)));
     ++issued;
     if (++iss_k == 2 * C::L) { iss_k = 0; ++iss_i; }
   };
@@ -1285,7 +1288,7 @@ __global__ __launch_bounds__(512) void blind_rotate_duos_kernel(BlindRotateArgs 
     }
     fill_window(0);
     __syncthreads();   // every wave has left the previous group's last exchange and extract before the key buffer is refilled
-    long p = 0;        // pair consumed next; it has been requested, pair p + 1 has not
+    int p = 0;         // pair consumed next; it has been requested, pair p + 1 has not
     issue_reset();
     issue_next();
     // publishes pair p (every wave first waits for its own share; nothing else of this wave is in flight) and requests pair

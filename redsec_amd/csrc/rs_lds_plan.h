@@ -57,7 +57,7 @@ RS_HD constexpr int duo_partner(int wave) { return wave ^ 1; }
 RS_HD constexpr int duo_quad_slot(int wave) { return wave >> 1; }
 RS_HD constexpr int duo_quad_first_chunk(int wave) { return (wave & 1) * 8; }
 // blind_rotate_duos_kernel: pair p = the half-rows of both components in slots 2 (p & 1) + comp; wave fetches 4 chunks
-RS_HD constexpr int duos_pair_slot(long p, int comp) { return 2 * (int)(p & 1) + comp; }
+RS_HD constexpr int duos_pair_slot(int p, int comp) { return 2 * (p & 1) + comp; }
 RS_HD constexpr int duos_fetch_comp(int wave) { return wave >> 2; }
 RS_HD constexpr int duos_first_chunk(int wave) { return (wave & 3) * 4; }
 
