@@ -547,14 +547,16 @@ __device__ __forceinline__ void glds_chunks_at(const double* gsrc_wave_base, uns
 #else
 #define RS_MAC_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
+// col0 / col1: offsets (in double2) of the column multiplied into s0 / s1 within a key row -- 0 and kN / 2 for (column 0, column 1);
+// the duo kernel passes them swapped for its odd waves, so that s0 is always the column the wave itself inverts
 __device__ __forceinline__ void mac_pair_stream(double (&s0)[kRegs], double (&s1)[kRegs], const double (&xa)[kRegs], const double (&xb)[kRegs],
-                                                const double* keyA, const double* keyB, int lane) {
+                                                const double* keyA, const double* keyB, int lane, int col0 = 0, int col1 = kN / 2) {
   const double2* ka = reinterpret_cast<const double2*>(keyA);
   const double2* kb = reinterpret_cast<const double2*>(keyB);
   double2 u[2][4];
   auto issue = [&](int step, double2 (&w)[4]) {
-    const double2* k0 = step < 4 ? ka : kb;
-    const double2* k1 = k0 + kN / 2;
+    const double2* k0 = (step < 4 ? ka : kb) + col0;
+    const double2* k1 = (step < 4 ? ka : kb) + col1;
     const int v = 2 * (step & 3);
     w[0] = k0[v * 64 + lane]; w[1] = k0[(v + 1) * 64 + lane];
     w[2] = k1[v * 64 + lane]; w[3] = k1[(v + 1) * 64 + lane];
@@ -1603,6 +1605,7 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int c = wave >> 1, h = wave & 1;
+  const int own_col = h ? kN / 2 : 0, given_col = h ? 0 : kN / 2;   // offsets (double2) of the two columns within a key row
   const Field f = a.f;
   double* buf = s_buf[wave];
   int32_t* acc = s_acc[c][h];
@@ -1680,9 +1683,12 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
       const int32_t bara = __builtin_amdgcn_readfirstlane((int)bara_next);
       bara_next = (active && i + 1 < n) ? s_bara[c][i + 1] : 0;
       const bool work = bara != 0;   // tfhe_blindRotate_FFT skips the identity CMUX
-      double s0[kRegs], s1[kRegs];
+      // own: partial sum of the column this wave inverts (column h); given: of the column its partner inverts. Addressed through the
+      // key-row offsets (own_col, given_col) instead of (column 0, column 1) selected by h afterwards: those selects were 310
+      // v_cndmask per CMUX step (the compiler cannot know h at compile time)
+      double own[kRegs], given[kRegs];
 #pragma unroll
-      for (int u = 0; u < kRegs; ++u) { s0[u] = 0.0; s1[u] = 0.0; }
+      for (int u = 0; u < kRegs; ++u) { own[u] = 0.0; given[u] = 0.0; }
       int32_t d[kRegs];
       if (work) {
 #pragma unroll
@@ -1703,10 +1709,10 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
         RS_DUO_STAMP(2);
         if (work) {
 #ifdef RS_NO_MAC_STREAM
-          mac_row(s0, s1, xa, 2 * h);
-          mac_row(s0, s1, xb, 2 * h + 1);
+          mac_row(h ? given : own, h ? own : given, xa, 2 * h);
+          mac_row(h ? given : own, h ? own : given, xb, 2 * h + 1);
 #else
-          mac_pair_stream(s0, s1, xa, xb, s_key[2 * h], s_key[2 * h + 1], lane);
+          mac_pair_stream(own, given, xa, xb, s_key[2 * h], s_key[2 * h + 1], lane, own_col, given_col);
 #endif
         }
         RS_DUO_STAMP(3);
@@ -1718,10 +1724,10 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
       double* xchg = &s_key[0][0] + duo_xchg_doubles(wave);
       if (work) {
 #pragma unroll
-        for (int u = 0; u < kRegs; ++u) xchg[u * 64 + lane] = h ? s0[u] : s1[u];
+        for (int u = 0; u < kRegs; ++u) xchg[u * 64 + lane] = given[u];
       }
       __syncthreads();
-      double (&mine)[kRegs] = h ? s1 : s0;
+      double (&mine)[kRegs] = own;
       if (work) {
         const double* theirs = &s_key[0][0] + duo_xchg_doubles(duo_partner(wave));
 #pragma unroll
