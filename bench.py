@@ -566,6 +566,16 @@ def main():
                                            "note": "blind rotation alone at that issue fraction, keyswitch not counted; the 1.0e6/s north-star figure is "
                                                    "beyond both for an FP64-carried transform product on this chip"}}
 
+        # box calibration: the FP64 FMA rate this device sustains right now at the kernel's occupancy (boxes of one pool were seen
+        # 5-6 % apart in it, and with it in every kernel of this path); the kernel's share of THAT is the box-independent figure
+        try:
+            fp64_now = be.fp64_rate() / 1e9
+            roofline_valu["sustained_on_this_box"] = {"fp64_fma_G_lane_ops_per_s": round(fp64_now, 1), "frac_of_nominal_peak": round(fp64_now / FP64_VALU_PEAK_GOPS, 4),
+                                                      "kernel_frac_of_it": round(valu / fp64_now, 4),
+                                                      "note": "pure FMA stream, 8 waves per CU, measured after the timed steps (rs_debug_fp64_rate)"}
+        except Exception as e:   # an older library without the tap: the line stays valid
+            roofline_valu["sustained_on_this_box"] = {"error": str(e)[:120]}
+
         # ---- CPU baseline + parity on a bounded sample of the same workload ----
         cpu = None
         parity = None

@@ -185,6 +185,10 @@ int rs_debug_polymul(rs_ctx* ctx, int32_t* out, const int32_t* a_small, const in
  * [xcd * 64 + slot] of workgroup (blockIdx & 7, blockIdx >> 3) reads 0x40000000 + the CMUX steps that workgroup walked once it
  * has left; entries no workgroup owned read 0x7f7f7f7f. RS_ERR_STATE before the first such launch. */
 int rs_debug_cohort_table(rs_ctx* ctx, void* stream, int32_t* out);
+/* Box calibration (no reference counterpart): the FP64 fused-multiply-add lane-operations per second the device sustains right
+ * now at the occupancy of the blind-rotation kernels (8 waves per CU, 16 independent chains per lane; best of three 10-ms
+ * launches on the default stream). bench.py reports it beside roofline_valu: boxes of one pool differ by several per cent. */
+int rs_debug_fp64_rate(rs_ctx* ctx, double* lane_ops_per_s);
 
 /* ---- linear stage on LWE words (no bootstrap), DEVICE pointers ---------------------------------
  * out[m] = bias_b[m % bias_depth] (on the b word, optional) + zero_tap_b * (#zero taps of m)

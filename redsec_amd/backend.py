@@ -18,7 +18,7 @@ _u8p = C.POINTER(C.c_uint8)
 ABI_SYMBOLS = [
     "rs_last_error", "rs_version", "rs_params_default128", "rs_params_redsec_small_v2", "rs_create", "rs_destroy",
     "rs_load_keys", "rs_reserve", "rs_bootstrap_dev", "rs_bootstrap", "rs_gate_dev", "rs_gate", "rs_mux_dev", "rs_mux",
-    "rs_gate_mu_dev", "rs_gather_rows_dev", "rs_bootstrap_wo_ks_dev", "rs_keyswitch_dev", "rs_debug_polymul", "rs_debug_cohort_table", "rs_linear_fc_dev", "rs_conv_ternary_dev",
+    "rs_gate_mu_dev", "rs_gather_rows_dev", "rs_bootstrap_wo_ks_dev", "rs_keyswitch_dev", "rs_debug_polymul", "rs_debug_cohort_table", "rs_debug_fp64_rate", "rs_linear_fc_dev", "rs_conv_ternary_dev",
     "rs_sumpool_dev", "rs_lincomb_dev", "rs_dev_alloc", "rs_dev_free", "rs_copy_to_dev", "rs_copy_to_host", "rs_sync",
     "rs_set_timing", "rs_last_kernel_ms", "rs_info", "rs_set_mode", "rs_get_mode", "rs_rounding_certificate", "rs_fft_fallbacks",
     "rs_bootstrap_lut_dev", "rs_set_certificate_limit", "rs_certify", "rs_reserve_stream", "rs_last_kernel_ms_stream", "rs_last_launch", "rs_copy_dev_to_dev",
@@ -100,6 +100,7 @@ def load_library(path=None):
     L.rs_keyswitch_dev.argtypes = [vp, vp, vp, C.c_size_t, vp]
     L.rs_debug_polymul.argtypes = [vp, _i32p, _i32p, _i32p, C.c_size_t]
     L.rs_debug_cohort_table.argtypes = [vp, vp, _i32p]
+    L.rs_debug_fp64_rate.argtypes = [vp, C.POINTER(C.c_double)]
     L.rs_linear_fc_dev.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, vp]
     L.rs_conv_ternary_dev.argtypes = [vp, vp, vp, vp, vp, C.POINTER(RsConvShape), C.c_int32, C.c_int32, vp, C.c_int32, vp]
     L.rs_sumpool_dev.argtypes = [vp, vp, vp, C.POINTER(RsPoolShape), vp, C.c_int32, vp]
@@ -406,6 +407,12 @@ class Backend:
         f, w, r = C.c_int32(), C.c_int32(), C.c_int64()
         _check(self.L, self.L.rs_last_launch(self.h, self._stream(), C.byref(f), C.byref(w), C.byref(r)))
         return {"form": ["per_wave", "workgroup", "duo", "coop2", "coop4", "general", "split_workgroup", "split_coop", "split_duo", "coop8"][f.value], "waves_per_block": w.value, "resident": r.value}
+
+    def fp64_rate(self):
+        """FP64 FMA lane-operations per second this device sustains right now (box calibration, see include/redsec_hip.h)."""
+        v = C.c_double()
+        _check(self.L, self.L.rs_debug_fp64_rate(self.h, C.byref(v)))
+        return v.value
 
     def cohort_table(self):
         """Progress table [8 XCDs][64 slots] of the current stream's last lock-step launch with XCD cohorts (debug tap)."""

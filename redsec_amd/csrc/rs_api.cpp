@@ -1093,6 +1093,32 @@ int rs_last_launch(rs_ctx* c, void* stream, int32_t* form, int32_t* waves_per_bl
   return RS_OK;
 }
 
+int rs_debug_fp64_rate(rs_ctx* c, double* lane_ops_per_s) {
+  if (!c || !lane_ops_per_s) return fail(RS_ERR_INVALID, "null argument");
+  RS_HIP(hipSetDevice(c->device));
+  double* d_out = nullptr;
+  RS_HIP(hipMalloc(&d_out, (size_t)c->num_cus * 512 * sizeof(double)));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t err = hipEventCreate(&e0);
+  if (err == hipSuccess) err = hipEventCreate(&e1);
+  double ops = 0.0, best_ms = 1e30;
+  for (int rep = 0; rep < 4 && err == hipSuccess; ++rep) {   // the first launch warms up; the best of three counts
+    err = hipEventRecord(e0, nullptr);
+    if (err == hipSuccess) err = rs::launch_fp64_rate(d_out, c->num_cus, 1 << 17, &ops, nullptr);
+    if (err == hipSuccess) err = hipEventRecord(e1, nullptr);
+    if (err == hipSuccess) err = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+    if (err == hipSuccess && rep > 0 && ms < best_ms) best_ms = ms;
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(d_out);
+  if (err != hipSuccess) return fail(RS_ERR_HIP, "rs_debug_fp64_rate: %s", hipGetErrorString(err));
+  *lane_ops_per_s = ops / (best_ms * 1e-3);
+  return RS_OK;
+}
+
 int rs_debug_cohort_table(rs_ctx* c, void* stream, int32_t* out) {
   if (!c || !out) return fail(RS_ERR_INVALID, "null argument");
   Lane* ln = nullptr;

@@ -116,6 +116,7 @@ hipError_t launch_conv_ternary_tiled(int32_t* out, const int32_t* in, const uint
                                      const int32_t* bias_b, int bias_depth, uint32_t* scratch, hipStream_t st);
 hipError_t launch_conv_ternary(int32_t* out, const int32_t* in, const uint8_t* sign, const uint8_t* zero, const ConvShape& s, int W,
                                int32_t zero_tap_b, int32_t pad_tap_b, const int32_t* bias_b, int bias_depth, hipStream_t st);
+hipError_t launch_fp64_rate(double* out, int num_cus, int iters, double* lane_ops, hipStream_t st);
 hipError_t launch_sumpool(int32_t* out, const int32_t* in, const PoolShape& s, int W, const int32_t* bias_b, int bias_depth,
                           hipStream_t st);
 

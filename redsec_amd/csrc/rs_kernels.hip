@@ -562,6 +562,30 @@ hipError_t launch_conv_ternary_tiled(int32_t* out, const int32_t* in, const uint
   return hipGetLastError();
 }
 
+// Box calibration for bench.py: what the FP64 vector pipes of THIS device sustain right now. One workgroup of 8 waves per CU (two
+// per SIMD, the occupancy of the blind-rotation kernels), 16 independent fused multiply-add chains per lane and nothing else in
+// the loop. The boxes of a pool differ by several per cent in exactly this number (clocks under their power limit); a bench
+// line carries it so that a figure from a slow box can be told from a slow kernel.
+__global__ __launch_bounds__(512) void fp64_rate_kernel(double* out, double b, double c, int iters) {
+  double x[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = (double)threadIdx.x * 1e-9 + (double)k;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = __builtin_fma(x[k], b, c);
+  }
+  double sum = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) sum += x[k];
+  out[(size_t)blockIdx.x * 512 + threadIdx.x] = sum;
+}
+// lane_ops = the FP64 lane-operations one launch performs (an FMA counted once, as in bench.py's roofline_valu)
+hipError_t launch_fp64_rate(double* out, int num_cus, int iters, double* lane_ops, hipStream_t st) {
+  hipLaunchKernelGGL(fp64_rate_kernel, dim3((unsigned)num_cus), dim3(512), 0, st, out, 0.999999, 1e-7, iters);
+  *lane_ops = (double)num_cus * 512.0 * 16.0 * (double)iters;
+  return hipGetLastError();
+}
+
 hipError_t launch_sumpool(int32_t* out, const int32_t* in, const PoolShape& s, int W, const int32_t* bias_b, int bias_depth,
                           hipStream_t st) {
   hipLaunchKernelGGL(sumpool_kernel, dim3((W + 255) / 256, s.C, s.Ho * s.Wo), dim3(256), 0, st, out, in, s, W, bias_b, bias_depth);
