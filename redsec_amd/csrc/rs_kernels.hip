@@ -73,85 +73,10 @@ constexpr int KS_CH = 32;            // output words per workgroup
 constexpr int KS_CHP = KS_CH + 4;    // padded row (words)
 constexpr int KS_TILE_THREADS = 256;
 
-template <int T, int BASEBIT, int KS_IG>  // KS_IG = input coefficients staged per round
-__global__ __launch_bounds__(KS_TILE_THREADS) void keyswitch_tiled_kernel(KeyswitchArgs a) {
-  constexpr int BASE = 1 << BASEBIT;
-  constexpr int ROWS = KS_IG * T * BASE;
-  __shared__ __attribute__((aligned(16))) int32_t s_ksk[2][ROWS * KS_CHP];
-  const int tid = threadIdx.x;
-  const long ct = (long)blockIdx.x * KS_TILE_THREADS + tid;
-  const bool live = ct < a.B;
-  const int w0 = blockIdx.y * KS_CH;
-  const int W = a.W, N = a.N;   // ring degree of the extracted samples: 1024 ... 8192
-  const int32_t* u0 = a.u0 + (live ? ct : 0) * (size_t)(N + 1);
-  const int32_t* u1 = a.u1 ? a.u1 + (live ? ct : 0) * (size_t)(N + 1) : nullptr;
-
-  for (int e = tid; e < 2 * ROWS * KS_CHP; e += KS_TILE_THREADS) (&s_ksk[0][0])[e] = 0;
-
-  uint32_t acc[KS_CH];
-#pragma unroll
-  for (int k = 0; k < KS_CH; ++k) acc[k] = 0;
-
-  constexpr uint32_t prec_offset = 1u << (32 - (1 + BASEBIT * T));
-  constexpr uint32_t mask = (1u << BASEBIT) - 1u;
-  // staging: KS_IG * T * (BASE-1) row segments of KS_CH words; 8 threads x 16 B per segment
-  constexpr int SEGS = KS_IG * T * (BASE - 1);
-  auto stage = [&](int buf, int i0) {
-    for (int sidx = tid; sidx < SEGS * 8; sidx += KS_TILE_THREADS) {
-      const int seg = sidx >> 3, part = sidx & 7;
-      const int v = seg % (BASE - 1) + 1;
-      const int ij = seg / (BASE - 1);          // ii * T + j
-      const int wq = w0 + part * 4;
-      const int32_t* src = a.ksk + (((size_t)i0 * T + ij) * BASE + v) * (size_t)W + wq;
-      int32_t* dst = &s_ksk[buf][(ij * BASE + v) * KS_CHP + part * 4];
-      if (wq + 3 < W) {
-        // rows are only 4-byte aligned in general (W odd): assemble from scalar loads
-        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dst[e] = (wq + e < W) ? src[e] : 0;
-      }
-    }
-  };
-
-  // blockIdx.z selects a slice of the N input coefficients (latency form for small batches: the
-  // slices add their partial sums into a zeroed output with integer atomics -- exact and
-  // order-independent mod 2^32); gridDim.z == 1 is the plain-store throughput form.
-  const int groups_per_split = (N / KS_IG) / (int)gridDim.z;
-  const int g_begin = (int)blockIdx.z * groups_per_split, g_end = g_begin + groups_per_split;
-  __syncthreads();
-  stage(g_begin & 1, g_begin * KS_IG);
-  __syncthreads();
-  for (int g = g_begin; g < g_end; ++g) {
-    const int buf = g & 1;
-    if (g + 1 < g_end) stage(buf ^ 1, (g + 1) * KS_IG);
-    const int i0 = g * KS_IG;
-    uint32_t ai[KS_IG];
-#pragma unroll
-    for (int ii = 0; ii < KS_IG; ++ii) {
-      uint32_t v = live ? (uint32_t)u0[i0 + ii] : 0u;
-      if (u1 && live) v += (uint32_t)u1[i0 + ii];
-      ai[ii] = live ? v + prec_offset : 0u;
-    }
-#pragma unroll
-    for (int ii = 0; ii < KS_IG; ++ii) {
-#pragma unroll
-      for (int j = 0; j < T; ++j) {
-        const uint32_t dgt = (ai[ii] >> (32 - (j + 1) * BASEBIT)) & mask;
-        const int4* row = reinterpret_cast<const int4*>(&s_ksk[buf][((ii * T + j) * BASE + (int)dgt) * KS_CHP]);
-#pragma unroll
-        for (int q = 0; q < KS_CH / 4; ++q) {
-          const int4 r = row[q];
-          acc[4 * q + 0] += (uint32_t)r.x;
-          acc[4 * q + 1] += (uint32_t)r.y;
-          acc[4 * q + 2] += (uint32_t)r.z;
-          acc[4 * q + 3] += (uint32_t)r.w;
-        }
-      }
-    }
-    __syncthreads();
-  }
-  if (!live) return;
+// What a tile workgroup does with a lane's KS_CH partial sums: the plain store of the throughput form, the slice's partials for
+// the two-step sliced form, or integer atomics into a zeroed output (sliced, no scratch).
+__device__ __forceinline__ void ks_tile_finish(const KeyswitchArgs& a, const uint32_t (&acc)[KS_CH], long ct, int w0, const int32_t* u0, const int32_t* u1) {
+  const int W = a.W, N = a.N;
   uint32_t bw = 0;
   if (blockIdx.z == 0) {
     bw = (uint32_t)u0[N];
@@ -179,6 +104,233 @@ __global__ __launch_bounds__(KS_TILE_THREADS) void keyswitch_tiled_kernel(Keyswi
       if (w < W) atomicAdd(reinterpret_cast<unsigned int*>(out + k), (w == W - 1 ? bw : 0u) - acc[k]);
     }
   }
+}
+
+template <int T, int BASEBIT, int KS_IG>  // KS_IG = input coefficients staged per round
+__global__ __launch_bounds__(KS_TILE_THREADS) void keyswitch_tiled_kernel(KeyswitchArgs a) {
+  constexpr int BASE = 1 << BASEBIT;
+  constexpr int ROWS = KS_IG * T * BASE;
+  __shared__ __attribute__((aligned(16))) int32_t s_ksk[2][ROWS * KS_CHP];
+  const int tid = threadIdx.x;
+  const long ct = (long)blockIdx.x * KS_TILE_THREADS + tid;
+  const bool live = ct < a.B;
+  const int w0 = blockIdx.y * KS_CH;
+  const int W = a.W, N = a.N;   // ring degree of the extracted samples: 1024 ... 8192
+  const int32_t* u0 = a.u0 + (live ? ct : 0) * (size_t)(N + 1);
+  const int32_t* u1 = a.u1 ? a.u1 + (live ? ct : 0) * (size_t)(N + 1) : nullptr;
+
+  for (int e = tid; e < 2 * ROWS * KS_CHP; e += KS_TILE_THREADS) (&s_ksk[0][0])[e] = 0;
+
+  uint32_t acc[KS_CH];
+#pragma unroll
+  for (int k = 0; k < KS_CH; ++k) acc[k] = 0;
+
+  constexpr uint32_t prec_offset = 1u << (32 - (1 + BASEBIT * T));
+  constexpr uint32_t mask = (1u << BASEBIT) - 1u;
+  // staging: KS_IG * T * (BASE-1) row segments of KS_CH words; 8 threads x 16 B per segment
+  constexpr int SEGS = KS_IG * T * (BASE - 1);
+  // the next group's rows are requested into registers before the current group's lookups and stored to LDS after them: their L2
+  // round trip runs behind the lookups (round 4; as in keyswitch_tiled_comb_kernel)
+  constexpr int NST = (SEGS * 8 + KS_TILE_THREADS - 1) / KS_TILE_THREADS;
+  int32_t st[NST][4];
+  auto stage_load = [&](int i0) {
+#pragma unroll
+    for (int sl = 0; sl < NST; ++sl) {
+      const int sidx = tid + sl * KS_TILE_THREADS;
+      const int seg = sidx >> 3, part = sidx & 7;
+      const int v = seg % (BASE - 1) + 1;
+      const int ij = seg / (BASE - 1);          // ii * T + j
+      const int wq = w0 + part * 4;
+      // rows are only 4-byte aligned in general (W odd): assemble from scalar loads
+      const int32_t* src = a.ksk + (((size_t)i0 * T + ij) * BASE + v) * (size_t)W + wq;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) st[sl][e] = (sidx < SEGS * 8 && wq + e < W) ? src[e] : 0;
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int sl = 0; sl < NST; ++sl) {
+      const int sidx = tid + sl * KS_TILE_THREADS;
+      if (sidx < SEGS * 8) {
+        const int seg = sidx >> 3, part = sidx & 7;
+        const int v = seg % (BASE - 1) + 1;
+        const int ij = seg / (BASE - 1);
+        *reinterpret_cast<int4*>(&s_ksk[buf][(ij * BASE + v) * KS_CHP + part * 4]) = make_int4(st[sl][0], st[sl][1], st[sl][2], st[sl][3]);
+      }
+    }
+  };
+
+  // blockIdx.z selects a slice of the N input coefficients (latency form for small batches: the
+  // slices add their partial sums into a zeroed output with integer atomics -- exact and
+  // order-independent mod 2^32); gridDim.z == 1 is the plain-store throughput form.
+  const int groups_per_split = (N / KS_IG) / (int)gridDim.z;
+  const int g_begin = (int)blockIdx.z * groups_per_split, g_end = g_begin + groups_per_split;
+  __syncthreads();
+  stage_load(g_begin * KS_IG);
+  stage_store(g_begin & 1);
+  __syncthreads();
+  for (int g = g_begin; g < g_end; ++g) {
+    const int buf = g & 1;
+    if (g + 1 < g_end) stage_load((g + 1) * KS_IG);
+    const int i0 = g * KS_IG;
+    uint32_t ai[KS_IG];
+#pragma unroll
+    for (int ii = 0; ii < KS_IG; ++ii) {
+      uint32_t v = live ? (uint32_t)u0[i0 + ii] : 0u;
+      if (u1 && live) v += (uint32_t)u1[i0 + ii];
+      ai[ii] = live ? v + prec_offset : 0u;
+    }
+#pragma unroll 1
+    for (int ii = 0; ii < KS_IG; ++ii) {
+#pragma unroll
+      for (int j = 0; j < T; ++j) {
+        const uint32_t dgt = (ai[ii] >> (32 - (j + 1) * BASEBIT)) & mask;
+        const int4* row = reinterpret_cast<const int4*>(&s_ksk[buf][((ii * T + j) * BASE + (int)dgt) * KS_CHP]);
+#pragma unroll
+        for (int q = 0; q < KS_CH / 4; ++q) {
+          const int4 r = row[q];
+          acc[4 * q + 0] += (uint32_t)r.x;
+          acc[4 * q + 1] += (uint32_t)r.y;
+          acc[4 * q + 2] += (uint32_t)r.z;
+          acc[4 * q + 3] += (uint32_t)r.w;
+        }
+      }
+    }
+    if (g + 1 < g_end) stage_store(buf ^ 1);   // the other buffer: nobody reads it in this round
+    __syncthreads();
+  }
+  if (!live) return;
+  ks_tile_finish(a, acc, ct, w0, u0, u1);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Tiled keyswitch with COMBINED digits. The tiled kernel above spends one 16-byte LDS read and four adds per four output words
+// and DIGIT, and both its LDS pipe and its vector pipe run at two thirds of their peaks. D adjacent digits of a coefficient
+// select one of BASE^D sums of KSK rows; those sums are built once per workgroup -- 256 ciphertexts share them -- into a second
+// LDS table, and every lane then does ONE read-and-add per D digits: default-128 (t = 8 digits of 2 bits) takes 4 lookups of 16
+// rows instead of 8 of 4, the (18, 1) keys of the larger sets 5 lookups (4 x 16 rows + 1 x 4) instead of 18 of 2. Wrapping
+// 32-bit sums are exact in any grouping, so the result is the tiled kernel's bit for bit. (The REDsec set's 9 digits of 3 bits
+// would need 64-row groups: building them costs what they save; it stays on the kernel above.)
+// Per group of KS_IG coefficients: base rows global -> s_base (requested before the previous group's lookups), barrier, sums
+// s_base -> s_tab, barrier, lookups.
+// -------------------------------------------------------------------------------------------------
+template <int T, int BASEBIT, int KS_IG, int D>
+__global__ __launch_bounds__(KS_TILE_THREADS) void keyswitch_tiled_comb_kernel(KeyswitchArgs a) {
+  constexpr int BASE = 1 << BASEBIT;
+  constexpr int NG = (T + D - 1) / D;              // lookups per coefficient
+  constexpr int RG = 1 << (BASEBIT * D);           // rows of a full group
+  constexpr int DL = T - (NG - 1) * D;             // digits of the last group (1 ... D)
+  constexpr int BROWS = KS_IG * T * BASE, TROWS = KS_IG * NG * RG;
+  __shared__ __attribute__((aligned(16))) int32_t s_base[BROWS * KS_CHP];
+  __shared__ __attribute__((aligned(16))) int32_t s_tab[TROWS * KS_CHP];
+  const int tid = threadIdx.x;
+  const long ct = (long)blockIdx.x * KS_TILE_THREADS + tid;
+  const bool live = ct < a.B;
+  const int w0 = blockIdx.y * KS_CH;
+  const int W = a.W, N = a.N;
+  const int32_t* u0 = a.u0 + (live ? ct : 0) * (size_t)(N + 1);
+  const int32_t* u1 = a.u1 ? a.u1 + (live ? ct : 0) * (size_t)(N + 1) : nullptr;
+  for (int e = tid; e < BROWS * KS_CHP; e += KS_TILE_THREADS) s_base[e] = 0;   // the v = 0 rows stay zero
+
+  uint32_t acc[KS_CH];
+#pragma unroll
+  for (int k = 0; k < KS_CH; ++k) acc[k] = 0;
+  constexpr uint32_t prec_offset = 1u << (32 - (1 + BASEBIT * T));
+  constexpr int SEGS = KS_IG * T * (BASE - 1);
+  // Base rows of the next group: requested into registers BEFORE the current group's lookups and put into s_base after them, so
+  // that their L2 round trip runs behind the lookups (8 threads x 16 B per row segment; rows are only 4-byte aligned in general)
+  constexpr int NST = (SEGS * 8 + KS_TILE_THREADS - 1) / KS_TILE_THREADS;
+  int32_t st[NST][4];
+  auto stage_load = [&](int i0) {
+#pragma unroll
+    for (int sl = 0; sl < NST; ++sl) {
+      const int sidx = tid + sl * KS_TILE_THREADS;
+      const int seg = sidx >> 3, part = sidx & 7;
+      const int v = seg % (BASE - 1) + 1;
+      const int ij = seg / (BASE - 1);          // ii * T + j
+      const int wq = w0 + part * 4;
+      const int32_t* src = a.ksk + (((size_t)i0 * T + ij) * BASE + v) * (size_t)W + wq;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) st[sl][e] = (sidx < SEGS * 8 && wq + e < W) ? src[e] : 0;
+    }
+  };
+  auto stage_store = [&]() {
+#pragma unroll
+    for (int sl = 0; sl < NST; ++sl) {
+      const int sidx = tid + sl * KS_TILE_THREADS;
+      if (sidx < SEGS * 8) {
+        const int seg = sidx >> 3, part = sidx & 7;
+        const int v = seg % (BASE - 1) + 1;
+        const int ij = seg / (BASE - 1);
+        *reinterpret_cast<int4*>(&s_base[(ij * BASE + v) * KS_CHP + part * 4]) = make_int4(st[sl][0], st[sl][1], st[sl][2], st[sl][3]);
+      }
+    }
+  };
+  // row `comb` of group gq of coefficient ii = the sum over the group's digits k of base row (ii, gq D + k, digit k of comb),
+  // digit 0 the most significant (as it sits in the coefficient)
+  auto build = [&]() {
+#pragma unroll 2
+    for (int item = tid; item < TROWS * 8; item += KS_TILE_THREADS) {
+      const int part = item & 7, r = item >> 3;
+      const int comb = r % RG, igq = r / RG, gq = igq % NG, ii = igq / NG;
+      const int dl = gq == NG - 1 ? DL : D;
+      if (comb >> (BASEBIT * dl)) continue;       // rows a short last group never selects
+      int4 sum = make_int4(0, 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        if (k < dl) {
+          const int dgt = (comb >> (BASEBIT * (dl - 1 - k))) & (BASE - 1);
+          const int4 v = *reinterpret_cast<const int4*>(&s_base[((ii * T + gq * D + k) * BASE + dgt) * KS_CHP + part * 4]);
+          sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+      }
+      *reinterpret_cast<int4*>(&s_tab[r * KS_CHP + part * 4]) = sum;
+    }
+  };
+
+  const int groups_per_split = (N / KS_IG) / (int)gridDim.z;
+  const int g_begin = (int)blockIdx.z * groups_per_split, g_end = g_begin + groups_per_split;
+  __syncthreads();
+  stage_load(g_begin * KS_IG);
+  stage_store();
+  __syncthreads();
+  build();
+  __syncthreads();
+  for (int g = g_begin; g < g_end; ++g) {
+    if (g + 1 < g_end) stage_load((g + 1) * KS_IG);
+    const int i0 = g * KS_IG;
+    uint32_t ai[KS_IG];
+#pragma unroll
+    for (int ii = 0; ii < KS_IG; ++ii) {
+      uint32_t v = live ? (uint32_t)u0[i0 + ii] : 0u;
+      if (u1 && live) v += (uint32_t)u1[i0 + ii];
+      ai[ii] = live ? v + prec_offset : 0u;
+    }
+#pragma unroll 1
+    for (int ii = 0; ii < KS_IG; ++ii) {
+#pragma unroll
+      for (int gq = 0; gq < NG; ++gq) {
+        constexpr int dl_full = D;
+        const int dl = gq == NG - 1 ? DL : dl_full;
+        const uint32_t comb = (ai[ii] >> (32 - (gq * D + dl) * BASEBIT)) & ((1u << (BASEBIT * dl)) - 1u);
+        const int4* row = reinterpret_cast<const int4*>(&s_tab[((ii * NG + gq) * RG + (int)comb) * KS_CHP]);
+#pragma unroll
+        for (int q = 0; q < KS_CH / 4; ++q) {
+          const int4 r = row[q];
+          acc[4 * q + 0] += (uint32_t)r.x;
+          acc[4 * q + 1] += (uint32_t)r.y;
+          acc[4 * q + 2] += (uint32_t)r.z;
+          acc[4 * q + 3] += (uint32_t)r.w;
+        }
+      }
+    }
+    if (g + 1 < g_end) stage_store();   // s_base is free: its sums were built before the last barrier
+    __syncthreads();   // the next base rows are in s_base; every lane has finished with s_tab
+    if (g + 1 < g_end) build();
+    __syncthreads();   // the next sums are in s_tab; s_base is free
+  }
+  if (!live) return;
+  ks_tile_finish(a, acc, ct, w0, u0, u1);
 }
 
 // Sliced keyswitch, second step: out[ct][w] = (w == n ? b word : 0) - sum over slices of scratch[slice][w][ct]. A workgroup
@@ -469,12 +621,17 @@ hipError_t launch_keyswitch(const KeyswitchArgs& a_in, hipStream_t st) {
     hipError_t e = hipMemsetAsync(a.out, 0, (size_t)a.B * a.W * sizeof(int32_t), st);
     if (e != hipSuccess) return e;
   }
+#ifndef RS_KS_COMB
+#define RS_KS_COMB 1   // 0: one LDS lookup per digit everywhere (A/B)
+#endif
   if (tiled && a.t == 8) {
-    hipLaunchKernelGGL((keyswitch_tiled_kernel<8, 2, 4>), grid, dim3(KS_TILE_THREADS), 0, st, a);
+    if (RS_KS_COMB) hipLaunchKernelGGL((keyswitch_tiled_comb_kernel<8, 2, 4, 2>), grid, dim3(KS_TILE_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((keyswitch_tiled_kernel<8, 2, 4>), grid, dim3(KS_TILE_THREADS), 0, st, a);
   } else if (tiled && a.t == 9) {
     hipLaunchKernelGGL((keyswitch_tiled_kernel<9, 3, 2>), grid, dim3(KS_TILE_THREADS), 0, st, a);
   } else if (tiled) {
-    hipLaunchKernelGGL((keyswitch_tiled_kernel<18, 1, 4>), grid, dim3(KS_TILE_THREADS), 0, st, a);
+    if (RS_KS_COMB) hipLaunchKernelGGL((keyswitch_tiled_comb_kernel<18, 1, 4, 4>), grid, dim3(KS_TILE_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((keyswitch_tiled_kernel<18, 1, 4>), grid, dim3(KS_TILE_THREADS), 0, st, a);
   } else {
     // generic gather form: any ring degree, any (t, basebit), any sample width
     const unsigned wy = (unsigned)((a.W + KS_THREADS * KS_MAXR - 1) / (KS_THREADS * KS_MAXR));
