@@ -1038,6 +1038,20 @@ long rs_emu_coop8_row_split_violations(int L) {
   return bad;
 }
 
+// keyswitch with combined digits: for the word `aibar` and a (t, basebit, D) shape, the number of (group, k) positions whose
+// digit, recovered from the group's row index, differs from the digit the per-digit kernel extracts (must be 0), plus groups whose
+// row index leaves the table
+long rs_emu_ks_comb_violations(uint32_t aibar, int t, int basebit, int D) {
+  long bad = 0;
+  const int NG = (t + D - 1) / D, DL = t - (NG - 1) * D;
+  for (int gq = 0; gq < NG; ++gq) {
+    const int dl = gq == NG - 1 ? DL : D;
+    const uint32_t comb = rs::ks_comb_index(aibar, gq, D, dl, basebit);
+    bad += comb >= (1u << (basebit * dl));
+    for (int k = 0; k < dl; ++k) bad += (uint32_t)rs::ks_comb_digit((int)comb, k, dl, basebit) != rs::ks_digit(aibar, gq * D + k, basebit);
+  }
+  return bad;
+}
 // slices of a small-batch keyswitch launch and the scratch they need (rs_host.h)
 long rs_emu_keyswitch_slices(long B, int W, int N) { return (long)rs::keyswitch_slices(B, W, N); }
 long rs_emu_keyswitch_scratch_words(long B, int W, int N) { return (long)rs::keyswitch_scratch_words_for(B, W, N); }

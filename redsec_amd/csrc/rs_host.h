@@ -55,6 +55,24 @@ inline std::vector<SliceCopy> exchange_schedule(size_t rows, int n) {
 // A tiled keyswitch launch is (ceil(B / 256) ciphertext blocks) x (ceil(W / 32) word blocks) workgroups; a small batch cuts the N
 // input coefficients into `slices` (a power of two, at most 64, at least 4 staging groups... coefficients each) until about 1,024
 // workgroups exist. Each slice leaves its partial sums in a scratch of slices x W x B words, which the reduce kernel adds up.
+// ---- keyswitch with combined digits (keyswitch_tiled_comb_kernel): the index arithmetic, shared with the host test --------
+// A coefficient a-bar (the extracted word plus the rounding offset) carries t digits of basebit bits, digit 0 the most
+// significant. Lookup group gq covers the digits [gq D, gq D + dl), dl = D except for a shorter last group.
+//   ks_comb_index: the group's table row = its dl digits read as one number (digit gq D in the top bits)
+//   ks_comb_digit: digit k of that row index, i.e. which base row (gq D + k, digit) the sum contains
+#ifndef RS_HD
+#ifdef __HIPCC__
+#define RS_HD __host__ __device__ inline
+#else
+#define RS_HD inline
+#endif
+#endif
+RS_HD constexpr uint32_t ks_digit(uint32_t aibar, int j, int basebit) { return (aibar >> (32 - (j + 1) * basebit)) & ((1u << basebit) - 1u); }
+RS_HD constexpr uint32_t ks_comb_index(uint32_t aibar, int gq, int D, int dl, int basebit) {
+  return (aibar >> (32 - (gq * D + dl) * basebit)) & ((1u << (basebit * dl)) - 1u);
+}
+RS_HD constexpr int ks_comb_digit(int comb, int k, int dl, int basebit) { return (comb >> (basebit * (dl - 1 - k))) & ((1 << basebit) - 1); }
+
 inline unsigned keyswitch_slices(long B, int W, int N) {
   if (B <= 0) return 1;
   const unsigned gx = (unsigned)((B + 255) / 256), gy = (unsigned)((W + 31) / 32);

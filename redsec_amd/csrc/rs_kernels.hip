@@ -279,7 +279,7 @@ __global__ __launch_bounds__(KS_TILE_THREADS) void keyswitch_tiled_comb_kernel(K
 #pragma unroll
       for (int k = 0; k < D; ++k) {
         if (k < dl) {
-          const int dgt = (comb >> (BASEBIT * (dl - 1 - k))) & (BASE - 1);
+          const int dgt = ks_comb_digit(comb, k, dl, BASEBIT);   // rs_host.h (host-tested)
           const int4 v = *reinterpret_cast<const int4*>(&s_base[((ii * T + gq * D + k) * BASE + dgt) * KS_CHP + part * 4]);
           sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
         }
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(KS_TILE_THREADS) void keyswitch_tiled_comb_kernel(K
       for (int gq = 0; gq < NG; ++gq) {
         constexpr int dl_full = D;
         const int dl = gq == NG - 1 ? DL : dl_full;
-        const uint32_t comb = (ai[ii] >> (32 - (gq * D + dl) * BASEBIT)) & ((1u << (BASEBIT * dl)) - 1u);
+        const uint32_t comb = ks_comb_index(ai[ii], gq, D, dl, BASEBIT);
         const int4* row = reinterpret_cast<const int4*>(&s_tab[((ii * NG + gq) * RG + (int)comb) * KS_CHP]);
 #pragma unroll
         for (int q = 0; q < KS_CH / 4; ++q) {

@@ -328,3 +328,19 @@ def test_keyswitch_slicing_rule():
         if W >= 351:                                                          # (a toy width has a single word block: even 65,536 ciphertexts are sliced)
             assert L.rs_emu_keyswitch_slices(65536, W, N) == 1
     assert L.rs_emu_keyswitch_slices(196, 351, 1024) == 64 and L.rs_emu_keyswitch_slices(1024, 351, 1024) == 32
+
+
+def test_keyswitch_combined_digit_index_recovers_every_digit():
+    """keyswitch_tiled_comb_kernel looks up ONE row per D digits: the row index of a group must decompose into exactly the digits the
+    per-digit kernel extracts from the same word, in the order the table builder adds the base rows up (rs_host.h: ks_comb_index /
+    ks_comb_digit, the functions the kernel calls), and stay inside the group's table -- for the three shipped key shapes and the
+    D each one could use."""
+    L = emu_lib.lib()
+    L.rs_emu_ks_comb_violations.restype = ctypes.c_long
+    L.rs_emu_ks_comb_violations.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    rng = np.random.default_rng(5)
+    words = [0, 0xFFFFFFFF, 0x80000000, 0x7FFFFFFF, 1] + [int(x) for x in rng.integers(0, 2**32, 300)]
+    for t, basebit, ds in ((8, 2, (1, 2, 3, 4)), (18, 1, (1, 2, 4, 5)), (9, 3, (1, 2, 3))):
+        for D in ds:
+            for w in words:
+                assert L.rs_emu_ks_comb_violations(w, t, basebit, D) == 0, (t, basebit, D, hex(w))
