@@ -509,9 +509,12 @@ def test_rccl_gather_world_size_one():
     assert r.returncode == 0 and "rccl world-1 ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-def test_sliced_keyswitch_two_step_equals_the_atomics_form_and_the_oracle(monkeypatch):
-    """lweKeySwitch at the batch sizes of the latency forms, on REDsec's shipped shape at its full size (N = 1024, t = 9,
-    basebit = 3, W = 351: 11 word blocks, 64 ... 4 input slices): the two-step form (every slice leaves its partial sums in a
+@pytest.mark.parametrize("set_name", ["redsec_small_v2", "default128", "redsec_small"])
+def test_sliced_keyswitch_two_step_equals_the_atomics_form_and_the_oracle(monkeypatch, set_name):
+    """lweKeySwitch at the batch sizes of the latency forms, on the three tiled key shapes at their full size -- REDsec's shipped
+    set (N = 1024, t = 9, basebit = 3, W = 351: 11 word blocks, 64 ... 4 input slices; one LDS lookup per digit), default-128
+    (t = 8, basebit = 2, W = 631) and redsec_params_small (t = 18, basebit = 1, W = 501), the two shapes of the combined-digit
+    kernel (keyswitch_tiled_comb_kernel: sums of 2 / 4 digits' rows built per workgroup in LDS): the two-step form (every slice leaves its partial sums in a
     per-stream scratch laid out [slice][word][ciphertext], keyswitch_reduce_kernel adds them up and transposes) against the
     round-1 form (RS_KS_ATOMICS=1: the slices meet by integer atomics in a zeroed output) on WHOLE batches, and against the
     oracle's lweKeySwitch on sampled rows. Batch sizes on both sides of every slice-count change, ragged against the 256-lane
@@ -519,11 +522,11 @@ def test_sliced_keyswitch_two_step_equals_the_atomics_form_and_the_oracle(monkey
     import torch
     import redsec_amd
     seed = 0xabc123
-    p = ol.params("redsec_small_v2")
+    p = ol.params(set_name)
     W, N = p.n + 1, p.N
 
     def backend():
-        be = redsec_amd.Backend(redsec_amd.params("redsec_small_v2"), device=0)
+        be = redsec_amd.Backend(redsec_amd.params(set_name), device=0)
         be.load_synthetic_keys(seed)
         return be
     be = backend()
