@@ -2019,6 +2019,7 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
   const int n = a.n;
   // rows [first, first + cnt) of this wave's component (digit index q = first + rr, TGSW row comp * L + q)
   const int comp = coop8_comp(L, wave), cnt = coop8_row_count(L, wave), first = coop8_row_first(L, wave);
+  [[maybe_unused]] const int r_first = cnt > 0 ? (int)(blockIdx.x % (unsigned)cnt) : 0;
   double dev = 0.0;
   RS_C8_STAMP_DECL;   // -DRS_STAMPS -DRS_STAMPS_COOP8 (tools/stamp_profile.py coop8): 0 mask word, 1 rotated difference, 2 rows (forward +
                       // multiply-accumulate), 3 atomics issued, 4 barrier 1, 5 inverse + accumulator update, 6 barrier 2, 7 prologue / extract
@@ -2057,9 +2058,18 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
 #pragma unroll
       for (int r = 0; r < kRegs; ++r) d[r] = gadget_prepare<C>(rotated_diff(s_acc[comp], lane + 64 * r, bara));
       RS_C8_STAMP(1);
+      [[maybe_unused]] int r_run = r_first;   // rr = 0 starts at blockIdx.x mod cnt in every step
 #pragma unroll 1
       for (int rr = 0; rr < cnt; ++rr) {
+#ifndef RS_COOP8_RUNNING_ROW
+#define RS_COOP8_RUNNING_ROW 1   // the rotated row index kept running instead of a modulo by the run-time row count per row (A/B)
+#endif
+#if RS_COOP8_RUNNING_ROW
+        const int q = first + r_run;                                       // per-workgroup row order, as in the four-wave form
+        r_run = r_run + 1 == cnt ? 0 : r_run + 1;
+#else
         const int q = first + (int)((rr + blockIdx.x) % (unsigned)cnt);   // per-workgroup row order, as in the four-wave form
+#endif
         const double2* bp0 = reinterpret_cast<const double2*>(bk_i + (size_t)((comp * L + q) * 2) * kN);
         const double2* bp1 = bp0 + kN / 2;
         double x[kRegs];
