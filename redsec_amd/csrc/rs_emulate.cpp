@@ -996,6 +996,33 @@ long rs_emu_exchange_schedule(long rows, int n, long* out) {
 }
 // form: 0 coop<2>, 1 coop<4>, 2 / 3 coop8 with the s_part exchange (-DRS_COOP8_ATOMICS=0; l = 10 / 3), 4 coops<2>, 5 coops<4>, 6 duo, 7 duos,
 //       8 wgs<8>, 9 wgs<4>, 10 wg, 11 / 12 coop8 as shipped (sums by LDS atomics; l = 10 / 3)
+// The tiled keyswitch kernels (rs_kernels.hip), four waves. Every wave touches the whole of each LDS table, so all that keeps the
+// protocol sound is which barrier separates which phase:
+//   per-digit kernel (comb = false): group g looks up s_ksk[g & 1]; the next group's rows are stored into s_ksk[(g + 1) & 1]
+//     AFTER the lookups and before the group's one barrier (broken 1: into the buffer being read; broken 2: no barrier);
+//   combined-digit kernel (comb = true): lookups read s_tab, then the next base rows go into s_base, barrier, the next sums are
+//     built s_base -> s_tab, barrier (broken 1: sums built before the first barrier, i.e. while other waves still look up;
+//     broken 2: second barrier missing, lookups of the next group race with the build).
+long model_keyswitch(bool comb, int broken) {
+  LdsModel m;
+  const long base = LdsModel::KEY, tab = LdsModel::PART, bytes = 16384;
+  auto buf = [&](int b) { return base + b * 0x100000L; };
+  for (int g = 0; g < 3; ++g) {
+    if (!comb) {
+      for (int w = 0; w < 4; ++w) m.rd(w, buf(g & 1), bytes);                                   // lookups
+      for (int w = 0; w < 4; ++w) m.wr(w, buf(broken == 1 ? (g & 1) : ((g + 1) & 1)) + w * 4096, 4096);   // next rows, this wave's share
+      if (broken != 2) m.barrier();
+    } else {
+      for (int w = 0; w < 4; ++w) m.rd(w, tab, bytes);                                          // lookups
+      for (int w = 0; w < 4; ++w) m.wr(w, base + w * 4096, 4096);                               // next base rows
+      if (broken == 1) for (int w = 0; w < 4; ++w) { m.rd(w, base, bytes); m.wr(w, tab + w * 4096, 4096); }
+      m.barrier();
+      if (broken != 1) for (int w = 0; w < 4; ++w) { m.rd(w, base, bytes); m.wr(w, tab + w * 4096, 4096); }   // sums of the next group
+      if (broken != 2) m.barrier();
+    }
+  }
+  return m.conflicts();
+}
 long rs_emu_lds_protocol_conflicts(int form, int broken) {
   switch (form) {
     case 0: return model_coop(2, broken);
@@ -1011,6 +1038,8 @@ long rs_emu_lds_protocol_conflicts(int form, int broken) {
     case 10: return model_wg(3, broken);
     case 11: return model_coop8_atomics(10, broken);
     case 12: return model_coop8_atomics(3, broken);
+    case 13: return model_keyswitch(false, broken);
+    case 14: return model_keyswitch(true, broken);
   }
   return -1;
 }

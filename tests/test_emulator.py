@@ -274,10 +274,11 @@ def test_general_path_digits_equal_tfhe_decomposition(l, bgbit):
 
 
 LDS_FORMS = ["coop<2>", "coop<4>", "coop8 s_part exchange (l = 10)", "coop8 s_part exchange (l = 3)", "coops<2>", "coops<4>", "duo", "duos", "wgs<8>",
-             "wgs<4>", "wg<8>", "coop8 as shipped: atomics (l = 10)", "coop8 as shipped: atomics (l = 3)"]
+             "wgs<4>", "wg<8>", "coop8 as shipped: atomics (l = 10)", "coop8 as shipped: atomics (l = 3)",
+             "keyswitch, one lookup per digit (rows stored behind the lookups)", "keyswitch, combined digits (base rows -> sums -> lookups)"]
 # perturbations every form's model knows (rs_emulate.cpp): 1 = one placement / slot-count / hold decision changed the way a
 # plausible edit would change it, 2 = one workgroup barrier dropped, 3 (duo only) = the next quad requested before the swap
-LDS_BROKEN = {0: (1, 2), 1: (1, 2), 2: (1, 2), 3: (1, 2), 4: (1, 2), 5: (1, 2), 6: (1, 2, 3), 7: (1, 2), 8: (1,), 9: (1,), 10: (2,), 11: (1, 2), 12: (1, 2)}
+LDS_BROKEN = {0: (1, 2), 1: (1, 2), 2: (1, 2), 3: (1, 2), 4: (1, 2), 5: (1, 2), 6: (1, 2, 3), 7: (1, 2), 8: (1,), 9: (1,), 10: (2,), 11: (1, 2), 12: (1, 2), 13: (1, 2), 14: (1, 2)}
 
 
 @pytest.mark.parametrize("form", range(len(LDS_FORMS)), ids=LDS_FORMS)
