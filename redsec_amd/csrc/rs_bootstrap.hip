@@ -1612,7 +1612,8 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
   typename Xf::State tw;
   Xf::init(tw, lane, s_tw, a.tw);
 #ifndef RS_DUO_KEEP_TW
-#define RS_DUO_KEEP_TW 9   // as RS_WG_KEEP_TW, for the forward pairs of this kernel: 6 / 3 spill 17 / 56 registers here, no gain on the 1,024-neuron MNIST layer
+#define RS_DUO_KEEP_TW 6   // as RS_WG_KEEP_TW, for the forward pairs of this kernel: the twiddles of the last stage group kept in registers. Round 3: 6 / 3
+                           // spilled 17 / 56 registers, no gain; since the column sums lost their selects (round 4) 6 fits: 7.71 -> 7.67 ms at 1,024 ciphertexts, 3: 7.83
 #endif
   FftTwKept<RS_DUO_KEEP_TW> tw_kept;
   fft_kept_load(tw_kept, tw);

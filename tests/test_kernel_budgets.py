@@ -43,7 +43,7 @@ def _kernels():
 BUDGETS = [
     (r"22blind_rotate_wg_kernelINS_5XfFft.*Li8EEEv", "lock-step kernel (headline): two waves per SIMD, one workgroup per CU", 256, 128, 163840),
     (r"23blind_rotate_wgs_kernel.*Li8EEEv", "split lock-step kernel: no scratch access inside the CMUX loop since the lean key requests (88 B outside)", 256, 96, 163840),
-    (r"23blind_rotate_duo_kernel", "duo kernel", 256, 32, 163840),
+    (r"23blind_rotate_duo_kernel", "duo kernel (80 B with the last stage group's twiddles kept in registers: all outside the CMUX loop)", 256, 96, 163840),
     (r"24blind_rotate_duos_kernel", "split duo kernel", 256, 48, 163840),
     (r"25blind_rotate_coop8_kernel", "coop8: eight waves of one ciphertext", 256, 16, 163840),
     (r"19blind_rotate_kernelINS_5XfNtt.*Li8EEEv", "exact-NTT per-wave kernel: 8 waves fill the LDS", 256, 128, 163840),
