@@ -61,6 +61,78 @@ def _oracle_stage(octx, rec, rows):
     return octx.bootstrap_batch(ins[0], rec["mu"])
 
 
+def _check_linear_stages(taps, net, image_ct, out, maxpool, rng):
+    """The LINEAR stage between every two bootstrapped stages of the run, word for word against the numpy restatement of
+    lib/BinFunc.cpp:217-320,373-402,677-732 (tests/linear_check.py) at the REAL shapes of nets/cifar/binarynet/net.cpp:114-209
+    (32x32x3 -> 128 ... 8x8x512 -> 512, K up to 4,608; FC 8192 -> 1024 -> 1024 -> 10): each stage's input slab is recomputed from
+    the previous stage's output slab at >= 64 outputs -- image corners, edges, interior; first / last channel and both sides
+    of the kernel's 32-channel tile boundaries -- so that a wrong border tap, a wrong filter index or a wrong bias in ONE
+    layer fails here even where the decrypted class would survive it. Returns the number of ciphertexts compared."""
+    import linear_check as lc
+    from redsec_amd.nets import MnistSignNet
+    tor = MnistSignNet.bias_to_torus
+    it = iter(taps)
+    n = 0
+
+    def same(slab, flat, want, what):
+        nonlocal n
+        got = lc.rows(slab, flat)
+        assert np.array_equal(lc.wrap32(got), want), what
+        n += len(flat)
+
+    # IntLayer(NO_CONV, SIGN): Quantize::execute adds bias[i % depth] (lib/IntFunc.cpp:871-887)
+    rec = next(it)
+    one = dict(H=32, Wd=32, C=3, win_h=1, win_w=1, stride_h=1, stride_w=1, off_h=0, off_w=0, Ho=32, Wo=32)
+    outs = [(int(rng.integers(32)), int(rng.integers(32)), c) for c in range(3) for _ in range(22)] + [(0, 0, 0), (31, 31, 2)]
+    same(rec["inputs"][0], *lc.sumpool_outputs(image_ct, one, tor(net.bias0), outs), rec["name"])
+    prev, H, C = rec["out"], 32, 3
+    for li, (sign, zero, bias) in enumerate(net.convs):
+        Cout = sign.shape[3]
+        shape = dict(H=H, Wd=H, Cin=C, Cout=Cout, fh=3, fw=3, stride_h=1, stride_w=1, off_h=1, off_w=1, Ho=H, Wo=H)
+        rec = next(it)
+        assert rec["name"] == "conv%d" % (li + 1)
+        same(rec["inputs"][0], *lc.conv_outputs(prev, shape, sign, zero, tor(bias), lc.spread_outputs(H, H, Cout, rng)), rec["name"])
+        prev, C = rec["out"], Cout
+        if li % 2 == 1 and maxpool == "fused":
+            # the OR of a 2x2 window as ONE bootstrap of the windowed sum + 3/16 (DESIGN.md section 7)
+            win = dict(H=H, Wd=H, C=C, win_h=2, win_w=2, stride_h=2, stride_w=2, off_h=0, off_w=0, Ho=H // 2, Wo=H // 2)
+            rec = next(it)
+            assert rec["name"] == "maxpool%d" % (li + 1)
+            outs = [(ph, pw, od) for ph, pw, od in lc.spread_outputs(H // 2, H // 2, C, rng)]
+            same(rec["inputs"][0], *lc.sumpool_outputs(prev, win, np.array([3 << 28], np.int64), outs), rec["name"])
+            prev, H = rec["out"], H // 2
+        elif li % 2 == 1:
+            # MaxPooling::execute (lib/BinFunc.cpp:896-921): the window's taps in (fh, fw) order, OR-ed one by one
+            Ho = H // 2
+            outs = lc.spread_outputs(Ho, Ho, C, rng)
+            flat = np.array([(oh * Ho + ow) * C + c for oh, ow, c in outs], np.int64)
+            src = lambda fh, fw: np.array([((2 * oh + fh) * H + (2 * ow + fw)) * C + c for oh, ow, c in outs], np.int64)
+            acc = None
+            for tp, (fh, fw) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+                if tp == 0:
+                    continue
+                rec = next(it)
+                assert rec["name"] == "maxpool%d_or%d" % (li + 1, tp)
+                first = lc.wrap32(lc.rows(prev, src(0, 0))) if tp == 1 else lc.wrap32(lc.rows(acc, flat))
+                same(rec["inputs"][0], flat, first, rec["name"] + " a")
+                same(rec["inputs"][1], flat, lc.wrap32(lc.rows(prev, src(fh, fw))), rec["name"] + " b")
+                acc = rec["out"]
+            prev, H = acc, Ho
+    for i, (sign, zero, bias) in enumerate(net.fcs):
+        M = sign.shape[1]
+        ms = sorted({0, M - 1, 31, 32, 33, M // 2} & set(range(M)) | {int(v) for v in rng.integers(0, M, 64)}) if M > 10 else range(M)
+        flat, want = lc.fc_outputs(prev, sign, zero, tor(bias), ms)
+        if i == len(net.fcs) - 1:
+            same(out, flat, want, "logits")                           # Quantize::add_bias, lib/BinFunc.cpp:1085-1107
+        else:
+            rec = next(it)
+            assert rec["name"] == "fc%d" % (i + 1)
+            same(rec["inputs"][0], flat, want, rec["name"])
+            prev = rec["out"]
+    assert next(it, None) is None
+    return n
+
+
 @pytest.mark.parametrize("maxpool", ["fused", "chain"])
 def test_binarynet_full_every_bootstrapped_stage_against_the_oracle(maxpool):
     """nets/cifar/binarynet/net.cpp:114-209 (the reference's widths 128-128-256-256-512-512, FC 1024-1024-10), one
@@ -109,6 +181,9 @@ def test_binarynet_full_every_bootstrapped_stage_against_the_oracle(maxpool):
         assert np.array_equal(rec["out"][more].cpu().numpy(), _oracle_stage(octx, rec, more)), (rec["name"], "fft path")
         checked += len(first) + len(more)
     assert checked >= 100 * len(taps)
+    # ... and the linear stage that produced each of those input slabs
+    n_lin = _check_linear_stages(taps, net, ct, out, maxpool, rng)
+    assert n_lin >= 64 * (len(taps) + 1)
     assert be.rounding_certificate() < 0.2 and be.fft_fallbacks() == 0
     # decrypt level, EVERY row of every stage: wherever the stage's (pre-combined) input phase is at least 32 message steps
     # away from both decision boundaries, the output decrypts to sign(input) * mu within half of mu (SURVEY.md hard part 7:
@@ -156,4 +231,28 @@ def test_binarynet_full_every_bootstrapped_stage_against_the_oracle(maxpool):
         assert torch.equal(a["out"], b["out"]), a["name"]
     assert torch.equal(out, out_s)
     be.sync()                                                    # an enforced split certificate would surface here
+    be.close()
+
+
+def test_convolution_whole_map_at_a_cifar_shape_both_constant_sets():
+    """rs_conv_ternary_dev at 16x16x128 -> 128 (conv3's input map with conv1's widths; K = 1,152), EVERY output word against
+    the numpy checker: once with the BinFunc constants (zero and padding taps add nothing: the register-tiled kernel, the one
+    every CIFAR layer runs) and once with IntFunc's (zero_tap_b = pad_tap_b = -1/4096, lib/IntFunc.cpp:268,277: the
+    one-output-per-thread kernel with its mask path), ternary density as in the trained weights."""
+    import torch
+    import redsec_amd
+    import linear_check as lc
+    be = redsec_amd.Backend(redsec_amd.params("redsec_small_v2", n=140), 0)      # W = 141: one full 128-word block + a ragged one
+    rng = np.random.default_rng(17)
+    H, Cin, Cout = 16, 128, 128
+    shape = dict(H=H, Wd=H, Cin=Cin, Cout=Cout, fh=3, fw=3, stride_h=1, stride_w=1, off_h=1, off_w=1, Ho=H, Wo=H)
+    x = rng.integers(-2**31, 2**31, (H, H, Cin, be.W)).astype(np.int32)
+    sign = rng.integers(0, 2, (3, 3, Cin, Cout)).astype(np.uint8)
+    zero = (rng.random((3, 3, Cin, Cout)) < 0.35).astype(np.uint8)
+    bias = rng.integers(-2**31, 2**31, Cout).astype(np.int32)
+    g = lambda a: torch.from_numpy(a).cuda()
+    for zb, pb in ((0, 0), (-(1 << 20), -(1 << 20))):
+        got = be.conv_ternary(g(x), g(sign), g(zero), shape, zero_tap_b=zb, pad_tap_b=pb, bias_b=g(bias)).cpu().numpy()
+        want = lc.conv_full(x, shape, sign, zero, bias, zb, pb)
+        assert np.array_equal(got.reshape(want.shape), want), (zb, pb)
     be.close()
