@@ -83,3 +83,53 @@ class OverlappedGather:
     def wait(handle):
         if handle is not None:
             handle.wait()
+
+
+def image_assignment(n_images, rank, world):
+    """Images of an image-parallel batch this rank runs: r, r + world, r + 2 world ... (BASELINE configs[4]: 8 images on
+    8 GPUs = one each). The reference's shape is enc_segs[NUM_GPUS], one host thread per GPU and no merge step
+    (lib/GPU/Layer.cuh:15,22-37, nets/mnist/sign1024x1/main.cu:81-83); here the ranks are processes and the merge is the
+    gather below."""
+    return list(range(int(rank), int(n_images), int(world)))
+
+
+def image_parallel(run_image, images, out_shape, group=None, force=False):
+    """Image-parallel replicas (partitioning 1): every rank holds a full key replica and runs
+    `run_image(images[i])` -> int32 [classes][W] (the logit ciphertexts, on the rank's device) for the images
+    image_assignment gives it; the only exchange is ONE all-gather of classes x W words per image at the end (10 x 351 words
+    = 14 KB for a CIFAR image: latency-bound, which is why it is a single collective). Returns (logits int32
+    [n_images][classes][W] in image order, identical on every rank; this rank's seconds of compute before the collective;
+    seconds in the collective). `images`: a sequence every rank can index (a rank touches only its own); `out_shape` =
+    (classes, W), known to a rank even when it has no image of a short batch. Without an initialised process group (or one
+    rank and not `force`) it is the plain loop."""
+    import time
+    n = len(images)
+    on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if on else 1
+    rank = dist.get_rank(group) if on else 0
+    mine = image_assignment(n, rank, world)
+    t0 = time.perf_counter()
+    outs = [run_image(images[i]) for i in mine]
+    if outs and outs[0].is_cuda:
+        torch.cuda.synchronize(outs[0].device)
+    t_compute = time.perf_counter() - t0
+    if world == 1 and not force:
+        return torch.stack(outs), t_compute, 0.0
+    t1 = time.perf_counter()
+    per_rank = -(-n // world)                                   # slots per rank; a short rank pads with zeros
+    shape = tuple(int(v) for v in out_shape)
+    assert all(tuple(o.shape) == shape for o in outs)
+    dev = outs[0].device if outs else torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    via_host = dev.type == "cuda" and dist.get_backend(group) == "gloo"
+    buf_dev = torch.device("cpu") if via_host else dev
+    local = torch.zeros((per_rank,) + shape, dtype=torch.int32, device=buf_dev)
+    for k, o in enumerate(outs):
+        local[k] = o.cpu() if via_host else o
+    full = torch.empty((world * per_rank,) + shape, dtype=torch.int32, device=buf_dev)
+    dist.all_gather_into_tensor(full, local, group=group)
+    if full.is_cuda:
+        torch.cuda.synchronize(full.device)
+    full = full.view((world, per_rank) + shape)
+    # slot k of rank r is image r + k * world
+    out = torch.stack([full[i % world, i // world] for i in range(n)])
+    return out.to(dev), t_compute, time.perf_counter() - t1

@@ -256,3 +256,44 @@ def test_convolution_whole_map_at_a_cifar_shape_both_constant_sets():
         want = lc.conv_full(x, shape, sign, zero, bias, zb, pb)
         assert np.array_equal(got.reshape(want.shape), want), (zb, pb)
     be.close()
+
+
+def test_image_parallel_two_ranks_one_device(tmp_path):
+    """BASELINE configs[4] (a batch of encrypted CIFAR images, one per GPU, logits gathered) rehearsed on ONE device: two
+    rank processes under torch.distributed.run (gloo; tests/cifar_batch_ranks.py) push a batch of two -- then of three:
+    a ragged batch, rank 0 takes two images -- binarynet_small images through sharding.image_parallel, the path bench.py's
+    `cifar_batch` leg times; the gathered logit ciphertexts must equal, word for word, what ONE process computes for the same
+    images with the same key (this process, below): a bootstrap's output depends on its own input and the key only, so which
+    rank ran an image cannot show. The reference's shape: enc_segs[NUM_GPUS], one host thread per device, no merge
+    (lib/GPU/Layer.cuh:15,22-37)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    import torch
+    import redsec_amd
+    from redsec_amd import client, nets
+    here = os.path.dirname(os.path.abspath(__file__))
+    got = {}
+    for n_images in (2, 3):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        path = str(tmp_path / ("gathered%d.npy" % n_images))
+        env = dict(os.environ, REDSEC_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), os.path.join(here, "cifar_batch_ranks.py"), path, "binarynet_small", str(n_images)],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=420)
+        assert r.returncode == 0, r.stdout[-3000:]
+        got[n_images] = np.load(path)
+    sk = client.SecretKeySet("redsec_small_v2", seed=19)
+    be = redsec_amd.Backend(redsec_amd.params("redsec_small_v2"), 0)
+    be.load_keys(sk.bk, sk.ksk)
+    enc = nets.EncryptedCifar(be, pm.CifarNet("binarynet_small"))
+    labels, pix = pm.load_cifar_images()
+    want = np.stack([enc.run(torch.from_numpy(sk.encrypt_image(pix[(k + 1) % len(pix)], seed=100 + (k + 1) % len(pix))).cuda()).cpu().numpy() for k in range(3)])
+    assert got[2].shape == (2, 10, be.W) and got[3].shape == (3, 10, be.W)
+    assert np.array_equal(got[3], want) and np.array_equal(got[2], want[:2])
+    # the gathered ciphertexts decrypt to this key's logits (image 1 has the clearest plaintext margin of the bundle)
+    logits = sk.decrypt_ints(got[3][0])
+    plain = pm.cifar_forward(pm.CifarNet("binarynet_small"), pix[1])
+    assert np.corrcoef(logits, plain)[0, 1] > 0.5
+    be.close()

@@ -232,3 +232,47 @@ def test_exchange_plan_orders_every_copy_and_falls_back_to_host_staging():
                     assert all((ctx, e) in copies for e in range(n) if e != ctx and spans[e][1] > spans[e][0])
             assert copies == {(d, e) for d in range(n) for e in range(n) if d != e and spans[e][1] > spans[e][0]}
             assert sum(1 for o in ops if o[0] == RECORD_COPIED) == n
+
+
+def _image_worker(rank, world, port, n_images, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        images = [torch.full((10, 5), 7 * i + 1, dtype=torch.int32) for i in range(n_images)]
+        ran = []
+
+        def run_image(x):
+            ran.append(int(x[0, 0]))
+            return x * 3 - 2                                # stands in for a whole encrypted network
+        got, t_c, t_g = sharding.image_parallel(run_image, images, (10, 5))
+        ok = torch.equal(got, torch.stack([x * 3 - 2 for x in images]))
+        ok = ok and ran == [7 * i + 1 for i in sharding.image_assignment(n_images, rank, world)] and t_c >= 0 and t_g >= 0
+        flag = torch.tensor([1 if ok else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            ret.put(int(flag.item()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_images", [2, 5, 1])           # one each (configs[4]'s shape), a ragged batch, a rank without an image
+def test_image_parallel_replicas_gloo(n_images):
+    """BASELINE configs[4] on the CPU: image-parallel replicas over two gloo ranks, the logits gathered in image order."""
+    assert sharding.image_assignment(8, 3, 8) == [3] and sharding.image_assignment(5, 1, 2) == [1, 3]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_image_worker, args=(r, 2, port, n_images, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) == 1
+
+
+def test_image_parallel_without_a_process_group_is_the_plain_loop():
+    images = [torch.full((10, 3), i, dtype=torch.int32) for i in range(3)]
+    got, _, t_g = sharding.image_parallel(lambda x: x + 1, images, (10, 3))
+    assert torch.equal(got, torch.stack(images) + 1) and t_g == 0.0
