@@ -82,11 +82,10 @@ def host_cpu_share():
     return n
 
 
-def live_traffic(args, kernel_name):
-    """Fabric-side bytes of ONE launch of the dominant kernel, measured now: rocprofv3 --pmc cannot be collected from inside a
-    process, so two child runs (FETCH_SIZE, WRITE_SIZE: separate passes, counters only, as MI355X_MICROARCH.md prescribes) execute
-    one step of the same workload on the same GPU; FETCH_SIZE (KiB) is doubled (the guide's gfx950 correction for wide coalesced
-    reads), WRITE_SIZE is in KiB. Returns None (and says why on stderr) when rocprofv3 is missing or a pass fails."""
+def pmc_child(args, kernel_name, counters):
+    """ONE rocprofv3 --pmc pass (counters only, as MI355X_MICROARCH.md prescribes: never together with a trace) over a child
+    run of one step of the same workload on the same GPU; returns {counter: value of the largest dispatch of exactly the timed
+    kernel form} or None (and says why on stderr) when rocprofv3 is missing or the pass fails."""
     import csv
     import glob
     import shutil
@@ -94,40 +93,127 @@ def live_traffic(args, kernel_name):
     import subprocess
     import tempfile
     if not shutil.which("rocprofv3"):
-        print("bench.py: rocprofv3 not on PATH, roofline.traffic falls back to the committed profile", file=sys.stderr)
+        print("bench.py: rocprofv3 not on PATH", file=sys.stderr)
         return None
-    vals = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        out = tempfile.mkdtemp(prefix="redsec_pmc_", dir="/tmp")
-        cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
-               "--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--no-exact-check", "--no-mnist", "--no-cifar", "--no-live-traffic",
-               "--params", args.params, "--mode", args.mode, "--gates", str(args.gates), "--seed", str(args.seed)]
-        env = dict(os.environ, TMPDIR="/tmp", REDSEC_BENCH_PMC_CHILD="1")
+    out = tempfile.mkdtemp(prefix="redsec_pmc_", dir="/tmp")
+    cmd = ["rocprofv3", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+           "--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--no-exact-check", "--no-mnist", "--no-cifar", "--no-live-traffic",
+           "--params", args.params, "--mode", args.mode, "--gates", str(args.gates), "--seed", str(args.seed)]
+    env = dict(os.environ, TMPDIR="/tmp", REDSEC_BENCH_PMC_CHILD="1")
+    try:
+        # own session: on a timeout the WHOLE process group goes (rocprofv3 and the bench child that holds the GPU)
+        proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
         try:
-            # own session: on a timeout the WHOLE process group goes (rocprofv3 and the bench child that holds the GPU)
-            proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
-            try:
-                proc.communicate(timeout=120)
-            except subprocess.TimeoutExpired:
-                os.killpg(proc.pid, signal.SIGKILL)
-                proc.communicate()
-                raise
-            rows = [row for f in sorted(glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)) for row in csv.DictReader(open(f))]
-            # the dispatches of exactly the timed kernel form (the gated exact-NTT recomputation is another blind_rotate_* kernel);
-            # one step = one such dispatch, or two when the launcher cuts a last round off: the largest one is the launch priced
+            proc.communicate(timeout=120)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+            proc.communicate()
+            raise
+        rows = [row for f in sorted(glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)) for row in csv.DictReader(open(f))]
+        # the dispatches of exactly the timed kernel form (the gated exact-NTT recomputation is another blind_rotate_* kernel);
+        # one step = one such dispatch, or two when the launcher cuts a last round off: the largest one is the launch priced
+        vals = {}
+        for counter in counters:
             hit = [float(row["Counter_Value"]) for row in rows
                    if row["Counter_Name"] == counter and row["Kernel_Name"].split("<")[0].split("(")[0].strip().endswith(kernel_name)]
             if proc.returncode != 0 or not hit:
-                print("bench.py: rocprofv3 --pmc %s pass failed (rc %d, %d rows), roofline.traffic falls back to the committed profile"
-                      % (counter, proc.returncode, len(rows)), file=sys.stderr)
+                print("bench.py: rocprofv3 --pmc %s pass failed (rc %d, %d rows)" % (counter, proc.returncode, len(rows)), file=sys.stderr)
                 return None
             vals[counter] = max(hit)
-        except Exception as e:              # noqa: BLE001 -- a profiler problem must not fail the benchmark
-            print("bench.py: rocprofv3 --pmc %s pass: %s" % (counter, e), file=sys.stderr)
+        keep = os.environ.get("REDSEC_BENCH_KEEP_PMC")      # a directory: the raw counter rows of the timed kernel are copied there (profiles/)
+        if keep:
+            os.makedirs(keep, exist_ok=True)
+            with open(os.path.join(keep, "bench_pmc_%s.csv" % "_".join(counters)[:80]), "w") as f:
+                f.write("Kernel_Name,Counter_Name,Counter_Value\n")
+                for row in rows:
+                    f.write("\"%s\",%s,%s\n" % (row["Kernel_Name"], row["Counter_Name"], row["Counter_Value"]))
+        return vals
+    except Exception as e:              # noqa: BLE001 -- a profiler problem must not fail the benchmark
+        print("bench.py: rocprofv3 --pmc %s pass: %s" % (" ".join(counters), e), file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def live_traffic(args, kernel_name):
+    """Fabric-side bytes of ONE launch of the dominant kernel, measured now: rocprofv3 --pmc cannot be collected from inside a
+    process, so two child runs (FETCH_SIZE, WRITE_SIZE: separate passes, counters only, as MI355X_MICROARCH.md prescribes) execute
+    one step of the same workload on the same GPU; FETCH_SIZE (KiB) is doubled (the guide's gfx950 correction for wide coalesced
+    reads), WRITE_SIZE is in KiB. Returns None when rocprofv3 is missing or a pass fails (the committed profile's figure is
+    reported instead, labelled as such)."""
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        v = pmc_child(args, kernel_name, [counter])
+        if v is None:
             return None
-        finally:
-            shutil.rmtree(out, ignore_errors=True)
+        vals.update(v)
     return int(2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024)
+
+
+# LDS instructions of the lock-step kernel per wave and CMUX step (csrc/rs_bootstrap.hip blind_rotate_wg_kernel; counted in the
+# ISA by tools/isa_scan.py and equal to SQ_INSTS_LDS / (waves x steps), MEASUREMENTS.md section 4.2): every transform passes its 8
+# complex values per lane through two planar exchanges (re plane, im plane: 2 x 2 x 8 eight-byte stores, read back as 2 x 2 x 4
+# sixteen-byte loads); a key row is 2 columns x 8 KB = 16 wave-wide 16-byte reads per digit row; ~83 accumulator accesses (the
+# rotated difference's 32-bit reads, the update's read-modify-writes, the mask word). Cycles per wave-instruction on the CU's ONE
+# LDS pipe from MI355X_MICROARCH.md "LDS": ds_write_b64 ~6 (the VGPR -> LDS store path, 85 B/clk), ds_read_b128 4, 32-bit
+# accesses 2 (reads) to 4 (writes).
+LDS_CYCLES = {"ds_write_b64": 6.0, "ds_read_b128": 4.0, "acc_32bit": 3.0}
+
+
+def lds_model(l, split=False):
+    transforms = 2 * l + (4 if split else 2)
+    rows = 2 * l * (2 if split else 1)
+    counts = {"plane_stores_ds_write_b64": 32 * transforms, "plane_loads_ds_read_b128": 16 * transforms,
+              "key_reads_ds_read_b128": 16 * rows, "accumulator_32bit": 83}
+    cycles = (counts["plane_stores_ds_write_b64"] * LDS_CYCLES["ds_write_b64"]
+              + (counts["plane_loads_ds_read_b128"] + counts["key_reads_ds_read_b128"]) * LDS_CYCLES["ds_read_b128"]
+              + counts["accumulator_32bit"] * LDS_CYCLES["acc_32bit"])
+    return counts, cycles
+
+
+def _phase(ct, key):
+    """Torus phase b - <a, s> of every ciphertext of a device slab [B][W], as signed 32-bit values in int64."""
+    ph = ct[:, -1].long() - (ct[:, :-1].long() * key).sum(dim=1)
+    return ((ph + (1 << 31)) % (1 << 32)) - (1 << 31)
+
+
+def sign_agreement(stages, lwe_key, device, strong=32):
+    """how many hidden units of an encrypted run carry the sign the plaintext network
+    computes (its logits are pinned to the reference's plaintext build, tests/golden). `stages`: [(name, input slab(s) of the
+    bootstrapped stage, its output slab, plaintext pre-activations or None, plaintext +-1 bits)]. Three fractions per stage:
+    `agree` = encrypted output sign == plaintext bit; `agree_strong` = the same over units whose PLAINTEXT |pre-activation| >= 32
+    message steps (weak-margin units flip under the 4096-level / 2N = 2048 mod-switch in any TFHE implementation, SURVEY hard part
+    7); `bootstrap_agree` = output sign == sign of the phase of the stage's OWN encrypted input (what the bootstrap itself does,
+    independent of flips inherited from earlier layers), and the same over inputs at least 32 steps from a decision boundary."""
+    import torch
+    key = torch.from_numpy(lwe_key.astype("int64")).to(device)
+    per, tot = [], {"units": 0, "agree": 0, "strong": 0, "agree_strong": 0, "bs_agree": 0, "bs_strong": 0, "bs_agree_strong": 0}
+    for name, ins, out, pre, bits in stages:
+        enc = torch.where(_phase(out, key) >= 0, 1, -1)
+        pb = torch.from_numpy(bits.astype("int64")).to(device)
+        ph_in = _phase(ins[0], key)
+        if len(ins) == 2:                                      # bootsOR: (0, 1/8) + a + b
+            ph_in = ((ph_in + _phase(ins[1], key) + (1 << 29) + (1 << 31)) % (1 << 32)) - (1 << 31)
+        own = torch.where(ph_in >= 0, 1, -1)
+        far = (ph_in.abs() >= (strong << 20)) & (ph_in.abs() <= (1 << 31) - (strong << 20))
+        agree = enc == pb
+        rec = {"stage": name, "units": int(enc.numel()), "agree": round(float(agree.float().mean()), 5),
+               "bootstrap_agree": round(float((enc == own).float().mean()), 5),
+               "bootstrap_agree_strong_input": round(float((enc == own)[far].float().mean()), 5) if bool(far.any()) else None}
+        tot["units"] += int(enc.numel()); tot["agree"] += int(agree.sum())
+        tot["bs_agree"] += int((enc == own).sum()); tot["bs_strong"] += int(far.sum()); tot["bs_agree_strong"] += int((enc == own)[far].sum())
+        if pre is not None:
+            st = torch.from_numpy((abs(pre) >= strong)).to(device)
+            rec["strong_units"] = int(st.sum())
+            rec["agree_strong"] = round(float(agree[st].float().mean()), 5) if bool(st.any()) else None
+            tot["strong"] += int(st.sum()); tot["agree_strong"] += int(agree[st].sum())
+        per.append(rec)
+    return {"strong_means": "|pre-activation| >= %d message steps of 1/4096" % strong, "hidden_units": tot["units"],
+            "agree": round(tot["agree"] / max(1, tot["units"]), 5),
+            "agree_strong": round(tot["agree_strong"] / max(1, tot["strong"]), 5), "strong_units": tot["strong"],
+            "bootstrap_agree": round(tot["bs_agree"] / max(1, tot["units"]), 5),
+            "bootstrap_agree_strong_input": round(tot["bs_agree_strong"] / max(1, tot["bs_strong"]), 5), "strong_inputs": tot["bs_strong"],
+            "per_stage": per}
 
 
 def redsec_set_legs(device_index, gates, with_cifar=True):
@@ -170,6 +256,11 @@ def redsec_set_legs(device_index, gates, with_cifar=True):
            "data": "bundled MNIST test image, trained sign1024x1 weights (tests/golden)"}
     res["encrypted_argmax"] = int(np.argmax(logits))
     res["label"] = int(labels[1])
+    ptaps, etaps = {}, {}
+    res["plaintext_argmax"] = int(np.argmax(pm.forward(enc.net, pixels[1], ptaps)))
+    enc.run(ct, taps=etaps)
+    res["sign_agreement"] = sign_agreement([("layer%d" % k, (etaps["pre%d" % k],), etaps["bits%d" % k], ptaps["pre%d" % k], ptaps["bits%d" % k]) for k in (0, 1)],
+                                           sk.lwe_key, ct.device)
     # "also run the REDsec set" -- the same 65,536-NAND step on the shipped parameters
     rng = np.random.default_rng(11)
     ba, bb = rng.integers(0, 2, gates), rng.integers(0, 2, gates)
@@ -255,17 +346,94 @@ def cifar_leg(be, sk, device_index):
     ms_s = 1e3 * (time.perf_counter() - t0)
     be.set_mode("fft")
     logits = sk.decrypt_ints(out.cpu().numpy())
-    return {"ms_per_image": round(ms, 1), "unit": "ms", "bootstraps": timer.bootstraps, "largest_launch": 131072, "maxpool": "fused",
+    taps, ptaps = [], {}
+    plain = pm.cifar_forward(net, pix[i], ptaps)
+    out_t = enc.run(ct, taps=taps)                            # third run: the stage slabs for the agreement statistics
+    agreement = sign_agreement([(r["name"], r["inputs"], r["out"]) + ptaps[r["name"]] for r in taps], sk.lwe_key, ct.device)
+    largest = max(int(r["out"].shape[0]) for r in taps)
+    del taps
+    return {"ms_per_image": round(ms, 1), "unit": "ms", "bootstraps": timer.bootstraps, "largest_launch": largest, "maxpool": enc.maxpool,
             "blind_rotate_ms": round(timer.blind_rotate_ms, 1), "keyswitch_ms": round(timer.keyswitch_ms, 1), "linear_ms": round(timer.linear_ms, 1),
             "bootstraps_per_s": round(timer.bootstraps / (ms * 1e-3), 1), "argmax": int(np.argmax(logits)), "label": int(labels[i]),
-            "plaintext_argmax": int(np.argmax(pm.cifar_forward(net, pix[i]))),
-            "class_note": "kernel-level parity is exact (tests/test_gpu_cifar.py: every bootstrapped stage = the oracle word for word); the CLASS of one "
-                          "encrypted image is a property of the reference's parameter choice: 4096 message levels through a 2N = 2048 mod-switch flip weak-margin "
-                          "units in any TFHE implementation (tools/cifar_agreement.py, profiles/r04)",
+            "plaintext_argmax": int(np.argmax(plain)), "logit_correlation_with_plaintext": round(float(np.corrcoef(logits, plain)[0, 1]), 4),
+            "sign_agreement": agreement, "rerun_logit_ciphertexts_equal": bool(torch.equal(out, out_t)),
+            "class_note": "kernel-level parity is exact (tests/test_gpu_cifar.py: every bootstrapped stage = the oracle word for word, every linear stage = numpy); "
+                          "the CLASS of one encrypted image rests on weak-margin units: bootstrap_agree_strong_input shows the bootstraps deciding every clear input "
+                          "as its sign, agree < 1 is what 4096 message levels through the 2N = 2048 mod-switch do to inputs near a boundary (SURVEY hard part 7; "
+                          "tools/cifar_agreement.py, profiles/r04: class equal to the plaintext class in 5 of 12 runs of the clearest images)",
             "params": "redsec_small_v2", "mode": "fft", "split_mode_ms_per_image": round(ms_s, 1),
             "logit_ciphertexts_equal_in_split_mode": bool(torch.equal(out, out_s)),
             "fft_rounding_certificate": round(be.rounding_certificate(), 6),
             "data": "bundled CIFAR-10 test image, trained binarynet weights (tests/golden)"}
+
+
+def cifar_batch_leg(local_rank, rank, world, dist_on, rehearsal, net_name, n_images):
+    """BASELINE configs[4]: a batch of encrypted CIFAR images, ONE IMAGE PER GPU (image-parallel replicas: full key replica on
+    every rank, sharding.image_parallel), the 10 x W logit words of every image gathered over RCCL INSIDE the timed region.
+    Inputs are resident in HBM before timing; one untimed warm-up image per rank; the batch is timed once, barrier +
+    synchronize on both sides, maximum over ranks. Afterwards every rank re-runs the image of its NEIGHBOUR rank by itself and
+    compares with what the gather delivered, word for word (a bootstrap's output depends on its input and the key only, so
+    where an image ran cannot show): `logits_equal_single_gpu`. The reference's shape: enc_segs[NUM_GPUS], one host thread per
+    GPU, no merge step (lib/GPU/Layer.cuh:15,22-37, nets/mnist/sign1024x1/main.cu:81-83)."""
+    import numpy as np
+    import torch
+    import redsec_amd
+    from redsec_amd import client, nets, sharding
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import plain_model as pm
+    dev = torch.device("cuda", local_rank)
+    sk = client.SecretKeySet("redsec_small_v2", seed=7)             # the same key on every rank (seeded)
+    be = redsec_amd.Backend(redsec_amd.params("redsec_small_v2"), device=local_rank)
+    be.load_keys(sk.bk, sk.ksk)
+    net = pm.CifarNet(net_name)
+    enc = nets.EncryptedCifar(be, net)
+    labels, pix = pm.load_cifar_images()
+    n = n_images if n_images > 0 else world
+    images = [(k + 1) % len(labels) for k in range(n)]              # image 0 of the bundle is misclassified by the plaintext net too
+    mine = sharding.image_assignment(n, rank, world)
+    check = [(k + 1) % n for k in mine]                             # the neighbour's images, re-run after the timed region
+    cts = {k: torch.from_numpy(sk.encrypt_image(pix[images[k]], seed=100 + images[k])).to(dev) for k in set(mine) | set(check)}
+    enc.run(cts[mine[0] if mine else check[0]])                     # warm-up: allocator, first launches
+    torch.cuda.synchronize()
+    if dist_on:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    logits, t_compute, t_gather = sharding.image_parallel(lambda k: enc.run(cts[k]), list(range(n)), (10, be.W), force=dist_on)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [{"rank": rank, "images": [images[k] for k in mine], "compute_ms": round(1e3 * t_compute, 1), "gather_ms": round(1e3 * t_gather, 3)}]
+    ok = all(bool(torch.equal(enc.run(cts[k]), logits[k])) for k in check)
+    ok = ok and be.fft_fallbacks() == 0
+    if dist_on:
+        tm = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        elapsed = float(tm.item())
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if rehearsal else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+        every = [None] * world
+        dist.all_gather_object(every, per_rank[0])
+        per_rank = every
+    res = None
+    if rank == 0:
+        dec = [sk.decrypt_ints(logits[k].cpu().numpy()) for k in range(n)]
+        plain = [pm.cifar_forward(net, pix[images[k]]) for k in range(n)]
+        res = {"workload": "nets/cifar/%s, %d encrypted image(s), image-parallel over %d GPU(s) (one each when equal), logits gathered" % (net_name, n, world),
+               "images": n, "s_per_batch": round(elapsed, 3), "images_per_s": round(n / elapsed, 4),
+               "gather_ms": round(max(r["gather_ms"] for r in per_rank), 3), "gather_words_per_image": 10 * be.W,
+               "collective": "none (one rank, no process group)" if not dist_on else ("all_gather_into_tensor over " + ("gloo (one-GPU rehearsal)" if rehearsal else "nccl (RCCL)")),
+               "inside_timed_region": True, "per_rank_ms": per_rank, "logits_equal_single_gpu": ok,
+               "encrypted_argmax": [int(np.argmax(d)) for d in dec], "plaintext_argmax": [int(np.argmax(q)) for q in plain],
+               "labels": [int(labels[images[k]]) for k in range(n)],
+               "logit_correlation_with_plaintext": [round(float(np.corrcoef(d, q)[0, 1]), 3) for d, q in zip(dec, plain)],
+               "params": "redsec_small_v2", "mode": "fft", "maxpool": enc.maxpool, "fft_rounding_certificate": round(be.rounding_certificate(), 6),
+               "data": "bundled CIFAR-10 test images, trained weights (tests/golden)"}
+    be.close()
+    return res
 
 
 def relaunch_under_torchrun(args):
@@ -306,6 +474,11 @@ def main():
     ap.add_argument("--no-cifar", action="store_true", help="skip the encrypted CIFAR binarynet image (BASELINE configs[3]; about 20 s at N = 1)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not measure roofline.traffic with two rocprofv3 --pmc child runs "
                     "of one step (N = 1 only, about 40 s); the committed profile's figure is reported instead, labelled as such")
+    ap.add_argument("--cifar-batch", default="auto", choices=["auto", "on", "off"],
+                    help="BASELINE configs[4]: a batch of encrypted CIFAR images, one per GPU, logits gathered over RCCL inside the timed "
+                         "region (JSON key cifar_batch). auto = on when N > 1 (at N = 1 the cifar_binarynet leg is the same image path)")
+    ap.add_argument("--cifar-batch-net", default="binarynet", choices=["binarynet", "binarynet_small"])
+    ap.add_argument("--cifar-batch-images", type=int, default=0, help="images in the batch (0 = one per GPU)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xC0FFEE)
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) and run the output all-gather also at ONE rank: "
                     "walks the N > 1 code path on a one-GPU box (tools/scale_sweep.sh checks it against the plain run)")
@@ -506,6 +679,11 @@ def main():
         del ref_exact
         be.set_mode("fft")
 
+    # ---- BASELINE configs[4]: image-parallel CIFAR batch (every rank takes part; own backend on the shipped parameter set) ----
+    cifar_batch = None
+    if args.cifar_batch == "on" or (args.cifar_batch == "auto" and world > 1):
+        cifar_batch = cifar_batch_leg(local_rank, rank, world, dist_on, rehearsal, args.cifar_batch_net, args.cifar_batch_images)
+
     # FFT mode: largest distance of any inverse-transform output from an integer over the whole run
     # (exactness needs < 0.5), and how many calls the device recomputed exactly
     certificate = round(be.rounding_certificate(), 6) if args.mode == "fft" else None
@@ -551,6 +729,19 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel_ms": round(last_br, 3), "algorithmic_bytes_per_launch": int(alg_bytes),
                     "resident_ciphertexts_per_key_sweep": R, "waves_per_workgroup": launch["waves_per_block"]}
+        # SURVEY.md section 8(d)'s whole-step figure: + the keyswitch term KS_rows * W * 4 / T, with KS_rows = N t (1 - 1/base) rows
+        # touched per ciphertext and T = the 256 ciphertexts of a keyswitch workgroup that share every key tile through LDS
+        # (csrc/rs_kernels.hip keyswitch_tiled*_kernel), + the extracted sample read back and the output ciphertext written
+        T_ks = 256
+        ks_rows = p.N * p.ks_t * (1.0 - 1.0 / (1 << p.ks_basebit))
+        ks_per_boot = ks_rows * be.W * 4 / T_ks + (p.N + 1) * 4 + be.W * 4
+        step_bytes = (per_boot + ks_per_boot) * G
+        step_ms = last_br + last_ks
+        roofline_step = {"bound": "hbm", "kernels": [kernel_name, "keyswitch"], "algorithmic_bytes_per_step": int(step_bytes),
+                         "keyswitch_bytes_per_bootstrap": int(ks_per_boot), "blind_rotate_bytes_per_bootstrap": int(per_boot),
+                         "ciphertexts_sharing_a_keyswitch_tile": T_ks, "kernels_ms": round(step_ms, 3),
+                         "achieved": round(step_bytes / (step_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}
         fwd_red, inv_red, fused = (2, 3, 36) if p.bk_l == 3 else (0, 1, 48)
         ops_per = fp64_ops_per_bootstrap_fft(p.n, p.bk_l) if args.mode == "fft" else \
             (fp64_ops_per_bootstrap_split(p.n, p.bk_l) if args.mode == "split" else fp64_ops_per_bootstrap(p.n, p.bk_l, fwd_red, inv_red, fused))
@@ -575,6 +766,50 @@ def main():
                                                       "note": "pure FMA stream, 8 waves per CU, measured after the timed steps (rs_debug_fp64_rate)"}
         except Exception as e:   # an older library without the tap: the line stays valid
             roofline_valu["sustained_on_this_box"] = {"error": str(e)[:120]}
+
+        # ---- the third bound: the CU's LDS pipe (what explains an FP64 issue fraction of 0.56) ----
+        roofline_lds = None
+        if launch["form"] in ("workgroup", "split_workgroup") and args.mode in ("fft", "split"):
+            counts, cyc_wave = lds_model(p.bk_l, split=args.mode == "split")
+            waves = launch["waves_per_block"]
+            cus = info["num_cus"]
+            rounds = -(-G // (waves * cus))
+            steps_per_cu = rounds * p.n                      # CMUX steps a CU walks per launch (identity steps, bara = 0, are 1 in 2N)
+            pmc = None
+            if world == 1 and not args.no_live_traffic and not under_profiler and not os.environ.get("REDSEC_BENCH_PMC_CHILD"):
+                sq = ["SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT"]
+                pmc = pmc_child(args, kernel_name, sq)
+                gui = pmc_child(args, kernel_name, ["GRBM_GUI_ACTIVE"]) if pmc else None
+                if pmc and gui:
+                    pmc.update(gui)
+            xcds = 8
+            clk_ghz = (pmc["GRBM_GUI_ACTIVE"] / xcds / (last_br * 1e-3) / 1e9) if pmc and "GRBM_GUI_ACTIVE" in pmc else 2.4
+            step_cycles = last_br * 1e-3 * clk_ghz * 1e9 / steps_per_cu
+            lds_cycles = cyc_wave * waves
+            fp64_cycles = ops_per / p.n / 64 * waves / 4 * 4.0       # per SIMD: (waves / 4) waves x FP64 wave-instructions x 4 cycles
+            roofline_lds = {"bound": "lds-pipe (one per CU)", "kernel": kernel_name,
+                            "lds_instructions_per_wave_and_cmux_step": counts, "cycles_per_wave_instruction": LDS_CYCLES,
+                            "lds_pipe_cycles_per_cu_and_cmux_step": round(lds_cycles), "fp64_issue_cycles_per_simd_and_cmux_step": round(fp64_cycles),
+                            "measured_cycles_per_cmux_step": round(step_cycles), "clock_ghz": round(clk_ghz, 3),
+                            "clock_source": "GRBM_GUI_ACTIVE / 8 XCDs / kernel time (pmc child)" if pmc and "GRBM_GUI_ACTIVE" in pmc else "nominal",
+                            "frac": round(lds_cycles / step_cycles, 4), "fp64_frac_same_clock": round(fp64_cycles / step_cycles, 4),
+                            "sum_of_both_over_step": round((lds_cycles + fp64_cycles) / step_cycles, 4),
+                            "note": "the step takes about the SUM of its FP64 issue time and its LDS-pipe time, not their maximum: beside a busy FP64 stream every "
+                                    "LDS instruction costs the issuing SIMD 1.1-2.0 FMA slots (tools/lds_issue_bench.hip), and the 8 lock-step waves of a CU reach their "
+                                    "exchange bursts together; fewer exchange bytes, not faster instructions, is what would move it (MEASUREMENTS.md section 4.2)"}
+            if pmc:
+                cu_cycles = (pmc.get("GRBM_GUI_ACTIVE", 0) / xcds) or (last_br * 1e-3 * 2.4e9)
+                roofline_lds["pmc"] = {k: int(v) for k, v in pmc.items()}
+                roofline_lds["pmc_derived"] = {
+                    "SQ_ACTIVE_INST_LDS_over_SQ_BUSY_CYCLES": round(pmc["SQ_ACTIVE_INST_LDS"] / pmc["SQ_BUSY_CYCLES"], 4),
+                    "SQ_ACTIVE_INST_VALU_over_SQ_BUSY_CYCLES": round(pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_BUSY_CYCLES"], 4),
+                    # SQ_LDS_IDX_ACTIVE = all LDS-array cycles (MI355X_MICROARCH.md "LDS"), summed over the CUs
+                    "lds_array_busy_frac_per_cu": round(pmc["SQ_LDS_IDX_ACTIVE"] / (cus * cu_cycles), 4),
+                    "lds_instructions_per_wave_and_cmux_step": round(pmc["SQ_INSTS_LDS"] / (rounds * cus * waves * p.n), 1),
+                    "valu_instructions_per_wave_and_cmux_step": round(pmc["SQ_INSTS_VALU"] / (rounds * cus * waves * p.n), 1),
+                    "bank_conflict_cycles": int(pmc["SQ_LDS_BANK_CONFLICT"]),
+                    "units": "SQ_ACTIVE_INST_* in quad-cycles summed over waves; SQ_BUSY_CYCLES in cycles summed over the 32 shader engines",
+                    "source": "measured_in_this_run: one rocprofv3 --pmc child run of one step of the same workload (counters only)"}
 
         # ---- CPU baseline + parity on a bounded sample of the same workload ----
         cpu = None
@@ -640,8 +875,8 @@ def main():
                                    % (G, args.params, p.n, p.N, p.bk_l, p.bk_Bgbit, p.ks_t, p.ks_basebit),
                        "gates_per_gpu": G, "total_gates": total_gates, "params": args.params, "mode": args.mode,
                        "parallelism": "gate-sharded x%d%s" % (world, "" if world == 1 else (", outputs all-gathered over RCCL, overlapped with the next step" if gather else ", no gather"))},
-            "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu, "exact_mode": exact_mode, "split_mode": split_mode,
-            "mnist_sign1024x1": mnist, "cifar_binarynet": cifar, "redsec_params_nands": redsec_nands,
+            "roofline": roofline, "roofline_step": roofline_step, "roofline_valu": roofline_valu, "roofline_lds": roofline_lds, "cpu_baseline": cpu, "exact_mode": exact_mode, "split_mode": split_mode,
+            "mnist_sign1024x1": mnist, "cifar_binarynet": cifar, "cifar_batch": cifar_batch, "redsec_params_nands": redsec_nands,
             "collective": None if not gather else {"op": "all_gather_into_tensor", "bytes_per_rank": int(width_rows * be.W * 4),
                                                    "bytes_received_per_rank": int(world * width_rows * be.W * 4),
                                                    "ms_alone_unoverlapped": round(gather_ms, 3), "inside_timed_region": True,

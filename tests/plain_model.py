@@ -107,8 +107,14 @@ class CifarNet:
 
 
 def cifar_forward(net, pixels, taps=None):
+    """-> integer logits [10]. `taps` (dict) receives, under the stage names of redsec_amd.nets.EncryptedCifar ("quantize0",
+    "conv<k>", "maxpool<k>", "fc<k>"), (pre-activations or None, +-1 bits) flattened in (row, column, channel) order, and the
+    pre-activation maps as "pre<k>"."""
     x = (2 * pixels - 255).reshape(32, 32, 3)
-    bits = np.where(x + net.bias0.astype(np.int64)[None, None, :] >= 0, 1, -1)
+    pre = x + net.bias0.astype(np.int64)[None, None, :]
+    bits = np.where(pre >= 0, 1, -1)
+    if taps is not None:
+        taps["quantize0"] = (pre.reshape(-1), bits.reshape(-1))
     for li, (sign, zero, bias) in enumerate(net.convs):
         H, W, C = bits.shape
         w = np.where(zero == 1, 0, np.where(sign == 1, 1, -1)).astype(np.int64).reshape(9 * C, -1)
@@ -119,8 +125,11 @@ def cifar_forward(net, pixels, taps=None):
         bits = np.where(pre >= 0, 1, -1)
         if taps is not None:
             taps["pre%d" % (li + 1)] = pre
+            taps["conv%d" % (li + 1)] = (pre.reshape(-1), bits.reshape(-1))
         if li % 2 == 1:                                          # E_MAXPOOL 2x2 on layers 2, 4, 6
             bits = bits.reshape(H // 2, 2, W // 2, 2, -1).max(axis=(1, 3))
+            if taps is not None:
+                taps["maxpool%d" % (li + 1)] = (None, bits.reshape(-1))
     v = bits.reshape(-1)
     for i, (sign, zero, bias) in enumerate(net.fcs):
         w = np.where(zero == 1, 0, np.where(sign == 1, 1, -1)).astype(np.int64)
@@ -128,3 +137,5 @@ def cifar_forward(net, pixels, taps=None):
         if i == len(net.fcs) - 1:
             return pre
         v = np.where(pre >= 0, 1, -1)
+        if taps is not None:
+            taps["fc%d" % (i + 1)] = (pre, v)

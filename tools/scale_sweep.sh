@@ -25,7 +25,9 @@ for N in 1 2 4 8; do
   [ "$N" -gt "$NGPU" ] && break
   for MODE in weak strong; do
     [ "$N" = 1 ] && [ "$MODE" = strong ] && continue
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29550 + N)) bench.py --gpus $N $COMMON --scaling $MODE \
+    # the weak line also carries BASELINE configs[4]: N encrypted CIFAR images, one per GPU, logits gathered (cifar_batch)
+    CB="off"; [ "$MODE" = weak ] && CB="on"
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29550 + N)) bench.py --gpus $N $COMMON --scaling $MODE --cifar-batch $CB \
       > "$OUT/scale_${MODE}_$N.json" || exit 1
     # every line is checked before it is believed: the size that ran, the collective that ran, the gathered batch, and that no
     # rank's kernels were slower than the others' by 3 % (a slow rank sets the whole job's time)
@@ -44,6 +46,11 @@ if N > 1:
     assert d["checks"]["gathered_batch_ok"], "the gathered batch is wrong"
     assert spread < 0.03, "per-rank kernel times differ by %.1f %%" % (100 * spread)
 assert d["checks"]["all_outputs_decrypt_to_nand"]
+cb = d.get("cifar_batch")
+if mode == "weak":
+    assert cb and cb["images"] == N and cb["logits_equal_single_gpu"], "the image-parallel CIFAR batch did not run or its gathered logits differ from single-GPU runs"
+    print("      cifar_batch: %d image(s) in %.3f s = %.3f images/s, gather %.3f ms, per-rank compute ms %s"
+          % (cb["images"], cb["s_per_batch"], cb["images_per_s"], cb["gather_ms"], [r["compute_ms"] for r in cb["per_rank_ms"]]))
 PY
   done
 done
