@@ -20,6 +20,7 @@
 #include <string>
 #include <vector>
 
+#include "rs_diag.h"
 #include "rs_host.h"
 #include "rs_general.h"
 #include "rs_kernels.h"
@@ -82,7 +83,7 @@ struct rs_ctx {
   double cert_limit = RS_CERTIFICATE_LIMIT;
   rs::LaunchOpts opts;
   double* d_tw = nullptr;          // exact-NTT tables (kTwTotal doubles)
-  double* d_tw_fft = nullptr;      // FFT tables (kFftTwDoublesAll doubles: the forward / Gentleman-Sande tables, then those of the DIT inverse)
+  double* d_tw_fft = nullptr;      // FFT tables (kFftTwDoubles doubles)
   double* d_bk_ntt = nullptr;      // key in the NTT domain
   double* d_bk_fft = nullptr;      // key in the FFT domain
   // general ring path (rs_general.h): every parameter set has it; sets outside the specialised N = 1024 kernels
@@ -233,14 +234,10 @@ int ready(rs_ctx* c) {
 // non-negative double (ordered like the value). A distance of 1/4 or more cannot be told from an error of the opposite sign
 // around the next integer once the a-priori bound exceeds 1/4, so it poisons the context instead of passing silently.
 bool split_distance_ok(const rs_ctx* c, unsigned long long bits) {
-#ifdef RS_T_NO_ENFORCE   // timing-only variant builds (tools/build_variant.sh) whose kernels compute wrong values on purpose
-  (void)c; (void)bits;
-  return true;
-#else
+  if (rs::diag::kNoKeyProbe) return true;   // diagnostic builds whose kernels compute wrong values on purpose (rs_diag.h)
   double d;
   memcpy(&d, &bits, sizeof d);
   return d < c->split_cert_limit;
-#endif
 }
 int inexact_error(rs_ctx* c) {
   return fail(RS_ERR_INEXACT, "split-key mode: a rounding distance of 1/4 or more was observed (a-priori bound %.3g): results of this context are not certified; "
@@ -465,8 +462,8 @@ int rs_create(rs_ctx** out, const rs_params* p, int device) {
   c->wgs_cfg = special ? c->cfg : ((p->N == rs::kN && p->bk_l == 3 && p->bk_Bgbit == 10) ? 2 : -1);
   if (special || c->wgs_cfg >= 0) {
     const std::vector<double> fft_tw = rs::make_fft_tables();
-    if (hipMalloc(&c->d_tw_fft, sizeof(double) * rs::kFftTwDoublesAll) != hipSuccess ||
-        hipMemcpy(c->d_tw_fft, fft_tw.data(), sizeof(double) * rs::kFftTwDoublesAll, hipMemcpyHostToDevice) != hipSuccess) {
+    if (hipMalloc(&c->d_tw_fft, sizeof(double) * rs::kFftTwDoubles) != hipSuccess ||
+        hipMemcpy(c->d_tw_fft, fft_tw.data(), sizeof(double) * rs::kFftTwDoubles, hipMemcpyHostToDevice) != hipSuccess) {
       destroy_ctx(c);
       return fail(RS_ERR_HIP, "twiddle table upload failed");
     }

@@ -16,16 +16,9 @@
 // and two inverse transforms update the accumulator. Waves never synchronise with each other after
 // the twiddle tables are staged.
 //
-// Build-time switches, all OFF in the product build (tools/build_variant.sh passes them for same-box A/B runs):
-//   RS_NO_MAC_STREAM, RS_NO_TW_AHEAD, RS_NO_ACC_AHEAD, RS_NO_SPLIT_STORES   the previous form of one optimisation
-//   RS_ISSUE_FENCE_ON                                   sched_barrier after every exchange burst (measured: -0.5 %)
-//   RS_ADDTID                                           B' <-> C' exchanges stored by ds_write_addtid_b32 rows, read back as 16-byte runs (rs_fft.h): -0.8 % / +0.5 %
-//   RS_WG_SETPRIO=<p>, RS_WG_BAREBAR                    static priority for waves 4-7 (-0.3 %); bare s_barrier instead of __syncthreads (+-0)
-//   RS_WGS_FWD_NOAHEAD, RS_WGS_DRAIN                    split-key workgroup kernel: twiddles fetched stage by stage (-1.9 %); full drain at barriers (+-0)
-//   RS_T_WPB4                                           timing: 4 ciphertexts per workgroup = one wave per SIMD (results correct): 78 % of the rate
-//   RS_NO_CERT, RS_T_NOBAR, RS_T_STAGGER=<n>, RS_T_HALFSTORE, RS_T_HALFLOAD   TIMING PROBES: results are wrong
-//   RS_STAMPS                                           DIAGNOSTIC: s_memtime stamps at the phase boundaries of blind_rotate_wg_kernel, summed per wave into
-//                                                       g_rs_stamps (tools/stamp_profile.py reads the SHARES; the stamps drain LDS reads, so never quote its run time)
+// Compile-time switches of this file: RS_BS_PART (below: which launchers an object holds) and RS_DIAG (rs_diag.h: phase stamps
+// and the no-key timing probe of diagnostic builds). Every experiment of rounds 1-4 that was measured and not adopted has its
+// verdict in MEASUREMENTS.md and no code path here.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -33,6 +26,7 @@
 
 #include "rs_fft.h"
 #include "rs_cohort.h"
+#include "rs_diag.h"
 #include "rs_kernels.h"
 #include "rs_lds_plan.h"
 #include "rs_ntt.h"
@@ -44,9 +38,6 @@
 // pass). Kernels are templates, so each object holds only what its launchers name. Default 3: one object with everything.
 #ifndef RS_BS_PART
 #define RS_BS_PART 3
-#endif
-#ifndef RS_COHORT_LAG_ADJ
-#define RS_COHORT_LAG_ADJ 1   // steps taken off the XCD cohort lag because the check runs one step behind its post (0: same throughput on one box, REDsec-set split traffic 67.5 instead of 58.5 GB; profiles/r04/ag_*)
 #endif
 
 namespace rs {
@@ -248,39 +239,16 @@ struct XfFft {
 #pragma unroll
     for (int r = 0; r < kRegs; ++r) x[r] = (double)gadget_digit_prepared<C>(d[r], q);
   }
-  __device__ static __forceinline__ void fwd_pair_wg(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const State& st, double* buf) {
+  // the lock-step workgroup kernel's pairs: per-lane twiddles from registers (FftTwKept) or the LDS tables (State)
+  template <class TWS>
+  __device__ static __forceinline__ void fwd_pair_wg(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TWS& st, double* buf) {
     ffwd_pair<true>(lane, xa, xb, st, buf, [] { wave_lds_sync(); });
   }
-  __device__ static __forceinline__ void inverse_pair_wg(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const State& st, double* buf) {
+  template <class TWS>
+  __device__ static __forceinline__ void inverse_pair_wg(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TWS& st, double* buf) {
     finv_pair<true>(lane, xa, xb, st, buf, [] { wave_lds_sync(); });
   }
-  // the same with a segment hook (issue-priority toggling in blind_rotate_wg_kernel)
-  template <class TWS, class Seg>
-  __device__ static __forceinline__ void fwd_pair_wg(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TWS& st, double* buf, Seg seg) {
-    ffwd_pair<true>(lane, xa, xb, st, buf, [] { wave_lds_sync(); }, seg);
-  }
-  template <class Seg>
-  __device__ static __forceinline__ void inverse_pair_wg(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const State& st, double* buf, Seg seg) {
-    finv_pair<true>(lane, xa, xb, st, buf, [] { wave_lds_sync(); }, seg);
-  }
-  // -DRS_WG_DIT: the lock-step workgroup kernel stages the tables of the decimation-in-time inverse as well (18.9 KB) and runs
-  // its inverse pairs through them: 228 instead of 288 FP64 operations per transform, 14 instead of 8 table reads (rs_fft.h).
-  // Bit-exact (emulator, 78 GPU parity tests) and SLOWER on the same box: 309.7-310.7 against 307.5-308.2 ms per 65,536
-  // default-128 gates, 470.3-471.1 against 467.4-467.8 ms on the REDsec set (profiles/r03/m_ab_dit_inverse_pair.txt) -- the
-  // six extra LDS reads per transform cost more than the 60 FP64 operations save. The Gentleman-Sande pair stays.
-#ifdef RS_WG_DIT
-  static constexpr int kWgTableDoubles = kFftTwDoublesAll;
-#else
   static constexpr int kWgTableDoubles = kFftTwDoubles;
-#endif
-  template <class TWS, class Seg>
-  __device__ static __forceinline__ void inverse_pair_wg_dit(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TWS& st, double* buf, Seg seg) {
-#ifdef RS_WG_DIT
-    finv_pair_dit<true>(lane, xa, xb, st.tab, buf, [] { wave_lds_sync(); }, seg);
-#else
-    finv_pair<true>(lane, xa, xb, st, buf, [] { wave_lds_sync(); }, seg);
-#endif
-  }
 };
 
 // largest rounding distance of the wave -> device flag (positive doubles order like their bit patterns)
@@ -542,11 +510,7 @@ __device__ __forceinline__ void glds_chunks_at(const double* gsrc_wave_base, uns
 // stream: 8 steps of two complex positions (4 ds_read_b128: both columns), the reads of step k+1 issued
 // before the FMAs of step k. Read in four blocks of 8 with the FMAs after each block (mac_row), every
 // block exposed a fresh LDS latency because the FMAs of a block drain its reads (in-order return).
-#if defined(RS_NO_MAC_STREAM)
-#define RS_MAC_FENCE() ((void)0)
-#else
 #define RS_MAC_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
 // col0 / col1: offsets (in double2) of the column multiplied into s0 / s1 within a key row -- 0 and kN / 2 for (column 0, column 1);
 // the duo kernel passes them swapped for its odd waves, so that s0 is always the column the wave itself inverts
 __device__ __forceinline__ void mac_pair_stream(double (&s0)[kRegs], double (&s1)[kRegs], const double (&xa)[kRegs], const double (&xb)[kRegs],
@@ -579,56 +543,8 @@ __device__ __forceinline__ void mac_pair_stream(double (&s0)[kRegs], double (&s1
   }
 }
 
-#ifdef RS_STAMPS_WGS   // diagnostic builds: which half of the file owns the stamp array (one definition of the symbol per library)
-#define RS_STAMP_PART 2   // blind_rotate_wgs_kernel is launched from part 2
-#else
-#define RS_STAMP_PART 1   // the lock-step, duo and coop8 kernels from part 1
-#endif
-#if defined(RS_STAMPS) && (RS_BS_PART & RS_STAMP_PART)
-// Diagnostic build only (cdna_hip_programming.md section 7, in-kernel stamps): phase sums per wave, read back by
-// rs_debug_read_stamps. Phases: 0 step prologue, 1 digits + forward pair, 2 wait for the key rows + barrier, 3 multiply-
-// accumulate, 4 barrier + next rows requested, 5 accumulator pre-read + inverse pair, 6 rounding + accumulator update,
-// 7 group prologue / sample extract.
-constexpr int kStampPhases = 8;
-__device__ unsigned long long g_rs_stamps[256 * 8 * kStampPhases];
-#define RS_STAMP_DECL unsigned long long st_sum_[kStampPhases] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_last_; \
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last_) :: "memory")
-#define RS_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; \
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
-  st_sum_[k] += t_ - st_last_; st_last_ = t_; } while (0)
-#define RS_STAMP_FLUSH(wave) do { if (lane == 0 && blockIdx.x < 256) { for (int k_ = 0; k_ < kStampPhases; ++k_) \
-  g_rs_stamps[((size_t)blockIdx.x * 8 + (wave)) * kStampPhases + k_] = st_sum_[k_]; } } while (0)
-#else
-#define RS_STAMP_DECL ((void)0)
-#define RS_STAMP(k) ((void)0)
-#define RS_STAMP_FLUSH(wave) ((void)0)
-#endif
-#if defined(RS_STAMPS) && defined(RS_STAMPS_WGS) && (RS_BS_PART & 2)   // diagnostic build: the phase stamps, in blind_rotate_wgs_kernel
-#define RS_WGS_STAMP_DECL RS_STAMP_DECL
-#define RS_WGS_STAMP(k) RS_STAMP(k)
-#define RS_WGS_STAMP_FLUSH(wave) RS_STAMP_FLUSH(wave)
-#else
-#define RS_WGS_STAMP_DECL ((void)0)
-#define RS_WGS_STAMP(k) ((void)0)
-#define RS_WGS_STAMP_FLUSH(wave) ((void)0)
-#endif
-#if defined(RS_STAMPS) && defined(RS_STAMPS_DUO)   // diagnostic build: the phase stamps, in blind_rotate_duo_kernel
-#define RS_DUO_STAMP_DECL RS_STAMP_DECL
-#define RS_DUO_STAMP(k) RS_STAMP(k)
-#define RS_DUO_STAMP_FLUSH(wave) RS_STAMP_FLUSH(wave)
-#else
-#define RS_DUO_STAMP_DECL ((void)0)
-#define RS_DUO_STAMP(k) ((void)0)
-#define RS_DUO_STAMP_FLUSH(wave) ((void)0)
-#endif
-#if defined(RS_STAMPS) && defined(RS_STAMPS_COOP8)   // diagnostic build: the phase stamps of the lock-step kernel, in this kernel
-#define RS_C8_STAMP_DECL RS_STAMP_DECL
-#define RS_C8_STAMP(k) RS_STAMP(k)
-#define RS_C8_STAMP_FLUSH(wave) RS_STAMP_FLUSH(wave)
-#else
-#define RS_C8_STAMP_DECL ((void)0)
-#define RS_C8_STAMP(k) ((void)0)
-#define RS_C8_STAMP_FLUSH(wave) ((void)0)
+#if RS_BS_PART & RS_DIAG_STAMP_PART   // diagnostic builds only (rs_diag.h): the phase sums, [workgroup < 256][wave][phase]
+__device__ unsigned long long g_rs_stamps[256 * 8 * diag::kStampPhases];
 #endif
 
 template <class Xf, int WPB>
@@ -643,7 +559,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
   __shared__ __attribute__((aligned(16))) double s_buf[WPB][Xf::kWgBufDoubles];
   __shared__ int32_t s_acc[WPB][2][kN];
   __shared__ __attribute__((aligned(16))) double s_key[2][kRowDoubles];
-  constexpr int kWin = 64;                       // mask words live in a 64-step window, as in the split kernel (leaves LDS for the tables of -DRS_WG_DIT)
+  constexpr int kWin = 64;                       // mask words live in a 64-step window, as in the split kernel
   __shared__ uint16_t s_bara[WPB][kWin];
   __shared__ int s_mail[kCohortSlots];   // XCD cohorts: the progress row requested a step ago (wave 0 only; rs_cohort.h)
   stage_tables(s_tw, a.tw, 64 * WPB, Xf::kWgTableDoubles);
@@ -655,42 +571,15 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
   int32_t* acc1 = s_acc[wave][1];
   typename Xf::State tw_table;
   Xf::init(tw_table, lane, s_tw, a.tw);
-#ifndef RS_WG_KEEP_TW
-#define RS_WG_KEEP_TW 3   // first stage whose per-lane twiddles stay in registers (3: all 8 values, 6: the last group's 4, 9: none)
-#endif
-  FftTwKept<RS_WG_KEEP_TW> tw;
+  FftTwKept<3> tw;   // all eight per-lane twiddles stay in registers for the whole kernel (32 registers; +2.4 % / +1.3 %, profiles/r03/n_*)
   fft_kept_load(tw, tw_table);
   const int n = a.n;
   constexpr uint32_t offset = gadget_offset<C>();
   double dev = 0.0;
   const long n_groups = (a.B + WPB - 1) / WPB;
   const int total_rows = n * KPL;   // key rows of one blind rotation (n <= 1024 steps x 2 l: far inside an int; scalar compares)
-  RS_STAMP_DECL;
-#ifdef RS_WG_SETPRIO   // A/B: static priority for the second-dispatched half of the workgroup (the arbitration loser)
-  if (wave >= WPB / 2) __builtin_amdgcn_s_setprio(RS_WG_SETPRIO);
-#endif
-  // Fair share of the SIMD. The two waves of a SIMD (wave w and w + WPB/2) run the same program between the same barriers,
-  // and at equal priority the OLDER one wins vector issue: stamps (tools/stamp_profile.py, profiles/r03/a_stamps_*) show waves
-  // 0-3 parked at the barriers 36 % of their time while waves 4-7 run on alone at a lone wave's lower issue rate. Each wave
-  // therefore raises its priority on alternate segments of a transform pair, the two halves in antiphase.
-#ifdef RS_WG_FAIRPRIO
-#ifndef RS_WG_FAIRMODE
-#define RS_WG_FAIRMODE 2
-#endif
-  const bool younger = WPB == 8 && wave >= WPB / 2;
-  auto seg = [&](int k) {
-    if (WPB == 8) {
-      if (RS_WG_FAIRMODE == 1) {        // both halves toggle, in antiphase
-        if (((k & 1) != 0) == younger) __builtin_amdgcn_s_setprio(RS_WG_FAIRPRIO); else __builtin_amdgcn_s_setprio(0);
-      } else {                          // only the younger half toggles: it wins its odd segments by priority, the older half the even ones by age
-        if (younger) { if (k & 1) __builtin_amdgcn_s_setprio(RS_WG_FAIRPRIO); else __builtin_amdgcn_s_setprio(0); }
-      }
-    }
-  };
-#else
-  auto seg = [](int) {};
-#endif
-
+  RS_STAMP_DECL;   // -DRS_DIAG=1 (tools/stamp_profile.py): 0 step prologue, 1 digits + forward pair, 2 wait for the key rows + barrier, 3 multiply-
+                   // accumulate, 4 barrier + next rows requested, 5 accumulator pre-read + inverse pair, 6 rounding + accumulator update, 7 group prologue / extract
   // my 1/WPB share of key row R -> ring slot R & 1
   const unsigned lane_off = (unsigned)lane * 16u;
   auto issue_row = [&](long R) {
@@ -738,45 +627,19 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
     // all global reads of this prologue are complete and every wave has left the previous group's
     // last multiply-accumulate before the ring is refilled
     __syncthreads();
-#ifndef RS_WG_ROTATE
-#define RS_WG_ROTATE 0   // even l: workgroup b walks the row pairs of a component in the order rotated by b. Measured -1.6 % on the REDsec
-                         // set (profiles/r03/v_ab_wg_pair_rotation_redsec.txt): this kernel pulls 16 KB per row and CU with a whole transform
-                         // pair to land, and gains more from every CU finding the row in L2 than it loses to channel contention
-#endif
-    // first row of the pair with running number kk (L pairs per step when l is even): the pairs of a component in rotated order
-    constexpr bool kRotate = RS_WG_ROTATE && C::L % 2 == 0;
-    const int wrot = kRotate ? (int)(blockIdx.x % (C::L / 2 > 0 ? C::L / 2 : 1)) : 0;
-    auto pair_row = [&](long kk) -> long {
-      if constexpr (!kRotate) return 2 * kk;
-      const long i = kk / C::L;
-      const int k = (int)(kk - i * C::L), comp = k / (C::L / 2);
-      int pp = k % (C::L / 2) + wrot;
-      if (pp >= C::L / 2) pp -= C::L / 2;
-      return i * KPL + (long)comp * C::L + 2 * pp;
+    // the pairs are requested in storage order, row R into slot 0 and R + 1 into slot 1: a running pointer and two fixed LDS
+    // byte addresses instead of a 64-bit row index, its compare, a multiply-add and a generic-pointer cast per row (the same
+    // change took the split lock-step kernel from 137 k to 145 k/s, profiles/r04/az_*)
+    const double* src_next = a.bk_x + (size_t)(wave * kChunksPerWave) * 128;
+    const unsigned key_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&s_key[0][0]) +
+                             (unsigned)(wave * kChunksPerWave) * 1024u;
+    auto issue_pair = [&] {
+      glds_chunks_at<kChunksPerWave>(src_next, lane_off, key_lds);
+      glds_chunks_at<kChunksPerWave>(src_next + kRowDoubles, lane_off, key_lds + (unsigned)(kRowDoubles * sizeof(double)));
+      src_next += 2 * kRowDoubles;
     };
-    int kk = 0;
-    // !kRotate: the pairs are requested in storage order, row R into slot 0 and R + 1 into slot 1: a running pointer and two
-    // fixed LDS byte addresses instead of a 64-bit row index, its compare, a multiply-add and a generic-pointer cast per row
-    // (the same change took the split lock-step kernel from 137 k to 145 k/s, profiles/r04/az_*)
-    [[maybe_unused]] const double* src_next = a.bk_x + (size_t)(wave * kChunksPerWave) * 128;
-    [[maybe_unused]] const unsigned key_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&s_key[0][0]) +
-                                              (unsigned)(wave * kChunksPerWave) * 1024u;
-    auto issue_pair = [&](int kk_) {
-      if constexpr (kRotate) {
-        const long Rn = pair_row(kk_);
-        issue_row(Rn); issue_row(Rn + 1);
-      } else {
-        glds_chunks_at<kChunksPerWave>(src_next, lane_off, key_lds);
-        glds_chunks_at<kChunksPerWave>(src_next + kRowDoubles, lane_off, key_lds + (unsigned)(kRowDoubles * sizeof(double)));
-        src_next += 2 * kRowDoubles;
-      }
-    };
-    issue_pair(0);
+    issue_pair();
     RS_STAMP(7);
-#ifdef RS_T_STAGGER   // timing experiments only: start the waves RS_T_STAGGER x 64 cycles apart
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (int w = 0; w < wave * RS_T_STAGGER; ++w) __builtin_amdgcn_s_sleep(1);
-#endif
 
     // Rows are processed in PAIRS (R, R+1), the two digit transforms interleaved phase by phase.
     // Barrier 1 of a pair publishes both rows (each wave first waits for its own shares); barrier 2
@@ -818,46 +681,28 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
             if (qB == 0) { if (compB) load_d(std::true_type{}); else load_d(std::false_type{}); }
           }
           Xf::digits(xb, d, qB);
-          Xf::fwd_pair_wg(lane, xa, xb, tw, buf, seg);
+          Xf::fwd_pair_wg(lane, xa, xb, tw, buf);
         }
         RS_STAMP(1);
-#ifndef RS_T_NOBAR   // timing experiments only (results are wrong without the barriers)
-#ifdef RS_WG_BAREBAR   // A/B: bare s_barrier behind explicit counts instead of __syncthreads()
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-#endif
-#endif
         RS_STAMP(2);
         if (work) {
-#ifdef RS_NO_MAC_STREAM
-          mac_row(s0, s1, xa, 0);
-          mac_row(s0, s1, xb, 1);
-#else
           mac_pair_stream(s0, s1, xa, xb, s_key[0], s_key[1], lane);
-#endif
         }
         RS_STAMP(3);
-#ifndef RS_T_NOBAR
-#ifdef RS_WG_BAREBAR
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
         __syncthreads();
-#endif
         R += 2;
-        ++kk;
-        if (R < total_rows) issue_pair(kk);
-#endif
+        if (R < total_rows) issue_pair();
         RS_STAMP(4);
       };
       if constexpr (C::L % 2 == 0) {
         if (work) load_d(std::false_type{});
 #pragma unroll 1
-        for (int q = 0; q < C::L; q += 2) { int qq = q + 2 * wrot; if (qq >= C::L) qq -= C::L; pair(0, qq, 0, qq + 1); }
+        for (int q = 0; q < C::L; q += 2) pair(0, q, 0, q + 1);
         if (work) { Xf::mid(s0, s1, f); load_d(std::true_type{}); }
 #pragma unroll 1
-        for (int q = 0; q < C::L; q += 2) { int qq = q + 2 * wrot; if (qq >= C::L) qq -= C::L; pair(1, qq, 1, qq + 1); }
+        for (int q = 0; q < C::L; q += 2) pair(1, q, 1, q + 1);
       } else {
         // odd l: the middle pair straddles the two accumulator components (no place for Xf::mid:
         // the workgroup form is only instantiated for policies whose mid() is empty)
@@ -869,15 +714,6 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
       }
 
       if (work) {
-#ifdef RS_NO_ACC_AHEAD
-        Xf::inverse_pair_wg_dit(lane, s0, s1, tw, buf, seg);
-#pragma unroll
-        for (int r = 0; r < kRegs; ++r) {
-          const int j = lane + 64 * r;
-          acc0[j] = (int32_t)((uint32_t)acc0[j] + (uint32_t)Xf::to_torus(s0[r], dev));
-          acc1[j] = (int32_t)((uint32_t)acc1[j] + (uint32_t)Xf::to_torus(s1[r], dev));
-        }
-#else
         // the accumulator words are read BEFORE the inverse pair (the digit transforms are dead, there
         // are registers to spare): read after it, every read-modify-write of the update exposed an LDS
         // round trip behind the store in front of it
@@ -885,7 +721,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
 #pragma unroll
         for (int r = 0; r < kRegs; ++r) { a0[r] = (uint32_t)acc0[lane + 64 * r]; a1[r] = (uint32_t)acc1[lane + 64 * r]; }
         wave_lds_sync();
-        Xf::inverse_pair_wg_dit(lane, s0, s1, tw, buf, seg);
+        Xf::inverse_pair_wg(lane, s0, s1, tw, buf);
         RS_STAMP(5);
 #pragma unroll
         for (int r = 0; r < kRegs; ++r) {
@@ -893,7 +729,6 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
           acc0[j] = (int32_t)(a0[r] + (uint32_t)Xf::to_torus(s0[r], dev));
           acc1[j] = (int32_t)(a1[r] + (uint32_t)Xf::to_torus(s1[r], dev));
         }
-#endif
         wave_lds_sync();
         RS_STAMP(6);
       }
@@ -980,17 +815,14 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
   int32_t* acc1 = s_acc[wave][1];
   typename Xf::State tw;
   Xf::init(tw, lane, s_tw, a.tw);
-#ifndef RS_WGS_KEEP_TW
-#define RS_WGS_KEEP_TW 9   // as RS_WG_KEEP_TW, for the forward transforms of this kernel: 6 / 3 spill 41 / 57 registers here, -9 % / -16 % (profiles/r03/n_ab_twiddles_kept_other_kernels.txt)
-#endif
-  FftTwKept<RS_WGS_KEEP_TW> tw_kept;
+  FftTwKept<9> tw_kept;
   fft_kept_load(tw_kept, tw);
   const int n = a.n;
   const long n_groups = (a.B + WPB - 1) / WPB;
   const int total_half = n * KPL * 2;   // half-rows of one blind rotation (n <= 1024 steps x 4 l: far inside an int; scalar compares)
   const unsigned lane_off = (unsigned)lane * 16u;
   auto sync_w = [] { wave_lds_sync(); };
-  RS_WGS_STAMP_DECL;   // -DRS_STAMPS -DRS_STAMPS_WGS (tools/stamp_profile.py --split): 0 step prologue + rotated differences, 1 digits + forward transform,
+  RS_WGS_STAMP_DECL;   // -DRS_DIAG=2 (tools/stamp_profile.py --split): 0 step prologue + rotated differences, 1 digits + forward transform,
                        // 2 key wait + barrier (low half), 3 multiply-accumulate low, 4 key wait + barrier (high half), 5 multiply-accumulate high,
                        // 6 two inverse pairs + update, 7 group prologue / extract
   int steps_done = 0;   // CMUX steps of the groups this workgroup has finished (XCD cohorts, rs_cohort.h)
@@ -1024,37 +856,18 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
     __syncthreads();
     int h_issue = 0;         // next half-row to request
     int slot_issue = 0;      // its slot, h_issue mod 3
-#ifndef RS_WGS_ROTATE
-#define RS_WGS_ROTATE 0   // workgroup b walks the l digits of a component in the order rotated by b: measured -11 % / -9 % (default-128 /
-                          // REDsec set, profiles/r03/v_ab_wgs_digit_rotation_split_mode.txt): like the unsplit lock-step kernel this form
-                          // lives on every CU finding the half-row in L2
-#endif
-    const int wrot = RS_WGS_ROTATE ? (int)(blockIdx.x % C::L) : 0;
-    int iss_i = 0, iss_k = 0;   // step and position (component, digit slot, half) of the next half-row to request
     const double* src_next = a.bk_x + (size_t)(wave * kChunks) * 128;   // this wave's share of the next half-row
     const unsigned key_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&s_key[0][0]) +
                              (unsigned)(wave * kChunks) * 1024u;
     auto issue_next = [&]() {
       if (h_issue < total_half) {
-        [[maybe_unused]] long hsrc = h_issue;
-        if (RS_WGS_ROTATE) {
-          const int comp = iss_k / (2 * C::L), k = iss_k - comp * 2 * C::L;
-          int q = (k >> 1) + wrot;
-          if (q >= C::L) q -= C::L;
-          hsrc = (((long)iss_i * KPL + (long)comp * C::L + q) << 1) + (k & 1);
-          if (++iss_k == 2 * KPL) { iss_k = 0; ++iss_i; }
-        }
-#ifdef RS_T_WGS_NOKEY   // TIMING PROBE (results are wrong): every step reads the half-rows of step 0, which stay in the L2s
-        hsrc %= 2 * KPL;
-#endif
-#if RS_WGS_ROTATE || defined(RS_T_WGS_NOKEY)
-        glds_chunks<kChunks>(a.bk_x + (size_t)hsrc * kSlotDoubles + (size_t)(wave * kChunks) * 128, lane_off, s_key[slot_issue] + (wave * kChunks) * 128);
-#else
         // half-rows are requested in storage order: a running pointer and the slot's byte address, seven scalar instructions
         // instead of the twenty-two of the general form (a 64-bit index compare, a shift-and-add pair, a pointer cast)
         glds_chunks_at<kChunks>(src_next, lane_off, key_lds + (unsigned)slot_issue * (unsigned)(kSlotDoubles * sizeof(double)));
         src_next += kSlotDoubles;
-#endif
+        if constexpr (diag::kNoKeyProbe) {   // diagnostic builds: every step reads the half-rows of step 0 (they stay in the L2s)
+          if ((h_issue + 1) % (2 * KPL) == 0) src_next -= (size_t)(2 * KPL) * kSlotDoubles;
+        }
         ++h_issue;
         slot_issue = slot_issue == 2 ? 0 : slot_issue + 1;
       }
@@ -1068,12 +881,8 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
     // (a bare s_barrier behind explicit counts: __syncthreads() would drain every outstanding load, i.e. also the
     // half-row requested one barrier ago, and with it half of the prefetch distance)
     auto publish = [&]() {
-#ifdef RS_WGS_DRAIN   // A/B: wait for every outstanding load, as __syncthreads() would
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
       if (h + 1 < total_half) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kChunks) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
       issue_next();
     };
     auto consumed = [&]() { ++h; slot = slot == 2 ? 0 : slot + 1; };
@@ -1097,9 +906,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
       auto row = [&](int q) {
         double x[kRegs];
         if (work) {
-          int qd = q + wrot;
-          if (qd >= C::L) qd -= C::L;
-          Xf::digits(x, d, qd);
+          Xf::digits(x, d, q);
           ffwd_planar(lane, x, tw_kept, buf, sync_w);
         }
         RS_WGS_STAMP(1);
@@ -1116,39 +923,6 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
       };
       // (the forward transforms stay single: run as software-pipelined pairs -- two transforms beside the four 32-register column
       // sums -- the kernel does not fit 256 registers: 1,040 bytes of scratch per lane, compiled in round 4 and dropped)
-#ifndef RS_WGS_PAIR
-#define RS_WGS_PAIR 0
-#endif
-#if RS_WGS_PAIR
-      auto row_pair = [&](int q) {
-        double xa[kRegs], xb[kRegs];
-        if (work) {
-          Xf::digits(xa, d, q);
-          Xf::digits(xb, d, q + 1);
-          Xf::fwd_pair_wg(lane, xa, xb, tw_kept, buf, FftNoSeg());
-        }
-        publish();
-        if (work) mac_half_stream(sl0, sl1, xa, s_key[slot], lane);
-        consumed();
-        publish();
-        if (work) mac_half_stream(sh0, sh1, xa, s_key[slot], lane);
-        consumed();
-        publish();
-        if (work) mac_half_stream(sl0, sl1, xb, s_key[slot], lane);
-        consumed();
-        publish();
-        if (work) mac_half_stream(sh0, sh1, xb, s_key[slot], lane);
-        consumed();
-      };
-      if (work) load_d(std::false_type{});
-#pragma unroll 1
-      for (int q = 0; q + 1 < C::L; q += 2) row_pair(q);
-      if (C::L & 1) row(C::L - 1);
-      if (work) load_d(std::true_type{});
-#pragma unroll 1
-      for (int q = 0; q + 1 < C::L; q += 2) row_pair(q);
-      if (C::L & 1) row(C::L - 1);
-#else
       if (work) load_d(std::false_type{});
       RS_WGS_STAMP(0);
 #pragma unroll 1
@@ -1157,7 +931,6 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wgs_kernel(BlindRotateA
       RS_WGS_STAMP(0);
 #pragma unroll 1
       for (int q = 0; q < C::L; ++q) row(q);
-#endif
 
       if (work) {
         Xf::inverse_pair_wg(lane, sl0, sl1, tw, buf);
@@ -1241,12 +1014,9 @@ __global__ __launch_bounds__(512) void blind_rotate_duos_kernel(BlindRotateArgs 
   };
   // pair p = (i L + k) 2 + half holds the half-rows ((i KPL + comp L + q_k) 2 + half) of comp = 0, 1, where q_k = (k + rot) mod L:
   // workgroup b walks the l digits of a step in the order rotated by b (the rows of a step are independent), so that the 256
-  // workgroups of a launch do not pull the same half-rows through the same L2 channels at the same moments (RS_DUOS_ROTATE=0:
-  // the same order everywhere). This wave fetches chunks [4 (wave & 3), +4) of component wave >> 2.
-#ifndef RS_DUOS_ROTATE
-#define RS_DUOS_ROTATE 1
-#endif
-  const int rot = RS_DUOS_ROTATE ? (int)(blockIdx.x % C::L) : 0;
+  // workgroups of a launch do not pull the same half-rows through the same L2 channels at the same moments (600 sign
+  // bootstraps 12.06 -> 11.25 ms, profiles/r03/v_ab_*). This wave fetches chunks [4 (wave & 3), +4) of component wave >> 2.
+  const int rot = (int)(blockIdx.x % C::L);
   const int kcomp = duos_fetch_comp(wave);                                 // placement: rs_lds_plan.h (checked on the host)
   const size_t chunk_off = (size_t)duos_first_chunk(wave) * 128;
   const unsigned key_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&s_key[0][0]) + (unsigned)chunk_off * 8u;
@@ -1385,9 +1155,6 @@ __global__ __launch_bounds__(512) void blind_rotate_duos_kernel(BlindRotateArgs 
   }
 }
 
-#ifndef RS_COOP_ROTATE_ROWS
-#define RS_COOP_ROTATE_ROWS 1   // 0: every workgroup walks its rows in the same order; 1: rotated by the workgroup index; 2: row groups rotated over the waves too
-#endif
 // -------------------------------------------------------------------------------------------------
 // Cooperative blind rotation on the SPLIT key (RS_MODE_FFT_SPLIT at latency batch sizes, B <= 2 x #CUs, N = 1024): G waves
 // share ONE ciphertext as in blind_rotate_coop_kernel. Wave g transforms the digit rows [g R, (g+1) R) and multiplies each
@@ -1452,11 +1219,7 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coops_kernel(BlindRotateA
     for (int r = 0; r < kRegs; ++r) d[r] = gadget_prepare<C>(rotated_diff(s_acc[comp], lane + 64 * r, bara));
 #pragma unroll 1
     for (int rr = 0; rr < R; ++rr) {
-#if RS_COOP_ROTATE_ROWS >= 1   // as in blind_rotate_coop_kernel: the rows of a step in an order rotated by the workgroup index
       const int row = row_begin + (int)((rr + blockIdx.x) % R);
-#else
-      const int row = row_begin + rr;
-#endif
       const int q = row - comp * C::L;
       // half-row (row, half) = [column 0: N doubles][column 1: N doubles], pairs (re, im) of position 8 lane + v at [v][lane]
       const double2* lo0 = reinterpret_cast<const double2*>(a.bk_x + ((size_t)i * KPL + row) * 4 * kN);
@@ -1467,12 +1230,7 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coops_kernel(BlindRotateA
 #pragma unroll
         for (int v = 0; v < 4; ++v) { w0[v] = k0[(v0 + v) * 64 + lane]; w1[v] = k1[(v0 + v) * 64 + lane]; }
       };
-#ifndef RS_COOPS_AHEAD
-#define RS_COOPS_AHEAD 4   // key chunks (of 4 per row) requested across the transform: 1, 2 (the low half-row) or 4 (the whole row); with rotated
-                           // rows 196 sign bootstraps take 4.80 / 4.49 / 4.33 ms (profiles/r03/v_ab_coops_chunks_ahead.txt)
-#endif
       double x[kRegs];
-#if RS_COOPS_AHEAD >= 4
       double2 wa0[4], wa1[4], wb0[4], wb1[4], wc0[4], wc1[4], wd0[4], wd1[4];
       load4(lo0, lo1, 0, wa0, wa1);
       load4(lo0, lo1, 4, wb0, wb1);
@@ -1483,29 +1241,6 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coops_kernel(BlindRotateA
       Xf::mac(s[0], s[1], x, wb0, wb1, 4, f);
       Xf::mac(s[2], s[3], x, wc0, wc1, 0, f);
       Xf::mac(s[2], s[3], x, wd0, wd1, 4, f);
-#elif RS_COOPS_AHEAD >= 2
-      double2 wa0[4], wa1[4], wb0[4], wb1[4], wc0[4], wc1[4];
-      load4(lo0, lo1, 0, wa0, wa1);
-      load4(lo0, lo1, 4, wb0, wb1);
-      Xf::fwd_digits(lane, x, d, q, 0u, tw, buf, f);
-      load4(hi0, hi1, 0, wc0, wc1);
-      Xf::mac(s[0], s[1], x, wa0, wa1, 0, f);
-      load4(hi0, hi1, 4, wa0, wa1);
-      Xf::mac(s[0], s[1], x, wb0, wb1, 4, f);
-      Xf::mac(s[2], s[3], x, wc0, wc1, 0, f);
-      Xf::mac(s[2], s[3], x, wa0, wa1, 4, f);
-#else
-      double2 wa0[4], wa1[4], wb0[4], wb1[4];
-      load4(lo0, lo1, 0, wa0, wa1);
-      Xf::fwd_digits(lane, x, d, q, 0u, tw, buf, f);
-      load4(lo0, lo1, 4, wb0, wb1);
-      Xf::mac(s[0], s[1], x, wa0, wa1, 0, f);
-      load4(hi0, hi1, 0, wa0, wa1);
-      Xf::mac(s[0], s[1], x, wb0, wb1, 4, f);
-      load4(hi0, hi1, 4, wb0, wb1);
-      Xf::mac(s[2], s[3], x, wa0, wa1, 0, f);
-      Xf::mac(s[2], s[3], x, wb0, wb1, 4, f);
-#endif
     }
     // partial sums a wave does not own go through LDS (position u*64 + lane is conflict-free)
 #pragma unroll
@@ -1611,27 +1346,18 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
   int32_t* acc = s_acc[c][h];
   typename Xf::State tw;
   Xf::init(tw, lane, s_tw, a.tw);
-#ifndef RS_DUO_KEEP_TW
-#define RS_DUO_KEEP_TW 6   // as RS_WG_KEEP_TW, for the forward pairs of this kernel: the twiddles of the last stage group kept in registers. Round 3: 6 / 3
-                           // spilled 17 / 56 registers, no gain; since the column sums lost their selects (round 4) 6 fits: 7.71 -> 7.67 ms at 1,024 ciphertexts, 3: 7.83
-#endif
-  FftTwKept<RS_DUO_KEEP_TW> tw_kept;
+  FftTwKept<6> tw_kept;
   fft_kept_load(tw_kept, tw);
   const int n = a.n;
   constexpr uint32_t offset = gadget_offset<C>();
   double dev = 0.0;
   const long n_groups = (a.B + kCts - 1) / kCts;
-  RS_DUO_STAMP_DECL;   // -DRS_STAMPS -DRS_STAMPS_DUO (tools/stamp_coop8.py duo): 0 step prologue + rotated difference, 1 digits + forward pair,
+  RS_DUO_STAMP_DECL;   // -DRS_DIAG=4 (tools/stamp_coop8.py duo): 0 step prologue + rotated difference, 1 digits + forward pair,
                        // 2 key wait + barrier 1, 3 multiply-accumulate, 4 barrier 2 + next quad, 5 partial exchange (2 barriers), 6 inverse + update, 7 group prologue / extract
 
   const unsigned lane_off = (unsigned)lane * 16u;
-  // Workgroup b walks the row pairs of a step in the order rotated by b (they are independent), so that the workgroups of a launch
-  // do not pull the same key rows through the same L2 channels at the same moments (RS_DUO_ROTATE=0: the same order everywhere).
-#ifndef RS_DUO_ROTATE
-#define RS_DUO_ROTATE 0   // measured: no effect on the 1,024-neuron MNIST layer (profiles/r03/v_ab_duo_row_rotation.txt), unlike the split forms
-#endif
-  const int prot0 = RS_DUO_ROTATE ? (int)(blockIdx.x % (C::L / 2)) : 0;
-  auto prot = [&](int p) { const int v = p + prot0; return v >= C::L / 2 ? v - C::L / 2 : v; };
+  // (Row pairs walked in per-workgroup rotated orders, as in the split forms: no effect on the 1,024-neuron MNIST layer,
+  // profiles/r03/v_ab_duo_row_rotation.txt -- every workgroup walks them in storage order.)
   // quad (i, p): rows i KPL + hh L + 2 p + k; this wave fetches half of slot (wave >> 1)
   auto issue_quad = [&](int i, int p) {
     const int slot = duo_quad_slot(wave), chunk0 = duo_quad_first_chunk(wave);   // placement: rs_lds_plan.h (checked on the host)
@@ -1676,7 +1402,7 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
       }
     }
     __syncthreads();   // bara complete; previous group's last reads of the quad buffer are over
-    issue_quad(0, prot(0));
+    issue_quad(0, 0);
     RS_DUO_STAMP(7);
 
     unsigned bara_next = active ? s_bara[c][0] : 0;   // read one step ahead
@@ -1700,25 +1426,20 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
       for (int p = 0; p < C::L / 2; ++p) {
         double xa[kRegs], xb[kRegs];
         if (work) {
-          Xf::digits(xa, d, 2 * prot(p));
-          Xf::digits(xb, d, 2 * prot(p) + 1);
-          Xf::fwd_pair_wg(lane, xa, xb, tw_kept, buf, FftNoSeg());
+          Xf::digits(xa, d, 2 * p);
+          Xf::digits(xb, d, 2 * p + 1);
+          Xf::fwd_pair_wg(lane, xa, xb, tw_kept, buf);
         }
         RS_DUO_STAMP(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                         // quad (i, p) published
         RS_DUO_STAMP(2);
         if (work) {
-#ifdef RS_NO_MAC_STREAM
-          mac_row(h ? given : own, h ? own : given, xa, 2 * h);
-          mac_row(h ? given : own, h ? own : given, xb, 2 * h + 1);
-#else
           mac_pair_stream(own, given, xa, xb, s_key[2 * h], s_key[2 * h + 1], lane, own_col, given_col);
-#endif
         }
         RS_DUO_STAMP(3);
         __syncthreads();                         // every wave has finished reading it
-        if (p + 1 < C::L / 2) issue_quad(i, prot(p + 1));
+        if (p + 1 < C::L / 2) issue_quad(i, p + 1);
         RS_DUO_STAMP(4);
       }
       // partial exchange through the idle quad buffer: wave (c, h) hands over its partial of column 1 - h
@@ -1735,7 +1456,7 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
         for (int u = 0; u < kRegs; ++u) mine[u] += theirs[u * 64 + lane];
       }
       __syncthreads();                           // partials consumed: the quad buffer may be refilled
-      if (i + 1 < n) issue_quad(i + 1, prot(0));
+      if (i + 1 < n) issue_quad(i + 1, 0);
       RS_DUO_STAMP(5);
       if (work) {
         uint32_t a0[kRegs];   // accumulator words read ahead of the inverse transform (see the workgroup kernel)
@@ -1776,11 +1497,6 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
 // and 1 sum one column each, run the inverse transform and update the shared accumulator. Two
 // workgroup barriers per CMUX step.
 // -------------------------------------------------------------------------------------------------
-#ifndef RS_COOP_HALF_ROW
-#define RS_COOP_HALF_ROW 0   // 1: only the first half of a key row requested across the transform. With every workgroup on the same rows
-                             // that was the faster form (3.12 against 3.45 ms, round 1); with the rows walked in rotated orders the
-                             // whole row in flight wins: 3.21 -> 3.01 ms for 196 sign bootstraps (profiles/r03/v_ab_coop_whole_row.txt)
-#endif
 template <class Xf, int G>
 __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateArgs a) {
   using C = typename Xf::Cfg;
@@ -1798,22 +1514,12 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateAr
   const long ct = blockIdx.x;
   const Field f = a.f;
   double* buf = s_buf[wave];
-#ifdef RS_COOP_KEEP_TW   // A/B: per-lane twiddles in registers (XfFft). Measured: no gain on the 196-neuron MNIST layer, which is
-                         // bound by key streaming (3.31-3.38 against 3.34-3.41 ms, profiles/r03/n_ab_twiddles_kept_other_kernels.txt)
-  typename Xf::LatencyState tw;
-  Xf::init_latency(tw, lane, s_tw, a.tw);
-#else
   typename Xf::State tw;
   Xf::init(tw, lane, s_tw, a.tw);
-#endif
   const int32_t* row0 = a.in0 + ct * a.W;
   const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
   const int n = a.n;
-#if RS_COOP_ROTATE_ROWS >= 2   // ... and which wave takes which group of rows
-  const int grp = (int)((wave + blockIdx.x) % G);
-#else
   const int grp = wave;
-#endif
   const int comp = grp / (G / 2);
   const int row_begin = grp * R;
   double dev = 0.0;
@@ -1839,86 +1545,29 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateAr
     double s0[kRegs], s1[kRegs];
 #pragma unroll
     for (int u = 0; u < kRegs; ++u) { s0[u] = 0.0; s1[u] = 0.0; }
-#ifdef RS_T_COOP_NOKEY   // TIMING PROBE (results are wrong): every step reads the rows of step 0, which stay in the L2s
-    const double* bk_i = a.bk_x;
-#else
-    const double* bk_i = a.bk_x + (size_t)i * KPL * 2 * kN;
-#endif
+    const double* bk_i = a.bk_x + (size_t)diag::key_step(i) * KPL * 2 * kN;
     int32_t d[kRegs];
 #pragma unroll
     for (int r = 0; r < kRegs; ++r) {
       d[r] = rotated_diff(s_acc[comp], lane + 64 * r, bara);
       if (Xf::kPreparedDigits) d[r] = gadget_prepare<C>(d[r]);
     }
-#ifndef RS_COOP_TWO_ROWS
-#define RS_COOP_TWO_ROWS 0   // the key of the NEXT row requested before the transform of this one (two rows in flight per wave): measured
-                             // slower, 3.31 against 3.0 ms for 196 sign bootstraps (profiles/r03/v_ab_coop_two_rows_in_flight.txt): one row is the spot
-#endif
-#if RS_COOP_TWO_ROWS
-    if constexpr (!(Xf::kSplitKeyLoads && RS_COOP_HALF_ROW)) {
-      auto row_of = [&](int rr) {
-#if RS_COOP_ROTATE_ROWS >= 1
-        return row_begin + (int)((rr + blockIdx.x) % R);
-#else
-        return row_begin + rr;
-#endif
-      };
-      auto load_row = [&](int rr, double2 (&w0)[8], double2 (&w1)[8]) {
-        const double2* bp0 = reinterpret_cast<const double2*>(bk_i + (size_t)(row_of(rr) * 2) * kN);
-        const double2* bp1 = bp0 + kN / 2;
-#pragma unroll
-        for (int v = 0; v < 8; ++v) { w0[v] = bp0[v * 64 + lane]; w1[v] = bp1[v * 64 + lane]; }
-      };
-      auto do_row = [&](int rr, const double2 (&w0)[8], const double2 (&w1)[8]) {
-        double x[kRegs];
-        Xf::fwd_digits(lane, x, d, row_of(rr) - comp * C::L, offset, tw, buf, f);
-        Xf::mac8(s0, s1, x, w0, w1, f);
-      };
-      double2 wA0[8], wA1[8], wB0[8], wB1[8];
-      load_row(0, wA0, wA1);
-      int rr = 0;
-#pragma unroll 1
-      for (; rr + 1 < R; rr += 2) {
-        load_row(rr + 1, wB0, wB1);
-        do_row(rr, wA0, wA1);
-        if (rr + 2 < R) load_row(rr + 2, wA0, wA1);
-        do_row(rr + 1, wB0, wB1);
-      }
-      if (rr < R) do_row(rr, wA0, wA1);
-    } else
-#endif
 #pragma unroll 1
     for (int rr = 0; rr < R; ++rr) {
-#if RS_COOP_ROTATE_ROWS >= 1   // workgroups walk their rows of a step in different orders (the rows of a step are independent), so that the
-                               // whole chip does not pull the same key rows through the same L2 channels at the same moments: the 196-neuron MNIST
-                               // layer 3.33 -> 3.15 ms (4 alternating runs each; rotating the row groups over the waves as well: 3.24 ms;
-                               // profiles/r03/v_ab_coop_row_rotation.txt)
+      // workgroups walk their rows of a step in different orders (the rows of a step are independent), so that the whole chip
+      // does not pull the same key rows through the same L2 channels at the same moments: the 196-neuron MNIST layer
+      // 3.33 -> 3.15 ms (profiles/r03/v_ab_coop_row_rotation.txt)
       const int row = row_begin + (int)((rr + blockIdx.x) % R);
-#else
-      const int row = row_begin + rr;
-#endif
       const int q = row - comp * C::L;
       const double2* bp0 = reinterpret_cast<const double2*>(bk_i + (size_t)(row * 2) * kN);
       const double2* bp1 = bp0 + kN / 2;
       double x[kRegs];
-      if constexpr (Xf::kSplitKeyLoads && RS_COOP_HALF_ROW) {
-        // first half of the key row prefetched across the transform, second half fetched after it
-        double2 wa0[4], wa1[4];
+      // the whole key row is requested across the transform (3.21 -> 3.01 ms once the rows were rotated, v_ab_coop_whole_row.txt)
+      double2 w0[8], w1[8];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) { wa0[v] = bp0[v * 64 + lane]; wa1[v] = bp1[v * 64 + lane]; }
-        Xf::fwd_digits(lane, x, d, q, offset, tw, buf, f);
-        double2 wb0[4], wb1[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) { wb0[v] = bp0[(v + 4) * 64 + lane]; wb1[v] = bp1[(v + 4) * 64 + lane]; }
-        Xf::mac(s0, s1, x, wa0, wa1, 0, f);
-        Xf::mac(s0, s1, x, wb0, wb1, 4, f);
-      } else {
-        double2 w0[8], w1[8];
-#pragma unroll
-        for (int v = 0; v < 8; ++v) { w0[v] = bp0[v * 64 + lane]; w1[v] = bp1[v * 64 + lane]; }
-        Xf::fwd_digits(lane, x, d, q, offset, tw, buf, f);
-        Xf::mac8(s0, s1, x, w0, w1, f);
-      }
+      for (int v = 0; v < 8; ++v) { w0[v] = bp0[v * 64 + lane]; w1[v] = bp1[v * 64 + lane]; }
+      Xf::fwd_digits(lane, x, d, q, offset, tw, buf, f);
+      Xf::mac8(s0, s1, x, w0, w1, f);
     }
     // partial sums exchanged through LDS: position u*64 + lane is conflict-free
 #pragma unroll
@@ -1977,13 +1626,6 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateAr
 // accumulator = 152 KB, one workgroup per CU. Integer results are independent of the summation order (the
 // sums are rounded to the exact integers, certificate-tracked as everywhere); two workgroup barriers per step.
 // -------------------------------------------------------------------------------------------------
-#ifndef RS_COOP8_ATOMICS
-#define RS_COOP8_ATOMICS 1   // the partial column sums meet by LDS f64 atomics (0: one store + 7 x 16 reads per inverse wave; 196 sign bootstraps
-                             // 2.92 -> 2.64 ms on one box, profiles/r04/i_ab_coop8_atomics.txt)
-#endif
-#ifndef RS_COOP8_KEEP_TW
-#define RS_COOP8_KEEP_TW 0   // 1: per-lane twiddles in registers (FftTwKept<3>) instead of LDS table reads
-#endif
 template <class Xf>
 __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs a) {
   using C = typename Xf::Cfg;
@@ -1993,11 +1635,7 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
   constexpr int kInvA = coop8_inv_a(L), kInvB = coop8_inv_b(L);   // placement: rs_lds_plan.h (checked on the host)
   __shared__ double s_tw[Xf::kTableDoubles + 1];
   __shared__ double s_buf[G][kBufDoubles];
-#if RS_COOP8_ATOMICS
   __shared__ double s_sum[2][kN];   // the two column sums, added up by LDS floating-point atomics (zero between steps)
-#else
-  __shared__ double s_part[G][kN];
-#endif
   __shared__ int32_t s_acc[2][kN];
   stage_tables(s_tw, a.tw, 64 * G, Xf::kTableDoubles);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -2005,16 +1643,9 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
   const long ct = blockIdx.x;
   const Field f = a.f;
   double* buf = s_buf[wave];
-#if RS_COOP8_ATOMICS
   for (int e = threadIdx.x; e < 2 * kN; e += 64 * G) (&s_sum[0][0])[e] = 0.0;
-#endif
-#if RS_COOP8_KEEP_TW
-  typename Xf::LatencyState tw;
-  Xf::init_latency(tw, lane, s_tw, a.tw);
-#else
   typename Xf::State tw;
   Xf::init(tw, lane, s_tw, a.tw);
-#endif
   const int32_t* row0 = a.in0 + ct * a.W;
   const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
   const int n = a.n;
@@ -2022,7 +1653,7 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
   const int comp = coop8_comp(L, wave), cnt = coop8_row_count(L, wave), first = coop8_row_first(L, wave);
   [[maybe_unused]] const int r_first = cnt > 0 ? (int)(blockIdx.x % (unsigned)cnt) : 0;
   double dev = 0.0;
-  RS_C8_STAMP_DECL;   // -DRS_STAMPS -DRS_STAMPS_COOP8 (tools/stamp_profile.py coop8): 0 mask word, 1 rotated difference, 2 rows (forward +
+  RS_C8_STAMP_DECL;   // -DRS_DIAG=8 (tools/stamp_coop8.py): 0 mask word, 1 rotated difference, 2 rows (forward +
                       // multiply-accumulate), 3 atomics issued, 4 barrier 1, 5 inverse + accumulator update, 6 barrier 2, 7 prologue / extract
   auto word = [&](int i) -> int32_t {
     uint32_t v = (uint32_t)a.c0 * (uint32_t)row0[i];
@@ -2050,11 +1681,7 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
 #pragma unroll
     for (int u = 0; u < kRegs; ++u) { s0[u] = 0.0; s1[u] = 0.0; }
     if (cnt > 0) {
-#ifdef RS_T_COOP_NOKEY   // TIMING PROBE (results are wrong): every step reads the rows of step 0, which stay in the L2s
-      const double* bk_i = a.bk_x;
-#else
-      const double* bk_i = a.bk_x + (size_t)i * KPL * 2 * kN;
-#endif
+      const double* bk_i = a.bk_x + (size_t)diag::key_step(i) * KPL * 2 * kN;
       int32_t d[kRegs];
 #pragma unroll
       for (int r = 0; r < kRegs; ++r) d[r] = gadget_prepare<C>(rotated_diff(s_acc[comp], lane + 64 * r, bara));
@@ -2062,15 +1689,8 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
       [[maybe_unused]] int r_run = r_first;   // rr = 0 starts at blockIdx.x mod cnt in every step
 #pragma unroll 1
       for (int rr = 0; rr < cnt; ++rr) {
-#ifndef RS_COOP8_RUNNING_ROW
-#define RS_COOP8_RUNNING_ROW 1   // the rotated row index kept running instead of a modulo by the run-time row count per row (A/B)
-#endif
-#if RS_COOP8_RUNNING_ROW
         const int q = first + r_run;                                       // per-workgroup row order, as in the four-wave form
         r_run = r_run + 1 == cnt ? 0 : r_run + 1;
-#else
-        const int q = first + (int)((rr + blockIdx.x) % (unsigned)cnt);   // per-workgroup row order, as in the four-wave form
-#endif
         const double2* bp0 = reinterpret_cast<const double2*>(bk_i + (size_t)((comp * L + q) * 2) * kN);
         const double2* bp1 = bp0 + kN / 2;
         double x[kRegs];
@@ -2082,7 +1702,6 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
       }
       RS_C8_STAMP(2);
     }
-#if RS_COOP8_ATOMICS
     // every wave adds its two partial sums into the column sums with ds_add_f64 (no return value: 32 instructions that overlap
     // the other waves' transforms); the order of the floating-point additions is free -- the sums are rounded to the exact
     // integers afterwards, with the certificate watching the distance as everywhere
@@ -2112,55 +1731,6 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
     __syncthreads();   // accumulator updated, sums zero
     RS_C8_STAMP(6);
     continue;
-#else
-    // partial sums: column 0 into the wave's own (now idle) exchange buffer, column 1 into its s_part slot; position
-    // u * 64 + lane is conflict-free. kInvA / kInvB keep the column they will invert in registers.
-    {
-      const int home0 = coop8_partial_home(L, wave, 0), home1 = coop8_partial_home(L, wave, 1);
-      if (home0 != kHomeRegisters) {
-        double* p0 = home0 == kHomePartSlot ? s_part[wave] : buf;
-#pragma unroll
-        for (int u = 0; u < kRegs; ++u) p0[u * 64 + lane] = s0[u];
-      }
-      if (home1 != kHomeRegisters) {
-#pragma unroll
-        for (int u = 0; u < kRegs; ++u) s_part[wave][u * 64 + lane] = s1[u];
-      }
-    }
-    __syncthreads();   // partials visible; every wave has finished reading the accumulator
-    if (wave == kInvA || wave == kInvB) {
-      double x[kRegs];
-      if (wave == kInvA) {
-#pragma unroll
-        for (int u = 0; u < kRegs; ++u) x[u] = s0[u];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          if (g == kInvA) continue;
-          const double* src = coop8_partial_home(L, g, 0) == kHomePartSlot ? s_part[g] : s_buf[g];
-#pragma unroll
-          for (int u = 0; u < kRegs; ++u) x[u] += src[u * 64 + lane];
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < kRegs; ++u) x[u] = s1[u];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          if (g == kInvB) continue;
-#pragma unroll
-          for (int u = 0; u < kRegs; ++u) x[u] += s_part[g][u * 64 + lane];
-        }
-      }
-      wave_lds_sync();   // this wave's reads of the partials are issued before its transform reuses LDS (in-order DS queue)
-      Xf::inverse(lane, x, tw, buf, f);
-      int32_t* acc = s_acc[wave == kInvA ? 0 : 1];
-#pragma unroll
-      for (int r = 0; r < kRegs; ++r) {
-        const int j = lane + 64 * r;
-        acc[j] = (int32_t)((uint32_t)acc[j] + (uint32_t)Xf::to_torus(x[r], dev));
-      }
-    }
-    __syncthreads();   // accumulator updated; partial slots free
-#endif
   }
   int32_t* out = a.u_out + ct * (kN + 1);
   if (wave == 0) {
@@ -2245,7 +1815,7 @@ template <class C>
 static hipError_t cohort_setup(BlindRotateArgs& w, long groups, long grid, const LaunchOpts& o, hipStream_t st) {
   if (!w.progress || o.no_cohort || grid > 8L * kCohortSlots || groups <= grid) { w.progress = nullptr; return hipSuccess; }
   const long step_bytes = 2L * C::L * 16384;
-  w.cohort_lag = (int32_t)std::max<long>(1, (4L << 20) / 3 / step_bytes - RS_COHORT_LAG_ADJ);
+  w.cohort_lag = (int32_t)std::max<long>(1, (4L << 20) / 3 / step_bytes - 1);
   w.cohort_every = w.cohort_lag >= 4 ? 2 : 1;
   return hipMemsetAsync(w.progress, 0x7f, 8 * kCohortSlots * sizeof(int), st);
 }
@@ -2282,14 +1852,6 @@ static hipError_t launch_br_xf(const BlindRotateArgs& a, int wpb, long num_cus, 
     // throughput form: lock-step workgroups of 8 ciphertexts, key rows shared in LDS. Taken as soon as the batch exceeds
     // FOUR ciphertexts per CU: a partly filled single round of it (10.2 ms for up to 2,048 default-128 ciphertexts) beats two
     // rounds of the half-size forms (12.8-13.1 ms at 1,536; tools/midsize_rate.py).
-#ifdef RS_T_WPB4   // timing experiment: one wave per SIMD (4 ciphertexts per workgroup, still one workgroup per CU by LDS)
-    if (!o.no_wg && a.B >= 8L * num_cus) {
-      const long groups = (a.B + 3) / 4;
-      const long grid = groups < num_cus ? groups : num_cus;
-      hipLaunchKernelGGL((blind_rotate_wg_kernel<Xf, 4>), dim3((unsigned)grid), dim3(256), 0, st, a);
-      return done(kFormWorkgroup, 4, 4 * grid);
-    }
-#endif
     if (!o.no_wg && a.B > 4L * num_cus) {
       // The grid walks the batch in rounds of 8 x #CUs ciphertexts. A last round of at most 4 x #CUs of them is cut off
       // and runs in the form that batch size would take by itself (cooperative / duo / half-size groups: 3.1-8.2 ms against
@@ -2420,7 +1982,7 @@ hipError_t launch_blind_rotate_split_wg(int cfg, const BlindRotateArgs& a, int n
     // XCD cohorts (see cohort_step): only for launches whose workgroups walk several groups, i.e. sweep the key more than once.
     // A CMUX step reads 2 * 2l half-rows of 16 KB; the lag keeps a cohort inside about a third of its 4 MB L2.
     const long step_bytes = 4L * (cfg == 1 ? 10 : 3) * 16384;
-    w.cohort_lag = (int32_t)std::max<long>(1, (4L << 20) / 3 / step_bytes - RS_COHORT_LAG_ADJ);
+    w.cohort_lag = (int32_t)std::max<long>(1, (4L << 20) / 3 / step_bytes - 1);
     w.cohort_every = w.cohort_lag >= 4 ? 2 : 1;
     if (hipError_t e = hipMemsetAsync(w.progress, 0x7f, 8 * kCohortSlots * sizeof(int), st); e != hipSuccess) return e;
   } else {
@@ -2474,13 +2036,13 @@ hipError_t launch_polymul(int cfg, int mode, const int32_t* a_small, const int32
 
 }  // namespace rs
 
-#if defined(RS_STAMPS) && (RS_BS_PART & RS_STAMP_PART)
+#if RS_BS_PART & RS_DIAG_STAMP_PART
 // diagnostic builds only (not part of include/redsec_hip.h): copy the per-wave phase sums to the host and clear them
 extern "C" int rs_debug_read_stamps(unsigned long long* host, size_t count) {
   const size_t all = sizeof(rs::g_rs_stamps) / sizeof(unsigned long long);
   if (count > all) count = all;
   if (hipMemcpyFromSymbol(host, HIP_SYMBOL(rs::g_rs_stamps), count * sizeof(unsigned long long)) != hipSuccess) return 1;
-  static unsigned long long zeros[256 * 8 * rs::kStampPhases];
+  static unsigned long long zeros[256 * 8 * rs::diag::kStampPhases];
   return hipMemcpyToSymbol(HIP_SYMBOL(rs::g_rs_stamps), zeros, sizeof(zeros)) == hipSuccess ? 0 : 1;
 }
 #endif

@@ -190,16 +190,7 @@ void emu_fft_forward(Wave& w, const double* tw, double* buf) {
   for (int l = 0; l < kLanes; ++l) rs::ffwd_F3(l, w.x[l], buf);
   for (int l = 0; l < kLanes; ++l) rs::ffwd_F4(l, w.x[l], t[l], buf);
 }
-static int g_dit = 0;      // 1: the decimation-in-time inverse of the lock-step workgroup kernel (finv_pair_dit's stages)
 void emu_fft_inverse(Wave& w, const double* tw, double* buf) {
-  if (g_dit) {
-    for (int l = 0; l < kLanes; ++l) rs::fft_dit3_ahead<2>(w.x[l], rs::FftTwTable{tw, l});
-    emu_exchange<rs::kLayC, rs::kLayB, 2>(w, buf);
-    for (int l = 0; l < kLanes; ++l) rs::fft_dit3_ahead<1>(w.x[l], rs::FftTwTable{tw, l});
-    emu_exchange<rs::kLayB, rs::kLayA, 1>(w, buf);
-    for (int l = 0; l < kLanes; ++l) rs::fft_dit3_ahead<0>(w.x[l], rs::FftTwTable{tw, l});
-    return;
-  }
   static rs::FftTw t[kLanes];
   for (int l = 0; l < kLanes; ++l) rs::fft_tw_load(t[l], l, tw);
   if (g_planar) {
@@ -840,7 +831,6 @@ int rs_emu_gen_literal_twiddle_check() {
 // selects the exchange form emulated by the FFT entry points (0 interleaved, 1 planar)
 void rs_emu_set_planar(int on) { g_planar = on; }
 // selects the inverse transform emulated by the FFT entry points (0 Gentleman-Sande, 1 decimation in time)
-void rs_emu_set_dit(int on) { g_dit = on; }
 
 // FFT-mode product of a small polynomial with a torus polynomial; returns the largest distance to
 // the nearest integer seen before rounding in *max_dev.

@@ -34,14 +34,6 @@ namespace rs {
 constexpr int kM = kN / 2;           // complex points
 constexpr int kCRegs = 8;            // complex values per lane
 constexpr int kFftTwDoubles = 2 * kM;  // complex twiddle table (interleaved re, im), stage-transposed
-// Tables of the decimation-in-time inverse (finv_pair<.., DIT>), appended to the table above (complex entries):
-//   kDitB + 8 e + c   (c = lane & 7):  e = 0: w16^-c   1: w32^-c   2: w64^-c   3: w64^-(c+8)            w_n = exp(2 pi i / n)
-//   kDitA + 64 e + L  (L = lane):      e = 0: w128^-L  1: w256^-L  2 + k: alpha_k = psi^-(L + 64 k)   6 + k: beta_k = alpha_k w512^-(L + 64 k)
-// (k = 0..3, psi = exp(2 pi i / 2048): the twist the forward transform folds into its twiddles)
-constexpr int kDitB = kM;
-constexpr int kDitA = kM + 32;
-constexpr int kFftDitEntries = 32 + 640;
-constexpr int kFftTwDoublesAll = 2 * (kM + kFftDitEntries);   // 18.9 KB
 
 struct Cplx { double re, im; };
 
@@ -331,7 +323,7 @@ RS_HD int flay_index(int lane, int k) {
 // Device: volatile stores stay eight separate ds_write_b64 (3 source dwords = 6 cycles on the VGPR -> LDS
 // path each); merged into ds_write2_b64 by the compiler a pair costs 13 (MI355X LDS table). The store
 // path is what bounds the exchange phases (halving the stores in a timing build: +22 %).
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RS_NO_SPLIT_STORES)
+#if defined(__HIP_DEVICE_COMPILE__)
 #define RS_PLANE_STORE(buf, pos, v) (*((volatile __attribute__((address_space(3))) double*)(buf) + (pos)) = (v))
 #else
 #define RS_PLANE_STORE(buf, pos, v) ((buf)[pos] = (v))
@@ -346,48 +338,6 @@ RS_HD int flay_index(int lane, int k) {
 // (low halves) and of its twin (high halves): four 16-byte reads per plane, the cycles of eight ds_read_b64. Row bases
 // (dwords) give every 16-lane group of a ds_read_b128 all 64 banks: residues {0, 4, 32, 36} by k mod 4.
 RS_HD int frow_base(int k, int hi) { const int c = k & 3; return 260 * c + 24 * (c >> 1) + 64 * (k >> 2) + 128 * hi; }   // classes at 0, 260, 544, 804
-#if defined(__HIP_DEVICE_COMPILE__) && defined(RS_ADDTID)
-template <int H>
-__device__ __forceinline__ void frow_store(const double (&x)[kRegs], double* buf) {
-  const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)buf);
-  unsigned lo[8], hi[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const unsigned long long b = (unsigned long long)__builtin_bit_cast(long long, x[k + 8 * H]);
-    lo[k] = (unsigned)b; hi[k] = (unsigned)(b >> 32);
-  }
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
-      "ds_write_addtid_b32 %2 offset:0\n\tds_write_addtid_b32 %10 offset:512\n\t"
-      "ds_write_addtid_b32 %3 offset:1040\n\tds_write_addtid_b32 %11 offset:1552\n\t"
-      "ds_write_addtid_b32 %4 offset:2176\n\tds_write_addtid_b32 %12 offset:2688\n\t"
-      "ds_write_addtid_b32 %5 offset:3216\n\tds_write_addtid_b32 %13 offset:3728\n\t"
-      "ds_write_addtid_b32 %6 offset:256\n\tds_write_addtid_b32 %14 offset:768\n\t"
-      "ds_write_addtid_b32 %7 offset:1296\n\tds_write_addtid_b32 %15 offset:1808\n\t"
-      "ds_write_addtid_b32 %8 offset:2432\n\tds_write_addtid_b32 %16 offset:2944\n\t"
-      "ds_write_addtid_b32 %9 offset:3472\n\tds_write_addtid_b32 %17 offset:3984\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "s"(base), "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(lo[4]), "v"(lo[5]), "v"(lo[6]), "v"(lo[7]),
-        "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]), "v"(hi[6]), "v"(hi[7])
-      : "memory");
-}
-template <int H>
-__device__ __forceinline__ void frow_load(int lane, double (&x)[kRegs], const double* buf) {
-  const int q = lane & 7, a8 = 8 * (lane >> 3);
-  const int4* plo = reinterpret_cast<const int4*>(reinterpret_cast<const int*>(buf) + frow_base(q, 0) + a8);
-  const int4* phi = reinterpret_cast<const int4*>(reinterpret_cast<const int*>(buf) + frow_base(q, 1) + a8);
-  const int4 l0 = plo[0], l1 = plo[1], h0 = phi[0], h1 = phi[1];
-  const unsigned lo[8] = {(unsigned)l0.x, (unsigned)l0.y, (unsigned)l0.z, (unsigned)l0.w, (unsigned)l1.x, (unsigned)l1.y, (unsigned)l1.z, (unsigned)l1.w};
-  const unsigned hi[8] = {(unsigned)h0.x, (unsigned)h0.y, (unsigned)h0.z, (unsigned)h0.w, (unsigned)h1.x, (unsigned)h1.y, (unsigned)h1.z, (unsigned)h1.w};
-#pragma unroll
-  for (int k = 0; k < 8; ++k) x[k + 8 * H] = __builtin_bit_cast(double, (long long)(((unsigned long long)hi[k] << 32) | lo[k]));
-}
-#define RS_ROW_FORM 1
-#else
-#define RS_ROW_FORM 0
-#endif
 
 // ---- 8-byte stores, 16-byte loads (the default form) ----
 // What an LDS instruction costs is vector-issue time of its SIMD (tools/lds_issue_bench.hip, profiles/r03/a_lds_issue_costs.jsonl:
@@ -417,25 +367,12 @@ RS_HD int xpos(int a, int b, int c) {
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef double rs_d2 __attribute__((ext_vector_type(2)));
 #endif
-#if defined(RS_PLANE_B64_LOADS) || RS_ROW_FORM   // A/B: the previous form, eight ds_read_b64 per plane (or the row form of RS_ADDTID)
-#define RS_WIDE_LOADS 0
-#else
-#define RS_WIDE_LOADS 1
-#endif
 
 template <int LAY, int T, int H>
 RS_HD void fpl_store(int lane, const double (&x)[kRegs], double* buf) {
-#if RS_ROW_FORM
-  if constexpr (T == 2) { frow_store<H>(x, buf); return; }
-#endif
-#if RS_WIDE_LOADS
   constexpr int TO = (T == 1) ? (LAY == kLayA ? kLayB : kLayA) : (LAY == kLayB ? kLayC : kLayB);
 #pragma unroll
   for (int k = 0; k < kCRegs; ++k) { int a, b, c; flay_abc<LAY>(lane, k, a, b, c); RS_PLANE_STORE(buf, (xpos<LAY, TO>(a, b, c)), x[k + 8 * H]); }
-#else
-#pragma unroll
-  for (int k = 0; k < kCRegs; ++k) { const int j = flay_index<LAY>(lane, k); RS_PLANE_STORE(buf, T == 1 ? ppos_t1(j) : ppos_t2(j), x[k + 8 * H]); }
-#endif
 }
 // Device: volatile LDS loads stay eight separate ds_read_b64 (2 LDS cycles each); merged into
 // ds_read2_b64 by the compiler they cost 8 cycles per pair (MI355X LDS table), i.e. twice as much.
@@ -446,10 +383,6 @@ RS_HD void fpl_store(int lane, const double (&x)[kRegs], double* buf) {
 #endif
 template <int LAY, int T, int H>
 RS_HD void fpl_load(int lane, double (&x)[kRegs], const double* buf) {
-#if RS_ROW_FORM
-  if constexpr (T == 2) { frow_load<H>(lane, x, buf); return; }
-#endif
-#if RS_WIDE_LOADS
   constexpr int FROM = (T == 1) ? (LAY == kLayB ? kLayA : kLayB) : (LAY == kLayC ? kLayB : kLayC);
 #pragma unroll
   for (int m = 0; m < kCRegs / 2; ++m) {
@@ -463,10 +396,6 @@ RS_HD void fpl_load(int lane, double (&x)[kRegs], const double* buf) {
     x[2 * m + 8 * H] = buf[pos]; x[2 * m + 1 + 8 * H] = buf[pos + 1];
 #endif
   }
-#else
-#pragma unroll
-  for (int k = 0; k < kCRegs; ++k) { const int j = flay_index<LAY>(lane, k); x[k + 8 * H] = RS_PLANE_LOAD(buf, T == 1 ? ppos_t1(j) : ppos_t2(j)); }
-#endif
 }
 // One exchange FROM layout L0 TO layout L1 through padding T; `sync` orders the wavefront's LDS
 // accesses (on the device a compiler-only fence: DS operations of one wavefront execute in order).
@@ -501,33 +430,23 @@ RS_HD void fft_inv3(double (&x)[kRegs], const TW& t) { fft_stage_inv<3 * G + 2>(
 // Exchange of x with `work(0..2)` -- three butterfly stages of the OTHER transform -- placed between
 // its LDS phases, so that the vector ALU has independent work while the stores drain (a 16-byte-per-
 // lane store occupies the LDS issue path for ~13 cycles) and the loads return.
-// The burst must be ISSUED before the butterflies it overlaps with: the instruction scheduler is free to
-// hoist run(k)'s vector instructions (no memory operands) above the LDS instructions of the burst, which
-// keeps the LDS pipe idle during the butterflies and exposes the burst's latency afterwards.
-#if defined(__HIP_DEVICE_COMPILE__) && defined(RS_ISSUE_FENCE_ON)
-#define RS_ISSUE_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define RS_ISSUE_FENCE() ((void)0)
-#endif
+// (A sched_barrier behind every burst, to force it out before the butterflies it overlaps with, was measured at -0.5 %:
+// with the twiddles a burst ahead the scheduler's own placement is better.)
 template <bool PLANAR, int L0, int L1, int T, class Sync, class Pre, class Run>
 RS_HD void fft_exchange_with(int lane, double (&x)[kRegs], double* buf, Sync sync, Pre pre, Run run) {
   // pre(k) issues the twiddle reads of work chunk k, run(k) is its butterflies. Every pre() is issued a
   // whole LDS burst AHEAD of its run() (see FftStageTw): wherever the scheduler then puts the burst that
   // run(k) overlaps with, the twiddles of run(k) are older than it and are waited for with a counted lgkmcnt.
   if (PLANAR) {
-    pre(0); pre(1); sync(); fpl_store<L0, T, 0>(lane, x, buf); RS_ISSUE_FENCE(); run(0); sync();
-    pre(2); sync(); fpl_load<L1, T, 0>(lane, x, buf); RS_ISSUE_FENCE(); run(1); sync();
-#ifndef RS_T_HALFSTORE   // timing probes only (wrong results): sensitivity to the store / load volume
+    pre(0); pre(1); sync(); fpl_store<L0, T, 0>(lane, x, buf); run(0); sync();
+    pre(2); sync(); fpl_load<L1, T, 0>(lane, x, buf); run(1); sync();
     fpl_store<L0, T, 1>(lane, x, buf);
-#endif
-    RS_ISSUE_FENCE(); run(2); sync();
-#ifndef RS_T_HALFLOAD
+    run(2); sync();
     fpl_load<L1, T, 1>(lane, x, buf);
-#endif
     sync();
   } else {
-    pre(0); pre(1); sync(); fil_store<L0, T>(lane, x, buf); RS_ISSUE_FENCE(); run(0); pre(2); run(1); sync();
-    fil_load<L1, T>(lane, x, buf); RS_ISSUE_FENCE(); run(2); sync();
+    pre(0); pre(1); sync(); fil_store<L0, T>(lane, x, buf); run(0); pre(2); run(1); sync();
+    fil_load<L1, T>(lane, x, buf); run(2); sync();
   }
 }
 // k-th stage (in execution order) of group G: twiddle fetch and butterflies
@@ -576,201 +495,34 @@ RS_HD void finv_planar(int lane, double (&x)[kRegs], const TW& t, double* buf, S
 // single forward transform, planar exchanges (split-key workgroup kernel)
 template <class TW, class Sync>
 RS_HD void ffwd_planar(int lane, double (&x)[kRegs], const TW& t, double* buf, Sync sync) {
-#ifdef RS_WGS_FWD_NOAHEAD   // A/B: twiddles fetched stage by stage (fewer registers, every fetch exposed)
-  fft_fwd3<0>(x, t);
-  fpl_exchange<kLayA, kLayB, 1>(lane, x, buf, sync);
-  fft_fwd3<1>(x, t);
-  fpl_exchange<kLayB, kLayC, 2>(lane, x, buf, sync);
-  fft_fwd3<2>(x, t);
-#else
   fft_fwd3_ahead<0>(x, t);
   fpl_exchange<kLayA, kLayB, 1>(lane, x, buf, sync);
   fft_fwd3_ahead<1>(x, t);
   fpl_exchange<kLayB, kLayC, 2>(lane, x, buf, sync);
   fft_fwd3_ahead<2>(x, t);
-#endif
 }
-// `seg(k)` is called at the start of the k-th of the six segments of a pair (the workgroup kernel toggles the wave's issue
-// priority there, see blind_rotate_wg_kernel; everywhere else it is a no-op).
-struct FftNoSeg { RS_HD void operator()(int) const {} };
-template <bool PLANAR, class TW, class Sync, class Seg = FftNoSeg>
-RS_HD void ffwd_pair(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TW& t, double* buf, Sync sync, Seg seg = Seg()) {
-  seg(0);
+// Two forward transforms as one software pipeline: six segments, each an LDS phase of one transform's exchange paired with a
+// butterfly stage group of the other.
+template <bool PLANAR, class TW, class Sync>
+RS_HD void ffwd_pair(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TW& t, double* buf, Sync sync) {
   fft_fwd3<0>(xa, t);
-  seg(1);
   fft_exchange_over<PLANAR, kLayA, kLayB, 1, 0, false>(lane, xa, xb, t, buf, sync);
-#ifdef RS_TW_NO_SHARE   // A/B: every transform fetches its own twiddles
-  seg(2);
-  fft_exchange_over<PLANAR, kLayA, kLayB, 1, 1, false>(lane, xb, xa, t, buf, sync);
-  seg(3);
-  fft_exchange_over<PLANAR, kLayB, kLayC, 2, 1, false>(lane, xa, xb, t, buf, sync);
-  seg(4);
-  fft_exchange_over<PLANAR, kLayB, kLayC, 2, 2, false>(lane, xb, xa, t, buf, sync);
-  seg(5);
-#ifdef RS_NO_TW_AHEAD
-  fft_fwd3<2>(xb, t);
-#else
-  fft_fwd3_ahead<2>(xb, t);
-#endif
-#else
   FftStageTw w[3];
-  seg(2);
   fft_exchange_over_keep<PLANAR, kLayA, kLayB, 1, 1, false, true>(lane, xb, xa, t, buf, sync, w);
-  seg(3);
   fft_exchange_over_keep<PLANAR, kLayB, kLayC, 2, 1, false, false>(lane, xa, xb, t, buf, sync, w);
-  seg(4);
   fft_exchange_over_keep<PLANAR, kLayB, kLayC, 2, 2, false, true>(lane, xb, xa, t, buf, sync, w);
-  seg(5);
   fft_stage_fwd_tw<6>(xb, w[0]); fft_stage_fwd_tw<7>(xb, w[1]); fft_stage_fwd_tw<8>(xb, w[2]);
-#endif
 }
-template <bool PLANAR, class TW, class Sync, class Seg = FftNoSeg>
-RS_HD void finv_pair(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TW& t, double* buf, Sync sync, Seg seg = Seg()) {
-  seg(0);
-#ifdef RS_TW_NO_SHARE
-#ifdef RS_NO_TW_AHEAD
-  fft_inv3<2>(xa, t);
-#else
-  fft_inv3_ahead<2>(xa, t);
-#endif
-#else
+template <bool PLANAR, class TW, class Sync>
+RS_HD void finv_pair(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TW& t, double* buf, Sync sync) {
   FftStageTw wk[3];   // group 2 (stages 8, 7, 6) in execution order; xb reuses them in segment 1
   fft_group_tw<2, true>(t, 0, wk[0]); fft_group_tw<2, true>(t, 1, wk[1]); fft_group_tw<2, true>(t, 2, wk[2]);
   fft_group_run<2, true>(xa, wk[0], 0); fft_group_run<2, true>(xa, wk[1], 1); fft_group_run<2, true>(xa, wk[2], 2);
-#endif
-#ifdef RS_TW_NO_SHARE
-  seg(1);
-  fft_exchange_over<PLANAR, kLayC, kLayB, 2, 2, true>(lane, xa, xb, t, buf, sync);
-  seg(2);
-  fft_exchange_over<PLANAR, kLayC, kLayB, 2, 1, true>(lane, xb, xa, t, buf, sync);
-  seg(3);
-  fft_exchange_over<PLANAR, kLayB, kLayA, 1, 1, true>(lane, xa, xb, t, buf, sync);
-#else
-  seg(1);
   fft_exchange_over_keep<PLANAR, kLayC, kLayB, 2, 2, true, false>(lane, xa, xb, t, buf, sync, wk);
-  seg(2);
   fft_exchange_over_keep<PLANAR, kLayC, kLayB, 2, 1, true, true>(lane, xb, xa, t, buf, sync, wk);
-  seg(3);
   fft_exchange_over_keep<PLANAR, kLayB, kLayA, 1, 1, true, false>(lane, xa, xb, t, buf, sync, wk);
-#endif
-  seg(4);
   fft_exchange_over<PLANAR, kLayB, kLayA, 1, 0, true>(lane, xb, xa, t, buf, sync);
-  seg(5);
   fft_inv3<0>(xb, t);
-}
-
-// -------------------------------------------------------------------------------------------------------------------
-// Decimation-in-time inverse. The inverse map is (un-twist) o (cyclic inverse DFT of the bit-reversed spectrum): a DIT
-// network pairs the same positions in the same order as the Gentleman-Sande stages above (distance 1, 2, 4 ... 256 in
-// j = 64 a + 8 b + c), so layouts and exchanges are shared; stage t multiplies the upper element by w_(2^(t+1))^-(j mod 2^t)
-// BEFORE the add/subtract: the 6-FMA butterfly of the forward transform instead of the 8-operation one, literal twiddles
-// 1, -i, (+-1 - i)/sqrt2 in the first group, and the un-twist psi^-j folded into the last stage as z = alpha x +- beta y.
-// 228 FP64 operations per lane instead of 288; 14 table reads instead of 8.
-struct FftDitTw { double wr[8], wi[8]; };
-template <int T, class TW>
-RS_HD void fft_dit_tw(const TW& t, FftDitTw& w) {
-  const int c = t.lane & 7, L = t.lane;
-  auto get = [&](int slot, int entry) { w.wr[slot] = t.tw[2 * entry]; w.wi[slot] = t.tw[2 * entry + 1]; };
-  if (T == 3) get(0, kDitB + c);
-  if (T == 4) get(0, kDitB + 8 + c);
-  if (T == 5) { get(0, kDitB + 16 + c); get(1, kDitB + 24 + c); }
-  if (T == 6) get(0, kDitA + L);
-  if (T == 7) get(0, kDitA + 64 + L);
-  if (T == 8) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) get(k, kDitA + 64 * (2 + k) + L);
-  }
-}
-RS_HD void fft_dit_bfly_1(double& xr, double& xi, double& yr, double& yi) {     // w = 1
-  const double ar = xr + yr, ai = xi + yi;
-  yr = xr - yr; yi = xi - yi;
-  xr = ar; xi = ai;
-}
-RS_HD void fft_dit_bfly_mi(double& xr, double& xi, double& yr, double& yi) {    // w = -i: w y = (yi, -yr)
-  const double ar = xr + yi, ai = xi - yr;
-  const double br = xr - yi, bi = xi + yr;
-  xr = ar; xi = ai; yr = br; yi = bi;
-}
-// last stage with the un-twist: positions j = L + 64 k and j + 256 (k < 4) take psi^-j and psi^-(j + 256) = psi^-j e^(-i pi / 4):
-// (x, y) -> (alpha x + beta y, e^(-i pi/4) (alpha x - beta y)), alpha = psi^-j, beta = alpha w512^-j; 14 operations
-RS_HD void fft_dit_bfly_untwist(double& xr, double& xi, double& yr, double& yi, double ar, double ai, double br, double bi) {
-  constexpr double kS = 0x1.6a09e667f3bcdp-1;   // sqrt(1/2)
-  const double pr = __builtin_fma(-ai, xi, ar * xr), pi = __builtin_fma(ai, xr, ar * xi);
-  const double sr = __builtin_fma(-bi, yi, __builtin_fma(br, yr, pr));
-  const double si = __builtin_fma(bi, yr, __builtin_fma(br, yi, pi));
-  const double dr = __builtin_fma(2.0, pr, -sr), di = __builtin_fma(2.0, pi, -si);   // alpha x - beta y
-  yr = __builtin_fma(kS, dr, kS * di);      // (1 - i)/sqrt2 * d
-  yi = __builtin_fma(kS, di, -(kS * dr));
-  xr = sr; xi = si;
-}
-template <int T>
-RS_HD void fft_dit_run(double (&x)[kRegs], const FftDitTw& w) {
-  constexpr int g = T % 3, half = 1 << g;
-  constexpr double kS = 0x1.6a09e667f3bcdp-1;   // sqrt(1/2)
-#pragma unroll
-  for (int k = 0; k < kCRegs; ++k) {
-    if (k & half) continue;                      // k is the lower element of its pair (k, k + half)
-    const int m = k & (half - 1);                // position within the half block = the register part of j mod 2^t
-    double &xr = x[k], &xi = x[k + 8], &yr = x[k + half], &yi = x[k + half + 8];
-    if (T < 3) {
-      // literal twiddles w8^-(m 2^(2-g)): 1, (1 - i)/sqrt2, -i, (-1 - i)/sqrt2
-      const int e = m << (2 - g);
-      if (e == 0) fft_dit_bfly_1(xr, xi, yr, yi);
-      else if (e == 2) fft_dit_bfly_mi(xr, xi, yr, yi);
-      else if (e == 1) fft_bfly_fwd(xr, xi, yr, yi, kS, -kS);
-      else fft_bfly_fwd(xr, xi, yr, yi, -kS, -kS);
-    } else if (T < 8) {
-      // twiddle = (table entry of this lane) x (-i)^(m >> ...) : m = 0 plain; g = 1: m = 1 is the -i sibling;
-      // g = 2: m = 0, 1 take entries 0, 1 and m = 2, 3 their -i siblings
-      const int slot = (g == 2) ? (m & 1) : 0;
-      const bool sib = (g == 1) ? (m == 1) : (g == 2 ? m >= 2 : false);
-      if (!sib) fft_bfly_fwd(xr, xi, yr, yi, w.wr[slot], w.wi[slot]);
-      else fft_bfly_fwd(xr, xi, yr, yi, w.wi[slot], -w.wr[slot]);     // -i w = (wi, -wr)
-    } else {
-      fft_dit_bfly_untwist(xr, xi, yr, yi, w.wr[m], w.wi[m], w.wr[4 + m], w.wi[4 + m]);
-    }
-  }
-}
-// the three stages of inverse group G (2 = C': t = 0-2, 1 = B': t = 3-5, 0 = A': t = 6-8) with the twiddle reads up front
-template <int G, class TW>
-RS_HD void fft_dit3_ahead(double (&x)[kRegs], const TW& t) {
-  constexpr int T0 = 3 * (2 - G);
-  FftDitTw w0, w1, w2;
-  fft_dit_tw<T0>(t, w0); fft_dit_tw<T0 + 1>(t, w1); fft_dit_tw<T0 + 2>(t, w2);
-  fft_dit_run<T0>(x, w0); fft_dit_run<T0 + 1>(x, w1); fft_dit_run<T0 + 2>(x, w2);
-}
-template <bool PLANAR, int L0, int L1, int T, int G, class TW, class Sync>
-RS_HD void fft_exchange_over_dit(int lane, double (&x)[kRegs], double (&y)[kRegs], const TW& t, double* buf, Sync sync) {
-  constexpr int T0 = 3 * (2 - G);
-  FftDitTw w[3];
-  fft_exchange_with<PLANAR, L0, L1, T>(lane, x, buf, sync,
-                                       [&](int k) { if (k == 0) fft_dit_tw<T0>(t, w[0]); else if (k == 1) fft_dit_tw<T0 + 1>(t, w[1]); else fft_dit_tw<T0 + 2>(t, w[2]); },
-                                       [&](int k) { if (k == 0) fft_dit_run<T0>(y, w[0]); else if (k == 1) fft_dit_run<T0 + 1>(y, w[1]); else fft_dit_run<T0 + 2>(y, w[2]); });
-}
-// the pipelined inverse pair of finv_pair, decimation in time (needs the appended tables: kFftTwDoublesAll doubles at t.tw)
-template <bool PLANAR, class TW, class Sync, class Seg = FftNoSeg>
-RS_HD void finv_pair_dit(int lane, double (&xa)[kRegs], double (&xb)[kRegs], const TW& t, double* buf, Sync sync, Seg seg = Seg()) {
-  seg(0);
-  fft_dit3_ahead<2>(xa, t);
-  seg(1);
-  fft_exchange_over_dit<PLANAR, kLayC, kLayB, 2, 2>(lane, xa, xb, t, buf, sync);
-  seg(2);
-  fft_exchange_over_dit<PLANAR, kLayC, kLayB, 2, 1>(lane, xb, xa, t, buf, sync);
-  seg(3);
-  fft_exchange_over_dit<PLANAR, kLayB, kLayA, 1, 1>(lane, xa, xb, t, buf, sync);
-  seg(4);
-  fft_exchange_over_dit<PLANAR, kLayB, kLayA, 1, 0>(lane, xb, xa, t, buf, sync);
-  seg(5);
-  fft_dit3_ahead<0>(xb, t);
-}
-// single transform, planar exchanges
-template <class TW, class Sync>
-RS_HD void finv_planar_dit(int lane, double (&x)[kRegs], const TW& t, double* buf, Sync sync) {
-  fft_dit3_ahead<2>(x, t);
-  fpl_exchange<kLayC, kLayB, 2>(lane, x, buf, sync);
-  fft_dit3_ahead<1>(x, t);
-  fpl_exchange<kLayB, kLayA, 1>(lane, x, buf, sync);
-  fft_dit3_ahead<0>(x, t);
 }
 
 // pointwise complex multiply-accumulate: (sr, si) += (xr, xi) * (wr, wi)
@@ -785,9 +537,7 @@ RS_HD void fft_cmac(double& sr, double& si, double xr, double xi, double wr, dou
 RS_HD int32_t fft_round_torus32(double v, double& max_dev) {
   const double t = v + 6755399441055744.0;       // 1.5 * 2^52: t's low mantissa bits = rint(v)
   const double r = t - 6755399441055744.0;
-#ifndef RS_NO_CERT   // timing experiments only: the product always tracks the certificate
   max_dev = __builtin_fmax(max_dev, __builtin_fabs(v - r));   // one v_max_f64 with an |abs| source modifier
-#endif
   long long bits;
   __builtin_memcpy(&bits, &t, sizeof(bits));
   return (int32_t)(uint32_t)(unsigned long long)bits;

@@ -48,11 +48,7 @@ constexpr RS_HD int gen_idx(int t, int H, int r) { return ((t >> (H - 3)) << H) 
 // without workgroup barriers. (Until round 3's last day Hr >= 8 was left unpadded: the wave-local stores of exchange 1 then
 // landed in slots that ANOTHER wave could still be reading as exchange 0's data -- a write-after-read race seen as a rare
 // wrong product at N = 4096 / 8192, caught by the enforced rounding certificate.)
-#ifdef RS_GEN_UNPADDED_WIDE_EXCHANGE   // the racy form, kept only to reproduce the failure (24 fresh processes of a full-size batch run twice: profiles/r03/s_general_exchange_race_repro.txt; tests/first_launch_stress.py is that run as a test)
-constexpr RS_HD int gen_phys(int idx, int Hr) { return Hr < 8 ? idx + ((idx >> Hr) << (Hr - 3)) : idx; }
-#else
 constexpr RS_HD int gen_phys(int idx, int Hr) { return idx + ((idx >> Hr) << (Hr - 3)); }
-#endif
 
 // the (at most four) EVEN twiddles of one pass: level e of the pass uses blocks (blk << e) | g, g < 2^e; odd g is
 // i times its even sibling and is applied by the _i butterflies (rs_fft.h)
@@ -62,17 +58,14 @@ struct GenPassTw { FftStageTw lv[3]; };
 // trip of its own (10 transforms x 3-4 passes per CMUX step).
 constexpr int kGenTwLds = 512;   // complex entries
 // the kernels stage the near levels in LDS for these rings (measured: N = 8192 is faster reading them from the L1-resident table)
-#ifndef RS_GEN_STAGE_TW_MAX_LOGN
-#define RS_GEN_STAGE_TW_MAX_LOGN 12   // A/B: 13 stages them for N = 8192 too, 9 for no ring
-#endif
 template <int LOGN>
-constexpr bool kGenStageTw = LOGN <= RS_GEN_STAGE_TW_MAX_LOGN;
+constexpr bool kGenStageTw = LOGN <= 12;
 // One table entry. On the device a read of the GLOBAL table is written as (uniform base) + (32-bit lane offset), which the
 // compiler turns into one load with a scalar base; indexed as a plain `const double*` it kept a 64-bit address pair per entry
 // (80 pairs live or recomputed per CMUX step at N = 8192, most of that kernel's register spills).
 template <bool GLOBAL>
 RS_HD void gen_tw_fetch(const double* src, unsigned entry, double& wr, double& wi) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RS_GEN_TW_GENERIC)
+#if defined(__HIP_DEVICE_COMPILE__)
   if constexpr (GLOBAL) {
     typedef double D2 __attribute__((ext_vector_type(2)));
     typedef const char __attribute__((address_space(1)))* BytePtr;
@@ -93,7 +86,6 @@ template <int LOGN, int PASS>
 RS_HD void gen_pass_tw(GenPassTw& w, int t, const double* tw, const double* tw_near) {
   using G = Gen<LOGN>;
   constexpr int H = G::H(PASS), E0 = G::first_level(PASS), SB = G::LOGM - H;
-#ifndef RS_GEN_NO_LITERAL_TW
   if constexpr (PASS == 0 && G::P > 1) {
     // pass 0 is one block for the whole workgroup: its even entries 1, 2, 4, 6 are the same for every ring (an entry does not
     // depend on M) and are the literals of rs_fft.h -- scalar registers instead of four table reads per transform
@@ -104,7 +96,6 @@ RS_HD void gen_pass_tw(GenPassTw& w, int t, const double* tw, const double* tw_n
     w.lv[2].wr[1] = kFftTwU[6]; w.lv[2].wi[1] = kFftTwU[7];
     return;
   }
-#endif
   const unsigned blk = (unsigned)t >> (H - 3);
   constexpr bool kNearGlobal = !kGenStageTw<LOGN>, kFarGlobal = true;   // which levels are read from the global table
 #pragma unroll
@@ -186,11 +177,7 @@ RS_HD void gen_load(double (&x)[kRegs], int t, const double* pre, const double* 
 // of whose barriers every wave still passes -- the first one after ITS last read of the previous transform.
 template <int LOGN, int XP>
 constexpr bool gen_exchange_is_wave_local() {
-#ifdef RS_GEN_WG_BARRIERS   // A/B: the previous form, workgroup barriers around every exchange
-  return Gen<LOGN>::T <= 64;
-#else
   return (1 << (Gen<LOGN>::H(XP) - 3)) <= 64;
-#endif
 }
 template <int LOGN, int XP, bool INV, class Sync, class WSync>
 RS_HD void gen_exchange(double (&x)[kRegs], int t, double* pre, double* pim, Sync sync, WSync wsync) {

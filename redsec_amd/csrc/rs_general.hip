@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <atomic>
 
+#include "rs_diag.h"
 #include "rs_general.h"
 #include "rs_kernels.h"
 
@@ -36,9 +37,7 @@ __device__ __forceinline__ void gen_sync() {
 // The thread index as an opaque value: address arithmetic that depends on it is then recomputed where it is used (a few shifts
 // and adds) instead of being hoisted out of the CMUX loop and held -- or spilled -- for the whole kernel.
 __device__ __forceinline__ int gen_local(int t) {
-#ifndef RS_GEN_NO_LOCAL
   asm volatile("" : "+v"(t));
-#endif
   return t;
 }
 typedef double GenD2 __attribute__((ext_vector_type(2)));
@@ -57,12 +56,8 @@ __device__ __forceinline__ GenKeyPtr gen_uniform_ptr(GenKeyPtr p) {   // of an a
 // that constant over to the lane offset (which turns every stream back into a 64-bit per-lane pointer)
 __device__ __forceinline__ double2 gen_key_load(GenKeyPtr base, uint32_t lane_bytes) {
   typedef const char __attribute__((address_space(1)))* BytePtr;
-#ifdef RS_GEN_KEY_GENERIC   // A/B and debugging: the plain per-lane pointer
-  const GenD2 v = *(GenKeyPtr)((BytePtr)base + lane_bytes);
-#else
   asm volatile("" : "+v"(lane_bytes));   // not hoisted, so that base + offset is selected as ONE load with a scalar base
   const GenD2 v = *(GenKeyPtr)((BytePtr)gen_uniform_ptr(base) + lane_bytes);
-#endif
   return make_double2(v.x, v.y);
 }
 
@@ -126,27 +121,16 @@ __global__ __launch_bounds__(Gen<LOGN>::T) void gen_bk_transform_kernel(const in
   }
 }
 
-// A/B switches of gen_blind_rotate_kernel (same-box measurements: profiles/r03/f_*, h_*):
-//   RS_GEN_LOOKAHEAD     key positions requested ahead of the one being multiplied (2; 3 spills again and loses)
-//   RS_GEN_FIRST_AT      where a row's first key position is requested: 0 behind the forward transform, 1 in front of it,
-//                        2 in front of its last exchange (default), 3 behind its last exchange
-//   RS_GEN_INV_SINGLE    the two inverse transforms of a column one after the other instead of as a pair
-//   RS_GEN_ROW0_AHEAD    the whole key row of a step's first digit requested at the start of the step, into the registers the
-//                        column sums do not need yet (bit-exact; measured 1.2-1.5 % SLOWER: off)
-//   RS_GEN_STAGGER_TICKS de-phase the workgroups of an XCD at kernel start (no effect)
-//   RS_GEN_T_NOKEY / NOFWD / NOINV   timing-only probes (wrong results): drop one phase
-#ifndef RS_GEN_LOOKAHEAD
-#define RS_GEN_LOOKAHEAD 2
-#endif
-#ifndef RS_GEN_STAGGER_TICKS
-#define RS_GEN_STAGGER_TICKS 0
-#endif
-#ifndef RS_GEN_STAGGER_SLOTS
-#define RS_GEN_STAGGER_SLOTS 32
-#endif
-#ifndef RS_GEN_FIRST_AT
-#define RS_GEN_FIRST_AT 2
-#endif
+// Choices of gen_blind_rotate_kernel, each from a same-box A/B (profiles/r03/f_*, h_*, profiles/r04/x_*; MEASUREMENTS.md section 4.5): two key
+// positions requested ahead of the one being multiplied (three spill and lose); a row's first key position requested in front of its
+// transform's last exchange (not in front of the transform, behind it, or behind the last exchange); the two inverse transforms of a
+// column as a pipelined pair; no whole-row prefetch at the start of a step (1.2-1.5 % slower); no de-phasing of an XCD's workgroups
+// at kernel start (no effect). Diagnostic builds (rs_diag.h, RS_DIAG bit 16) replace every key load by register values.
+// A key chunk of the row at `p`; under the no-key probe a value made of registers instead (no load at all; results wrong).
+__device__ __forceinline__ double2 gen_key_or_probe(GenKeyPtr p, uint32_t tb, double pa, double pb) {
+  if constexpr (diag::kNoKeyProbe) { (void)p; (void)tb; return make_double2(pa, pb); }
+  else { (void)pa; (void)pb; return gen_key_load(p, tb); }
+}
 template <int LOGN>
 __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2, 2))) void gen_blind_rotate_kernel(GenArgs a) {
   using G = Gen<LOGN>;
@@ -164,12 +148,8 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
   // were requested one exchange ahead of their use and mostly waited for (profiles/r03/h_general_ab_last_pass_twiddles_kept.txt,
   // h_general_ab_which_pass_kept.txt). Keeping an LDS-served pass costs more in spilled registers than its reads save (pass 1 or 2
   // at N = 4096: -0.7 % / -3.8 %). RS_GEN_KEEP_PASS forces a pass (-1: none).
-#ifndef RS_GEN_KEEP_PASS
   constexpr bool kLastPassGlobal = !kGenStageTw<LOGN> || (2 << (Gen<LOGN>::LOGM - 1)) > kGenTwLds;
   constexpr int kKeepPass = (Gen<LOGN>::P >= 2 && kLastPassGlobal) ? Gen<LOGN>::P - 1 : -1;
-#else
-  constexpr int kKeepPass = Gen<LOGN>::P < 2 ? -1 : RS_GEN_KEEP_PASS;
-#endif
   GenPassTw tw_kept;
   if constexpr (kKeepPass == 1) gen_pass_tw<LOGN, 1>(tw_kept, t, a.tw, twn);
   if constexpr (kKeepPass == 2 && Gen<LOGN>::P > 2) gen_pass_tw<LOGN, 2>(tw_kept, t, a.tw, twn);
@@ -177,16 +157,6 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
   const GenKeptTw kept1{kKeepPass >= 1 && kKeepPass < Gen<LOGN>::P ? &tw_kept : nullptr, kKeepPass};
   const uint32_t goff = gen_gadget_offset(l, bgbit);
   double dev = 0.0;
-#if RS_GEN_STAGGER_TICKS > 0
-  // De-phase the workgroups that share an L2 (blockIdx.x & 7 = XCD under round-robin dispatch): started together they reach the
-  // multiply-accumulate phases -- where all the key bytes of a CMUX step are pulled from L2 -- at the same moments.
-  {
-    const unsigned slot = (blockIdx.x >> 3) & (RS_GEN_STAGGER_SLOTS - 1);
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    const unsigned long long wait = (unsigned long long)slot * RS_GEN_STAGGER_TICKS;
-    while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-  }
-#endif
 
   // (XCD cohorts, rs_cohort.h, were tried here in round 4 -- wave 0 posting the step count and waiting for its XCD's slowest workgroup -- and
   // cost 7 % at N = 4096 and 3 % at N = 8192 whether switched on or off: the few registers of the cohort state spill 10-20 more dwords per lane in
@@ -254,55 +224,29 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll
           for (int r = 0; r < 16; ++r) x[r] = (double)gen_gadget_digit(v[r], q, bgbit);
           GenKeyPtr kp = gen_uniform_ptr(reinterpret_cast<const double2*>(a.bk_x) + ((size_t)i * 2 * l + (size_t)comp * l + q) * 4 * M);
-          constexpr int LA = RS_GEN_LOOKAHEAD, NB = LA + 1;   // key positions requested ahead of the one being multiplied
+          constexpr int LA = 2, NB = LA + 1;   // key positions requested ahead of the one being multiplied
           double2 w[NB][4];
           // both halves x both columns of position r; position 0 is requested in front of the transform's last exchange, position
           // r + LA before the FMAs of position r (the compiler's own schedule waited for each group of four in full before its 16
           // FMAs: eight exposed L2 round trips per row, most of a CMUX step on the large rings)
-#ifdef RS_GEN_FIRST_GROUPS
-          constexpr int kFirstGroups = RS_GEN_FIRST_GROUPS;
-#else
           constexpr int kFirstGroups = LOGN >= 13 ? 2 : 1;   // N = 8192 (with the row rotation): 458.5 -> 445.7 ms; N = 4096: +0.4 % at best
-#endif
           constexpr int FG = kFirstGroups < LA ? kFirstGroups : LA;   // positions requested at the tail hook
           auto first = [&] {
 #pragma unroll
             for (int g = 0; g < FG; ++g) {
 #pragma unroll
               for (int hc = 0; hc < 4; ++hc) {
-#ifdef RS_GEN_T_NOKEY
-                w[g][hc] = make_double2(1.0 + hc, 2.0 + g);
-#else
-                w[g][hc] = gen_key_load(kp + (size_t)hc * M + g * T, tb);
-#endif
+                w[g][hc] = gen_key_or_probe(kp + (size_t)hc * M + g * T, tb, 1.0 + hc, 2.0 + g);
               }
             }
             __builtin_amdgcn_sched_barrier(0);
           };
-#if RS_GEN_FIRST_AT == 1        // A/B: in front of the whole transform (more spills: measured slower)
-          first();
-#endif
-#ifdef RS_GEN_T_NOFWD           // timing-only probes (wrong results): RS_GEN_T_NOFWD / NOKEY / NOINV drop one phase each
-          first();
-#elif RS_GEN_FIRST_AT == 2
           gen_fft_fwd<LOGN>(x, gen_local(t), a.tw, twn, s_re, s_im, sync, wsync, first, kept1);
-#elif RS_GEN_FIRST_AT == 3    // A/B: behind the last exchange, in front of the last pass's butterflies
-          gen_fft_fwd<LOGN, true>(x, gen_local(t), a.tw, twn, s_re, s_im, sync, wsync, first, kept1);
-#else
-          gen_fft_fwd<LOGN>(x, gen_local(t), a.tw, twn, s_re, s_im, sync, wsync);
-#endif
-#if RS_GEN_FIRST_AT == 0        // A/B: behind the transform (the round-3 form before the tail hook)
-          first();
-#endif
 #pragma unroll
           for (int g = FG; g < LA; ++g) {
 #pragma unroll
             for (int hc = 0; hc < 4; ++hc) {
-#ifdef RS_GEN_T_NOKEY
-              w[g][hc] = make_double2(x[hc + g], x[hc + 8]);
-#else
-              w[g][hc] = gen_key_load(kp + (size_t)hc * M + g * T, tb);
-#endif
+              w[g][hc] = gen_key_or_probe(kp + (size_t)hc * M + g * T, tb, x[hc + g], x[hc + 8]);
             }
           }
 #pragma unroll
@@ -310,11 +254,7 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
             if (r + LA < 8) {
 #pragma unroll
               for (int hc = 0; hc < 4; ++hc) {
-#ifdef RS_GEN_T_NOKEY
-                w[(r + LA) % NB][hc] = make_double2(x[hc + 1], x[hc + 4]);
-#else
-                w[(r + LA) % NB][hc] = gen_key_load(kp + (size_t)hc * M + (r + LA) * T, tb);
-#endif
+                w[(r + LA) % NB][hc] = gen_key_or_probe(kp + (size_t)hc * M + (r + LA) * T, tb, x[hc + 1], x[hc + 4]);
               }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -324,38 +264,6 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
           }
       };
       int32_t v[kRegs];
-#ifdef RS_GEN_ROW0_AHEAD
-      // The column sums are not alive between the accumulator update and the first multiply of the next step: the WHOLE key row of
-      // the step's first digit (32 loads, 128 registers) is requested here, across the rotated difference and the first forward
-      // transform, and that row's products INITIALISE the sums position by position as its key registers die.
-      {
-        GenKeyPtr kp0 = gen_uniform_ptr(reinterpret_cast<const double2*>(a.bk_x) + ((size_t)i * 2 * l) * 4 * M);
-        double2 wpre[8][4];
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-#pragma unroll
-          for (int hc = 0; hc < 4; ++hc) wpre[r][hc] = gen_key_load(kp0 + (size_t)hc * M + r * T, tb);
-        __builtin_amdgcn_sched_barrier(0);
-        prep(0, v);
-        double x[kRegs];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = (double)gen_gadget_digit(v[r], 0, bgbit);
-        gen_fft_fwd<LOGN>(x, gen_local(t), a.tw, twn, s_re, s_im, sync, wsync);
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-#pragma unroll
-          for (int hc = 0; hc < 4; ++hc) {
-            // fft_cmac on a zero sum, written as the initialisation it is
-            S[hc >> 1][hc & 1][r] = __builtin_fma(-x[r + 8], wpre[r][hc].y, __builtin_fma(x[r], wpre[r][hc].x, 0.0));
-            S[hc >> 1][hc & 1][r + 8] = __builtin_fma(x[r + 8], wpre[r][hc].x, __builtin_fma(x[r], wpre[r][hc].y, 0.0));
-          }
-      }
-#pragma unroll 1
-      for (int q = 1; q < l; ++q) row(0, q, v);
-      prep(1, v);
-#pragma unroll 1
-      for (int q = 0; q < l; ++q) row(1, q, v);
-#else
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -366,13 +274,9 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
       // together, all workgroups otherwise pull the same key rows through the same L2 channels at the same moments. Mode 1 (digit
       // rotation + component order from b): N = 8192 516.5 -> 458.8 ms per 512 (+12.6 %); at N = 4096 digit rotation costs 8-10 %
       // (two workgroups per CU and 512 per launch lose more L2 locality than they gain), component order alone +0.4 %
-      // (profiles/r03/h_general_ab_row_rotation_modes.txt). RS_GEN_ROTATE forces a mode: 0 none, 1 both, 2 digits, 3 components.
+      // (profiles/r03/h_general_ab_row_rotation_modes.txt). Modes: 0 none, 1 both, 2 digits, 3 components.
       {
-#ifdef RS_GEN_ROTATE
-        constexpr int kRot = RS_GEN_ROTATE;
-#else
         constexpr int kRot = LOGN >= 13 ? 1 : 3;
-#endif
         // (round 4: the order taken from the XCD, blockIdx.x & 7, instead of the workgroup -- same rows at the same time inside an L2, different
         // rows in different XCDs -- measured: N = 4096 +-0, N = 8192 -3.7 % against mode 1; profiles/r04/x_ab_general_cohorts_and_xcd_rotation.txt)
         const int qrot = (kRot == 1 || kRot == 2) ? (int)(blockIdx.x % (unsigned)l) : 0;
@@ -389,19 +293,11 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
           }
         }
       }
-#endif
 
       // every thread passed at least one barrier since its reads of the accumulator: the update cannot overtake them
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-#ifndef RS_GEN_T_NOINV
-#ifdef RS_GEN_INV_SINGLE   // A/B: the two halves of a column one after the other
-        gen_fft_inv<LOGN>(S[0][c], gen_local(t), a.tw, twn, s_re, s_im, sync, wsync);
-        gen_fft_inv<LOGN>(S[1][c], gen_local(t), a.tw, twn, s_re, s_im, sync, wsync);
-#else
         gen_fft_inv2<LOGN>(S[0][c], S[1][c], gen_local(t), a.tw, twn, s_re, s_im, sync, wsync, kept1);
-#endif
-#endif
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int j = t + T * (r & 7) + (r >> 3) * M;

@@ -77,10 +77,8 @@ inline unsigned keyswitch_slices(long B, int W, int N) {
   if (B <= 0) return 1;
   const unsigned gx = (unsigned)((B + 255) / 256), gy = (unsigned)((W + 31) / 32);
   unsigned split = 1;
-#ifndef RS_KS_WANT_WGS
-#define RS_KS_WANT_WGS 1024   // workgroups a sliced launch aims for (A/B: 2048, 4096)
-#endif
-  while (split < 64 && gx * gy * split < RS_KS_WANT_WGS && N / (int)(2 * split) >= 4) split *= 2;
+  constexpr unsigned kWantWorkgroups = 1024;   // workgroups a sliced launch aims for (2048 and 4096 measured: no better)
+  while (split < 64 && gx * gy * split < kWantWorkgroups && N / (int)(2 * split) >= 4) split *= 2;
   return split;
 }
 inline size_t keyswitch_scratch_words_for(long B, int W, int N) {
@@ -194,7 +192,7 @@ inline Tables make_tables(const PrimeSpec& ps, int fuse) {
 // Complex twiddles of the folded FFT (rs_fft.h): w_{m,i} = exp(2 pi i (1 + 4 bitrev_s(i)) / 2^(s+3)),
 // m = 2^s, stored interleaved (re, im) at the stage-transposed position ftw_pos(m + i).
 inline std::vector<double> make_fft_tables() {
-  std::vector<double> t(kFftTwDoublesAll, 0.0);
+  std::vector<double> t(kFftTwDoubles, 0.0);
   const long double two_pi = 6.283185307179586476925286766559005768L;
   for (int s = 0; s < 9; ++s) {
     const int m = 1 << s;
@@ -210,26 +208,6 @@ inline std::vector<double> make_fft_tables() {
       const double re = (double)cosl(ang), im = (double)sinl(ang);
       t[2 * pos] = (i & 1) ? -im : re;
       t[2 * pos + 1] = (i & 1) ? re : im;
-    }
-  }
-  // tables of the decimation-in-time inverse (rs_fft.h, kDitB / kDitA): exp(-2 pi i num / den), rounded once from long double
-  auto put = [&](int entry, long num, long den) {
-    const long double ang = -two_pi * (long double)num / (long double)den;
-    t[2 * entry] = (double)cosl(ang);
-    t[2 * entry + 1] = (double)sinl(ang);
-  };
-  for (int c = 0; c < 8; ++c) {
-    put(kDitB + c, c, 16);
-    put(kDitB + 8 + c, c, 32);
-    put(kDitB + 16 + c, c, 64);
-    put(kDitB + 24 + c, c + 8, 64);
-  }
-  for (int L = 0; L < 64; ++L) {
-    put(kDitA + L, L, 128);
-    put(kDitA + 64 + L, L, 256);
-    for (int k = 0; k < 4; ++k) {
-      put(kDitA + 64 * (2 + k) + L, L + 64 * k, 2048);            // alpha_k = psi^-(L + 64 k)
-      put(kDitA + 64 * (6 + k) + L, 5L * (L + 64 * k), 2048);     // beta_k = alpha_k w512^-(L + 64 k)
     }
   }
   return t;

@@ -108,18 +108,15 @@ __device__ __forceinline__ void ks_tile_finish(const KeyswitchArgs& a, const uin
 
 // XCD-aware tile order of the tiled keyswitch kernels (A/B switch, OFF). Workgroups reach the 8 XCDs round-robin in dispatch order
 // (x fastest), so the 256 ciphertext tiles that share one 32-word slice of the KSK are spread over all eight L2s and every L2 pulls
-// every slice (27.6 GB of fabric traffic per 65,536-gate launch for a 62 MB key). With RS_KS_XCD=1 the idx-th workgroup an XCD
+// every slice (27.6 GB of fabric traffic per 65,536-gate launch for a 62 MB key). With 0=1 the idx-th workgroup an XCD
 // receives takes tile xcd * (total / 8) + idx of the y-major order, so that an XCD works through whole slices: measured 16.8 GB
 // instead of 27.6 GB and 11.30 instead of 11.18 ms (profiles/r04/bm_*) -- the rows are requested behind the lookups since round 4
 // and the kernel is bound by its LDS reads, so the traffic was not what it waited for; left off.
-#ifndef RS_KS_XCD
-#define RS_KS_XCD 0
-#endif
 __device__ __forceinline__ void ks_tile_of_block(unsigned& bx, unsigned& by) {
   bx = blockIdx.x; by = blockIdx.y;
   const unsigned nx = gridDim.x, total = gridDim.x * gridDim.y, per = total >> 3;
   const unsigned lin = blockIdx.x + nx * blockIdx.y;
-  if (RS_KS_XCD && gridDim.z == 1 && per > 0 && lin < 8 * per) {
+  if (0 && gridDim.z == 1 && per > 0 && lin < 8 * per) {
     const unsigned tile = (lin & 7) * per + (lin >> 3);
     by = tile / nx; bx = tile - by * nx;
   }
@@ -644,16 +641,13 @@ hipError_t launch_keyswitch(const KeyswitchArgs& a_in, hipStream_t st) {
     hipError_t e = hipMemsetAsync(a.out, 0, (size_t)a.B * a.W * sizeof(int32_t), st);
     if (e != hipSuccess) return e;
   }
-#ifndef RS_KS_COMB
-#define RS_KS_COMB 1   // 0: one LDS lookup per digit everywhere (A/B)
-#endif
   if (tiled && a.t == 8) {
-    if (RS_KS_COMB) hipLaunchKernelGGL((keyswitch_tiled_comb_kernel<8, 2, 4, 2>), grid, dim3(KS_TILE_THREADS), 0, st, a);
+    if (1) hipLaunchKernelGGL((keyswitch_tiled_comb_kernel<8, 2, 4, 2>), grid, dim3(KS_TILE_THREADS), 0, st, a);
     else hipLaunchKernelGGL((keyswitch_tiled_kernel<8, 2, 4>), grid, dim3(KS_TILE_THREADS), 0, st, a);
   } else if (tiled && a.t == 9) {
     hipLaunchKernelGGL((keyswitch_tiled_kernel<9, 3, 2>), grid, dim3(KS_TILE_THREADS), 0, st, a);
   } else if (tiled) {
-    if (RS_KS_COMB) hipLaunchKernelGGL((keyswitch_tiled_comb_kernel<18, 1, 4, 4>), grid, dim3(KS_TILE_THREADS), 0, st, a);
+    if (1) hipLaunchKernelGGL((keyswitch_tiled_comb_kernel<18, 1, 4, 4>), grid, dim3(KS_TILE_THREADS), 0, st, a);
     else hipLaunchKernelGGL((keyswitch_tiled_kernel<18, 1, 4>), grid, dim3(KS_TILE_THREADS), 0, st, a);
   } else {
     // generic gather form: any ring degree, any (t, basebit), any sample width

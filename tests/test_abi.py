@@ -99,3 +99,28 @@ def test_header_is_plain_c99_and_a_c_program_links(tmp_path):
     import torch
     if not torch.cuda.is_available():
         assert "refused: " in r.stdout and "no HIP device" in r.stdout, r.stdout
+
+
+def test_kernel_sources_carry_no_experiment_switches():
+    """Round 5 deleted the ~70 compile-time experiment switches of rounds 1-4 (RS_T_*, RS_WG_*, RS_GEN_* ...: each measured, none adopted,
+    verdicts in MEASUREMENTS.md) together with their code paths. What may still select code in csrc/: RS_BS_PART (which launchers an
+    object of rs_bootstrap.hip holds, redsec_amd/build.py) and RS_DIAG (rs_diag.h: phase stamps and the no-key timing probe of
+    diagnostic builds, the ONE guard for everything diagnostic). This test keeps it that way."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "redsec_amd", "csrc")
+    allowed = {"RS_BS_PART", "RS_DIAG", "RS_DIAG_STAMP_PART", "RS_STAMPS_ON", "RS_HD"}     # the last three: helper macros, not switches
+    seen, conditionals = set(), 0
+    for path in sorted(glob.glob(os.path.join(csrc, "*"))):
+        text = open(path).read()
+        name = os.path.basename(path)
+        if name != "rs_diag.h":
+            assert not re.search(r"\bRS_T_[A-Z0-9_]+\b", text), "timing-probe switch outside rs_diag.h: " + name
+        for line in text.splitlines():
+            if re.match(r"\s*#\s*(if|ifdef|ifndef|elif)\b", line):
+                conditionals += 1
+                seen |= set(re.findall(r"\bRS_[A-Z0-9_]+\b", line))
+            m = re.match(r"\s*#\s*ifndef\s+(RS_[A-Z0-9_]+)", line)     # the `#ifndef X / #define X default` idiom of an A/B switch
+            assert not (m and m.group(1) not in allowed), "overridable default in %s: %s" % (name, line.strip())
+    assert seen <= allowed, sorted(seen - allowed)
+    assert conditionals <= 40, conditionals                          # 25 today, most of them __HIP_DEVICE_COMPILE__ / __HIPCC__

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Where the eight waves of a latency-form workgroup spend a CMUX step (REDsec set, MNIST layer sizes).
 
-  tools/build_variant.sh stamps8 . -DRS_STAMPS -DRS_STAMPS_COOP8     blind_rotate_coop8_kernel, B = 196 (one ciphertext per workgroup)
-  tools/build_variant.sh stampsduo . -DRS_STAMPS -DRS_STAMPS_DUO     blind_rotate_duo_kernel, B = 1024 (four ciphertexts x two waves)
+  tools/build_variant.sh stamps8 . -DRS_DIAG=8     blind_rotate_coop8_kernel, B = 196 (one ciphertext per workgroup)
+  tools/build_variant.sh stampsduo . -DRS_DIAG=4     blind_rotate_duo_kernel, B = 1024 (four ciphertexts x two waves)
   REDSEC_HIP_LIB=$PWD/variants/lib_stamps8.so python tools/stamp_coop8.py [B]
 
 Diagnostic build only (every stamp drains the wave's LDS reads): read the SHARES and the per-wave differences.
@@ -29,7 +29,7 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 196
     lib = redsec_amd.load_library()
     if not hasattr(lib, "rs_debug_read_stamps"):
-        raise SystemExit("not a -DRS_STAMPS build: set REDSEC_HIP_LIB to variants/lib_stamps8.so")
+        raise SystemExit("not a -DRS_DIAG stamps build: set REDSEC_HIP_LIB to variants/lib_stamps8.so")
     sk = client.SecretKeySet("redsec_small_v2", seed=7)
     be = redsec_amd.Backend(redsec_amd.params("redsec_small_v2"), device=0)
     be.load_keys(sk.bk, sk.ksk)

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Where a wave of blind_rotate_wg_kernel spends its cycles: reads the per-wave phase sums of a -DRS_STAMPS build.
+"""Where a wave of blind_rotate_wg_kernel spends its cycles: reads the per-wave phase sums of a -DRS_DIAG=1 build (csrc/rs_diag.h).
 
-  tools/build_variant.sh stamps . -DRS_STAMPS
+  tools/build_variant.sh stamps . -DRS_DIAG=1
   REDSEC_HIP_LIB=$PWD/variants/lib_stamps.so python tools/stamp_profile.py [default128|redsec_small_v2] [gates]
-  tools/build_variant.sh stampswgs . -DRS_STAMPS -DRS_STAMPS_WGS       (the split lock-step kernel instead)
+  tools/build_variant.sh stampswgs . -DRS_DIAG=2       (the split lock-step kernel instead)
   REDSEC_HIP_LIB=$PWD/variants/lib_stampswgs.so python tools/stamp_profile.py default128 16384 --split
 
 Diagnostic build only: every stamp drains the wave's LDS reads, so the run is slower than the product; read the SHARES.
@@ -40,7 +40,7 @@ def main():
     gates = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
     lib = redsec_amd.load_library()
     if not hasattr(lib, "rs_debug_read_stamps"):
-        raise SystemExit("not a -DRS_STAMPS build: set REDSEC_HIP_LIB to variants/lib_stamps.so")
+        raise SystemExit("not a -DRS_DIAG stamps build: set REDSEC_HIP_LIB to variants/lib_stamps.so")
     sk = client.SecretKeySet(name, seed=7)
     be = redsec_amd.Backend(redsec_amd.params(name), device=0)
     be.load_keys(sk.bk, sk.ksk)
