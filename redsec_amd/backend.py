@@ -180,12 +180,18 @@ class Backend:
         _check(self.L, self.L.rs_create(C.byref(h), C.byref(p), device))
         self.h = h
 
-    def close(self):
+    def close(self, check=None):
         """rs_destroy; raises if the enforced split-mode certificate of some stream's last call had failed (nothing else would
-        look at it any more)."""
+        look at it any more) -- unless another exception is already on its way out (a close() in a `finally:` block must not
+        mask the error that brought the caller there) or check=False says the caller has dealt with the context's state."""
         if getattr(self, "h", None):
             h, self.h = self.h, None
-            _check(self.L, self.L.rs_destroy(h))
+            rc = self.L.rs_destroy(h)
+            if check is None:
+                import sys
+                check = sys.exc_info()[0] is None
+            if check:
+                _check(self.L, rc)
 
     def __del__(self):
         try:

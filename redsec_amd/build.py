@@ -19,7 +19,7 @@ HIP_LIB = os.path.join(HERE, "libredsec_hip.so")
 EMU_LIB = os.path.join(HERE, "librs_emulate.so")
 
 HIP_SOURCES = ["rs_bootstrap.hip", "rs_general.hip", "rs_kernels.hip", "rs_api.cpp"]
-HIP_DEPS = HIP_SOURCES + ["rs_kernels.h", "rs_cohort.h", "rs_lds_plan.h", "rs_ntt.h", "rs_fft.h", "rs_general.h", "rs_host.h", os.path.join(INCLUDE, "redsec_hip.h")]
+HIP_DEPS = HIP_SOURCES + ["rs_kernels.h", "rs_cohort.h", "rs_diag.h", "rs_lds_plan.h", "rs_ntt.h", "rs_fft.h", "rs_general.h", "rs_host.h", os.path.join(INCLUDE, "redsec_hip.h")]
 # Objects of the product library: (object name, source, extra flags). rs_bootstrap.hip is compiled twice (its RS_BS_PART
 # switch): part 1 -- the FFT / exact-NTT blind-rotation kernels and the split duo form -- with LLVM's post-register-allocation
 # scheduler off: its in-block reordering of the hand-laid-out LDS / FP64 sequences costs these kernels 1-3 % (same-box A/B,
@@ -75,9 +75,6 @@ def write_stamp(target, deps, extra=""):
 def _stale(target, deps):
     return is_stale(target, _abs(deps) + [os.path.abspath(__file__)])
 
-
-def _stamp(target, deps):
-    write_stamp(target, _abs(deps) + [os.path.abspath(__file__)])
 
 
 def find_hipcc():
@@ -155,13 +152,20 @@ def build_emulator(force=False, verbose=False):
     cxx = shutil.which("g++") or shutil.which("c++")
     if cxx is None:
         raise RuntimeError("no host C++ compiler for the emulator")
-    cmd = [cxx, "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", "-msse4.1", "-fPIC", "-shared",
-           "-Wno-unknown-pragmas", "-I" + CSRC] + _abs(EMU_SOURCES) + ["-o", EMU_LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    _stamp(EMU_LIB, EMU_DEPS)
-    return EMU_LIB
+    lock = _locked("emulate")
+    try:
+        if not force and not _stale(EMU_LIB, EMU_DEPS):      # built by another process while this one waited
+            return EMU_LIB
+        tmp = EMU_LIB + ".tmp.%d" % os.getpid()
+        cmd = [cxx, "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", "-msse4.1", "-fPIC", "-shared",
+               "-Wno-unknown-pragmas", "-I" + CSRC] + _abs(EMU_SOURCES) + ["-o", tmp]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        _publish(tmp, EMU_LIB, EMU_DEPS)
+        return EMU_LIB
+    finally:
+        lock.close()
 
 
 HOST = os.path.join(HERE, "host")
@@ -178,13 +182,20 @@ def build_layers(force=False, verbose=False):
     if not force and not _stale(LAYERS_LIB, LAYERS_DEPS):
         return LAYERS_LIB
     cxx = shutil.which("g++") or shutil.which("c++")
-    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result", "-I" + HOST, "-I" + INCLUDE] + LAYERS_SOURCES + \
-          ["-L" + HERE, "-lredsec_hip", "-Wl,-rpath,$ORIGIN", "-o", LAYERS_LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    _stamp(LAYERS_LIB, LAYERS_DEPS)
-    return LAYERS_LIB
+    lock = _locked("layers")
+    try:
+        if not force and not _stale(LAYERS_LIB, LAYERS_DEPS):
+            return LAYERS_LIB
+        tmp = LAYERS_LIB + ".tmp.%d" % os.getpid()
+        cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result", "-I" + HOST, "-I" + INCLUDE] + LAYERS_SOURCES + \
+              ["-L" + HERE, "-lredsec_hip", "-Wl,-rpath,$ORIGIN", "-o", tmp]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        _publish(tmp, LAYERS_LIB, LAYERS_DEPS)
+        return LAYERS_LIB
+    finally:
+        lock.close()
 
 
 REF = "/root/reference"

@@ -201,7 +201,15 @@ void attach_ks_scratch(const rs_ctx* c, Lane* ln, rs::KeyswitchArgs& k) {
 
 // the lane's XCD cohort table (rs_kernels.h), allocated on first use; nullptr if that fails (the launch then runs free)
 int* lane_progress(Lane* ln) {
-  if (!ln->d_progress && hipMalloc(&ln->d_progress, 8 * rs::kCohortSlots * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); ln->d_progress = nullptr; }
+  if (!ln->d_progress) {
+    // 0x7f7f7f7f = "no workgroup owns this entry": also what rs_debug_cohort_table shows before the first cohort launch
+    if (hipMalloc(&ln->d_progress, 8 * rs::kCohortSlots * sizeof(int)) != hipSuccess ||
+        hipMemset(ln->d_progress, 0x7f, 8 * rs::kCohortSlots * sizeof(int)) != hipSuccess) {
+      (void)hipGetLastError();
+      if (ln->d_progress) (void)hipFree(ln->d_progress);
+      ln->d_progress = nullptr;
+    }
+  }
   return ln->d_progress;
 }
 

@@ -1809,19 +1809,30 @@ static hipError_t launch_br(const BlindRotateArgs& a, long max_blocks, hipStream
   return hipGetLastError();
 }
 
-// XCD cohorts of the unsplit lock-step kernel (cohort_step): only for launches whose workgroups sweep the key more than once. A CMUX step
-// reads 2l rows of 16 KB; the lag keeps a cohort inside about a third of its XCD's 4 MB L2.
-template <class C>
-static hipError_t cohort_setup(BlindRotateArgs& w, long groups, long grid, const LaunchOpts& o, hipStream_t st) {
-  if (!w.progress || o.no_cohort || grid > 8L * kCohortSlots || groups <= grid) { w.progress = nullptr; return hipSuccess; }
-  const long step_bytes = 2L * C::L * 16384;
+#endif  // RS_BS_PART & 1
+// XCD cohorts of the lock-step kernels (cohort_step, rs_cohort.h): the ONLY place that hands a kernel a progress table. Every
+// launch path starts from arguments whose `progress` is null and calls this for the launches that may use one: those whose
+// workgroups sweep the key more than once (groups > grid), on a device whose workgroups are dealt round-robin over EIGHT XCDs --
+// the protocol's xcd = blockIdx & 7. The one MI355X configuration that is true for is the whole chip as one partition (SPX,
+// 256 CUs = 8 x 32); under CPX / DPX / QPX partitions a table row would mix workgroups served by different L2s, which
+// could only wait for each other with no L2 to share, so there the workgroups run free. `step_bytes` = key bytes a CMUX step
+// reads; the lag keeps a cohort inside about a third of its XCD's 4 MB L2.
+static hipError_t cohort_setup(BlindRotateArgs& w, int* table, long step_bytes, long groups, long grid, long num_cus, const LaunchOpts& o, hipStream_t st) {
+  w.progress = nullptr; w.cohort_every = 0; w.cohort_lag = 0;
+  if (!table || o.no_cohort || num_cus != 256 || grid > 8L * kCohortSlots || groups <= grid) return hipSuccess;
   w.cohort_lag = (int32_t)std::max<long>(1, (4L << 20) / 3 / step_bytes - 1);
   w.cohort_every = w.cohort_lag >= 4 ? 2 : 1;
-  return hipMemsetAsync(w.progress, 0x7f, 8 * kCohortSlots * sizeof(int), st);
+  w.progress = table;
+  return hipMemsetAsync(table, 0x7f, 8 * kCohortSlots * sizeof(int), st);
 }
+#if RS_BS_PART & 1
 
 template <class Xf>
-static hipError_t launch_br_xf(const BlindRotateArgs& a, int wpb, long num_cus, bool coop4, const LaunchOpts& o, hipStream_t st, LaunchInfo* info) {
+static hipError_t launch_br_xf(const BlindRotateArgs& a_in, int wpb, long num_cus, bool coop4, const LaunchOpts& o, hipStream_t st, LaunchInfo* info) {
+  int* const cohort_table = a_in.progress;   // the caller's offer; only cohort_setup puts it back into a launch's arguments
+  BlindRotateArgs a = a_in;
+  a.progress = nullptr; a.cohort_every = 0; a.cohort_lag = 0;
+  constexpr long kStepBytes = 2L * Xf::Cfg::L * 16384;   // a CMUX step reads 2l rows of 16 KB
   LaunchInfo li;
   auto done = [&](int form, int w, long resident) {
     li.form = form; li.waves_per_block = w; li.resident = resident;
@@ -1865,11 +1876,10 @@ static hipError_t launch_br_xf(const BlindRotateArgs& a, int wpb, long num_cus, 
         if (a.in1) t.in1 = a.in1 + m.B * a.W;
         t.u_out = a.u_out + m.B * (kN + 1);
         if (a.lut) t.lut_first = (int32_t)((a.lut_first + m.B) % a.lut_count);
-        if (hipError_t ce = cohort_setup<typename Xf::Cfg>(m, m.B / 8, num_cus, o, st); ce != hipSuccess) return ce;
+        if (hipError_t ce = cohort_setup(m, cohort_table, kStepBytes, m.B / 8, num_cus, num_cus, o, st); ce != hipSuccess) return ce;
         hipLaunchKernelGGL((blind_rotate_wg_kernel<Xf, 8>), dim3((unsigned)num_cus), dim3(512), 0, st, m);
         hipError_t e = hipGetLastError();
-        t.progress = nullptr;   // the cut-off last round runs in a form without cohorts
-        if (e != hipSuccess) return e;
+        if (e != hipSuccess) return e;   // (t, the cut-off last round, runs in a form without cohorts: its progress is null)
         e = launch_br_xf<Xf>(t, wpb, num_cus, coop4, o, st, nullptr);
         if (e != hipSuccess) return e;
         return done(kFormWorkgroup, 8, 8 * num_cus);
@@ -1877,7 +1887,7 @@ static hipError_t launch_br_xf(const BlindRotateArgs& a, int wpb, long num_cus, 
       const long groups = (a.B + 7) / 8;
       const long grid = groups < num_cus ? groups : num_cus;
       BlindRotateArgs w = a;
-      if (hipError_t e = cohort_setup<typename Xf::Cfg>(w, groups, grid, o, st); e != hipSuccess) return e;
+      if (hipError_t e = cohort_setup(w, cohort_table, kStepBytes, groups, grid, num_cus, o, st); e != hipSuccess) return e;
       hipLaunchKernelGGL((blind_rotate_wg_kernel<Xf, 8>), dim3((unsigned)grid), dim3(512), 0, st, w);
       return done(kFormWorkgroup, 8, 8 * grid);   // the workgroups sweep the key together: 8 x grid ciphertexts per sweep
     }
@@ -1940,7 +1950,10 @@ hipError_t launch_split_duos(int cfg, const BlindRotateArgs& a, long grid, hipSt
 hipError_t launch_split_duos(int cfg, const BlindRotateArgs& a, long grid, hipStream_t st);
 // Split-key workgroup form (N = 1024; cfg 0 / 1 = the two shipped gadgets, 2 = redsec_params_small's l=3 Bgbit=10): a.bk_x = the split key of rs_general.h,
 // a.tw = the FFT tables of rs_fft.h. Returns hipErrorNotSupported for an unknown gadget id (caller: general kernel).
-hipError_t launch_blind_rotate_split_wg(int cfg, const BlindRotateArgs& a, int num_cus, const LaunchOpts& o, hipStream_t st, LaunchInfo* info) {
+hipError_t launch_blind_rotate_split_wg(int cfg, const BlindRotateArgs& a_in, int num_cus, const LaunchOpts& o, hipStream_t st, LaunchInfo* info) {
+  int* const cohort_table = a_in.progress;   // the caller's offer; only cohort_setup puts it back into a launch's arguments
+  BlindRotateArgs a = a_in;
+  a.progress = nullptr; a.cohort_every = 0; a.cohort_lag = 0;
   // any batch size: even a single group of it walks its CMUX chain in 57 us per step (REDsec set) against the 92 us of a lone
   // wave of the general kernel (sign1024x1 in split mode: 65.7 -> 40 ms). Up to 4 ciphertexts per CU the groups are 4 waves:
   // one wave per SIMD on twice the CUs.
@@ -1978,16 +1991,8 @@ hipError_t launch_blind_rotate_split_wg(int cfg, const BlindRotateArgs& a, int n
   const long groups = (a.B + wpb - 1) / wpb;
   const long grid = groups < num_cus ? groups : num_cus;
   BlindRotateArgs w = a;
-  if (w.progress && !o.no_cohort && grid <= 8L * kCohortSlots && groups > grid) {
-    // XCD cohorts (see cohort_step): only for launches whose workgroups walk several groups, i.e. sweep the key more than once.
-    // A CMUX step reads 2 * 2l half-rows of 16 KB; the lag keeps a cohort inside about a third of its 4 MB L2.
-    const long step_bytes = 4L * (cfg == 1 ? 10 : 3) * 16384;
-    w.cohort_lag = (int32_t)std::max<long>(1, (4L << 20) / 3 / step_bytes - 1);
-    w.cohort_every = w.cohort_lag >= 4 ? 2 : 1;
-    if (hipError_t e = hipMemsetAsync(w.progress, 0x7f, 8 * kCohortSlots * sizeof(int), st); e != hipSuccess) return e;
-  } else {
-    w.progress = nullptr;
-  }
+  // a CMUX step reads 2 * 2l half-rows of 16 KB
+  if (hipError_t e = cohort_setup(w, cohort_table, 4L * (cfg == 1 ? 10 : 3) * 16384, groups, grid, num_cus, o, st); e != hipSuccess) return e;
   auto go = [&](auto c) {
     using C = decltype(c);
     if (wpb == 8) hipLaunchKernelGGL((blind_rotate_wgs_kernel<C, 8>), dim3((unsigned)grid), dim3(512), 0, st, w);

@@ -158,3 +158,29 @@ def test_xcd_cohort_table_after_a_lock_step_launch(fix, name, mode, request, mon
     assert np.array_equal(got.cpu().numpy()[sample], ctx.bootstrap_batch(ct[sample], mu))
     be2.close()
     be.close()
+
+
+def test_cohort_table_is_left_alone_by_launches_without_cohorts(toy_default):
+    """Round-4 advisor finding: the half-size lock-step launch (default-128, 2 x #CUs < B <= 4 x #CUs: blind_rotate_wg_kernel<.., 4>)
+    used to reach the kernel with a non-null progress table and cohort_every = cohort_lag = 0 -- the workgroups then compared against
+    stale entries (48 polls each) and wrote their step counts into a table no launch had cleared. cohort_setup is now the only
+    place that hands a kernel the table: after a launch WITH cohorts the table holds that launch's entries, and a launch without
+    cohorts behind it (B = 3 x #CUs) must leave every word of it as it was -- and still equal the oracle."""
+    ks, ctx = toy_default
+    be = _backend(ks, "default128")
+    cus, n = be.info()["num_cus"], ks.p.n
+    mu = ol.to_torus(1, 8)
+    _, ct = _bits(ks, 16 * cus, 78)
+    be.bootstrap(_dev(ct), mu)
+    assert be.last_launch()["form"] == "workgroup" and be.last_launch()["waves_per_block"] == 8
+    before = be.cohort_table()
+    if cus == 256:                      # cohorts run on the whole chip as one partition only (8 XCDs, round-robin dispatch)
+        assert (before[:, :cus // 8] == 0x40000000 + 2 * n).all()
+    B = 3 * cus
+    _, ct3 = _bits(ks, B, 79)
+    got = be.bootstrap(_dev(ct3), mu)
+    assert be.last_launch()["form"] == "workgroup" and be.last_launch()["waves_per_block"] == 4
+    assert np.array_equal(be.cohort_table(), before)
+    sample = np.r_[0:6, B // 2 - 3:B // 2 + 3, B - 6:B]
+    assert np.array_equal(got.cpu().numpy()[sample], ctx.bootstrap_batch(ct3[sample], mu))
+    be.close()
