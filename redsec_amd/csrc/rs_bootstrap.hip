@@ -1618,13 +1618,11 @@ __global__ __launch_bounds__(64 * G) void blind_rotate_coop_kernel(BlindRotateAr
 // two inverse transforms to two waves with the fewest rows, on different SIMDs (waves 6 and 7). For l < 4 (six rows for
 // eight waves) the first form's deal stays -- waves 0-3 component 0, waves 4-7 component 1, inverse transforms on the
 // two waves without rows (3 and 4): measured faster there (2.66 against 2.73 ms).
-// Partial column sums meet in LDS in ONE exchange: 14 partials of 8 KB need homes, and every wave's transform
-// buffer is idle by then, so wave w leaves its column-0 partial in its own exchange buffer and its column-1
-// partial in slot w of s_part -- except that kInvA keeps column 0 and kInvB column 1 in registers, and kInvB's
-// column-0 partial goes to ITS s_part slot (free for that reason): after the barrier both inverse waves find
-// their own exchange buffers unused by anyone. LDS: 8 KB tables + 8 x 9 KB buffers + 64 KB partials + 8 KB
-// accumulator = 152 KB, one workgroup per CU. Integer results are independent of the summation order (the
-// sums are rounded to the exact integers, certificate-tracked as everywhere); two workgroup barriers per step.
+// Partial column sums meet by LDS floating-point atomics (ds_add_f64, no return value) in s_sum[2][N]; after the barrier each
+// inverse wave reads its 16 values, clears them for the next step, transforms and updates the accumulator (a first form parked
+// the 14 partials in idle transform buffers and s_part slots: 2.92 ms where the atomics take 2.64, MEASUREMENTS.md R4). Integer
+// results are independent of the summation order (the sums are rounded to the exact integers, certificate-tracked as
+// everywhere); two workgroup barriers per step. LDS: 8 KB tables + 8 x 9 KB buffers + 16 KB sums + 8 KB accumulator = 104 KB.
 // -------------------------------------------------------------------------------------------------
 template <class Xf>
 __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs a) {

@@ -591,37 +591,7 @@ long model_coop(int G, int broken) {
   }
   return m.conflicts();
 }
-// blind_rotate_coop8_kernel
-long model_coop8(int L, int broken) {
-  LdsModel m;
-  auto home = [&](int w, int col) {
-    int h = rs::coop8_partial_home(L, w, col);
-    if (broken == 1 && w == rs::coop8_inv_b(L) && col == 0) h = rs::kHomeOwnBuffer;   // the tempting uniform rule: "column 0 into the own buffer"
-    return h;
-  };
-  auto home_addr = [&](int w, int col) { return home(w, col) == rs::kHomeOwnBuffer ? buf_of(w) : LdsModel::PART + w * kPolyBytes; };
-  for (int step = 0; step < 2; ++step) {
-    for (int w = 0; w < rs::kCoop8Waves; ++w) {
-      if (rs::coop8_row_count(L, w) > 0) {
-        m.rd(w, LdsModel::ACC + rs::coop8_comp(L, w) * kAccBytes, kAccBytes);
-        m.rw(w, buf_of(w), kBufBytes);
-      }
-      for (int col = 0; col < 2; ++col)
-        if (home(w, col) != rs::kHomeRegisters) m.wr(w, home_addr(w, col), kPolyBytes);
-    }
-    m.barrier();
-    for (int col = 0; col < 2; ++col) {
-      const int w = col == 0 ? rs::coop8_inv_a(L) : rs::coop8_inv_b(L);
-      for (int g = 0; g < rs::kCoop8Waves; ++g)
-        if (g != w) m.rd(w, home_addr(g, col), kPolyBytes);
-      m.rw(w, buf_of(w), kBufBytes);
-      m.rw(w, LdsModel::ACC + col * kAccBytes, kAccBytes);
-    }
-    if (broken != 2) m.barrier();
-  }
-  return m.conflicts();
-}
-// blind_rotate_coop8_kernel as shipped (RS_COOP8_ATOMICS): every wave adds its partials into s_sum[2][N] by LDS f64 atomics; after the
+// blind_rotate_coop8_kernel: every wave adds its partials into s_sum[2][N] by LDS f64 atomics; after the
 // barrier the two inverse waves read their column's sum, clear it for the next step, transform, update the accumulator
 long model_coop8_atomics(int L, int broken) {
   LdsModel m;
@@ -984,7 +954,7 @@ long rs_emu_exchange_schedule(long rows, int n, long* out) {
   }
   return (long)plan.size();
 }
-// form: 0 coop<2>, 1 coop<4>, 2 / 3 coop8 with the s_part exchange (-DRS_COOP8_ATOMICS=0; l = 10 / 3), 4 coops<2>, 5 coops<4>, 6 duo, 7 duos,
+// form: 0 coop<2>, 1 coop<4>, (2 / 3: the s_part exchange form of coop8, removed in round 5) 4 coops<2>, 5 coops<4>, 6 duo, 7 duos,
 //       8 wgs<8>, 9 wgs<4>, 10 wg, 11 / 12 coop8 as shipped (sums by LDS atomics; l = 10 / 3)
 // The tiled keyswitch kernels (rs_kernels.hip), four waves. Every wave touches the whole of each LDS table, so all that keeps the
 // protocol sound is which barrier separates which phase:
@@ -1017,8 +987,6 @@ long rs_emu_lds_protocol_conflicts(int form, int broken) {
   switch (form) {
     case 0: return model_coop(2, broken);
     case 1: return model_coop(4, broken);
-    case 2: return model_coop8(10, broken);
-    case 3: return model_coop8(3, broken);
     case 4: return model_coops<2>(broken);
     case 5: return model_coops<4>(broken);
     case 6: return model_duo(10, broken);

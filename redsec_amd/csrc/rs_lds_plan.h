@@ -38,12 +38,6 @@ RS_HD constexpr int coop8_row_first(int L, int wave) {
   if (coop8_by_age(L) || (wave >> 2) == 0) return j * (L / 4) + (j < rem ? j : rem);
   return j * (L / 4) + (j > 4 - rem ? j - (4 - rem) : 0);
 }
-// where wave `wave` leaves its partial of column `col` for the wave that inverts that column (RS_COOP8_ATOMICS=0 form)
-enum { kHomeRegisters = 0, kHomeOwnBuffer = 1, kHomePartSlot = 2 };
-RS_HD constexpr int coop8_partial_home(int L, int wave, int col) {
-  if (col == 0) return wave == coop8_inv_a(L) ? kHomeRegisters : (wave == coop8_inv_b(L) ? kHomePartSlot : kHomeOwnBuffer);
-  return wave == coop8_inv_b(L) ? kHomeRegisters : kHomePartSlot;
-}
 
 // ---- blind_rotate_coops_kernel<G>: four sums (2 key halves x 2 columns), one owner wave each -----------------------------
 template <int G> RS_HD constexpr int coops_owner(int sum) { return G == 4 ? sum : (sum & 1); }

@@ -250,15 +250,16 @@ def test_general_path_digits_equal_tfhe_decomposition(l, bgbit):
     assert f(l, bgbit, 12345, 2654435761, 1 << 18) == 0
 
 
-LDS_FORMS = ["coop<2>", "coop<4>", "coop8 s_part exchange (l = 10)", "coop8 s_part exchange (l = 3)", "coops<2>", "coops<4>", "duo", "duos", "wgs<8>",
-             "wgs<4>", "wg<8>", "coop8 as shipped: atomics (l = 10)", "coop8 as shipped: atomics (l = 3)",
-             "keyswitch, one lookup per digit (rows stored behind the lookups)", "keyswitch, combined digits (base rows -> sums -> lookups)"]
+# form ids of rs_emu_lds_protocol_conflicts (2 and 3 were coop8's s_part exchange, removed with the switch that selected it)
+LDS_FORMS = {0: "coop<2>", 1: "coop<4>", 4: "coops<2>", 5: "coops<4>", 6: "duo", 7: "duos", 8: "wgs<8>", 9: "wgs<4>", 10: "wg<8>",
+             11: "coop8: sums by LDS atomics (l = 10)", 12: "coop8: sums by LDS atomics (l = 3)",
+             13: "keyswitch, one lookup per digit (rows stored behind the lookups)", 14: "keyswitch, combined digits (base rows -> sums -> lookups)"}
 # perturbations every form's model knows (rs_emulate.cpp): 1 = one placement / slot-count / hold decision changed the way a
 # plausible edit would change it, 2 = one workgroup barrier dropped, 3 (duo only) = the next quad requested before the swap
-LDS_BROKEN = {0: (1, 2), 1: (1, 2), 2: (1, 2), 3: (1, 2), 4: (1, 2), 5: (1, 2), 6: (1, 2, 3), 7: (1, 2), 8: (1,), 9: (1,), 10: (2,), 11: (1, 2), 12: (1, 2), 13: (1, 2), 14: (1, 2)}
+LDS_BROKEN = {0: (1, 2), 1: (1, 2), 4: (1, 2), 5: (1, 2), 6: (1, 2, 3), 7: (1, 2), 8: (1,), 9: (1,), 10: (2,), 11: (1, 2), 12: (1, 2), 13: (1, 2), 14: (1, 2)}
 
 
-@pytest.mark.parametrize("form", range(len(LDS_FORMS)), ids=LDS_FORMS)
+@pytest.mark.parametrize("form", sorted(LDS_FORMS), ids=[LDS_FORMS[k] for k in sorted(LDS_FORMS)])
 def test_lds_protocols_of_the_n1024_forms_have_no_cross_wave_conflict(form):
     """Every place where the waves of an N = 1024 blind-rotation workgroup hand data to each other through LDS -- the partial
     column sums of the cooperative forms (coop, coops, coop8), the partials the two waves of a ciphertext swap through the idle
