@@ -10,6 +10,11 @@
 //   16            NO-KEY TIMING PROBE, RESULTS ARE WRONG: every CMUX step reads the key rows of step 0, which stay in the L2s --
 //                 bounds what key streaming can cost a kernel (split lock-step, cooperative, coop8 and general-ring kernels);
 //                 rs_api.cpp then also switches the enforced split certificate off (the sums are garbage by construction)
+//   32            EXCHANGE-VOLUME TIMING PROBE, RESULTS ARE WRONG: every planar exchange moves only its re plane (half the
+//                 plane stores and loads of a transform), and each transform pays 16 v_permlane32_swap on its data registers
+//                 instead -- the instruction mix of a transform built from two 4-stage register passes on 32-lane halves (ONE
+//                 LDS exchange per transform) plus one cross-half swap stage. Prices that formulation before it is written.
+//   64            with 32: the same probe without the swaps (what the exchange volume alone is worth)
 //
 // Phase stamps (cdna_hip_programming.md section 7, in-kernel stamps): s_memtime behind s_waitcnt lgkmcnt(0) at up to eight
 // phase boundaries, summed per wave into g_rs_stamps and read back by rs_debug_read_stamps (not part of include/redsec_hip.h).
@@ -27,8 +32,13 @@ constexpr int kBits = RS_DIAG;
 constexpr int kBits = 0;
 #endif
 constexpr bool kNoKeyProbe = (kBits & 16) != 0;
+constexpr bool kHalfExchangeProbe = (kBits & 32) != 0;
+constexpr bool kHalfExchangeSwaps = (kBits & 64) == 0;
 // key rows of CMUX step i: step 0's under the probe
-__host__ __device__ constexpr int key_step(int i) { return kNoKeyProbe ? 0 : i; }
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+constexpr int key_step(int i) { return kNoKeyProbe ? 0 : i; }
 constexpr int kStampPhases = 8;
 }  // namespace diag
 }  // namespace rs

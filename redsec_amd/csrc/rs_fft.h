@@ -27,6 +27,7 @@
 
 #include <cstdint>
 
+#include "rs_diag.h"
 #include "rs_ntt.h"
 
 namespace rs {
@@ -371,6 +372,7 @@ typedef double rs_d2 __attribute__((ext_vector_type(2)));
 template <int LAY, int T, int H>
 RS_HD void fpl_store(int lane, const double (&x)[kRegs], double* buf) {
   constexpr int TO = (T == 1) ? (LAY == kLayA ? kLayB : kLayA) : (LAY == kLayB ? kLayC : kLayB);
+  if constexpr (diag::kHalfExchangeProbe && H == 1) return;   // diagnostic builds (rs_diag.h bit 32): the im plane stays where it is
 #pragma unroll
   for (int k = 0; k < kCRegs; ++k) { int a, b, c; flay_abc<LAY>(lane, k, a, b, c); RS_PLANE_STORE(buf, (xpos<LAY, TO>(a, b, c)), x[k + 8 * H]); }
 }
@@ -384,6 +386,22 @@ RS_HD void fpl_store(int lane, const double (&x)[kRegs], double* buf) {
 template <int LAY, int T, int H>
 RS_HD void fpl_load(int lane, double (&x)[kRegs], const double* buf) {
   constexpr int FROM = (T == 1) ? (LAY == kLayB ? kLayA : kLayB) : (LAY == kLayC ? kLayB : kLayC);
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (diag::kHalfExchangeProbe && H == 1) {   // diagnostic builds (rs_diag.h bit 32): no im plane; 16 cross-half swaps per transform
+    if constexpr (T == 1 && diag::kHalfExchangeSwaps) {
+#pragma unroll
+      for (int k = 0; k < kCRegs; ++k) {
+        unsigned long long u = (unsigned long long)__builtin_bit_cast(long long, x[k]), v = (unsigned long long)__builtin_bit_cast(long long, x[k + 8]);
+        unsigned ul = (unsigned)u, uh = (unsigned)(u >> 32), vl = (unsigned)v, vh = (unsigned)(v >> 32);
+        asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(ul), "+v"(vl));
+        asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(uh), "+v"(vh));
+        x[k] = __builtin_bit_cast(double, (long long)(((unsigned long long)uh << 32) | ul));
+        x[k + 8] = __builtin_bit_cast(double, (long long)(((unsigned long long)vh << 32) | vl));
+      }
+    }
+    return;
+  }
+#endif
 #pragma unroll
   for (int m = 0; m < kCRegs / 2; ++m) {
     int a, b, c;
