@@ -34,6 +34,7 @@ constexpr int kBits = 0;
 constexpr bool kNoKeyProbe = (kBits & 16) != 0;
 constexpr bool kHalfExchangeProbe = (kBits & 32) != 0;
 constexpr bool kHalfExchangeSwaps = (kBits & 64) == 0;
+constexpr bool kWrongOnPurpose = kNoKeyProbe || kHalfExchangeProbe;   // timing probes: rs_api.cpp then gates and enforces nothing
 // key rows of CMUX step i: step 0's under the probe
 #if defined(__HIPCC__)
 __host__ __device__
