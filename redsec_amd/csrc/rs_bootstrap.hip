@@ -580,23 +580,7 @@ __global__ __launch_bounds__(64 * WPB) void blind_rotate_wg_kernel(BlindRotateAr
   const int total_rows = n * KPL;   // key rows of one blind rotation (n <= 1024 steps x 2 l: far inside an int; scalar compares)
   RS_STAMP_DECL;   // -DRS_DIAG=1 (tools/stamp_profile.py): 0 step prologue, 1 digits + forward pair, 2 wait for the key rows + barrier, 3 multiply-
                    // accumulate, 4 barrier + next rows requested, 5 accumulator pre-read + inverse pair, 6 rounding + accumulator update, 7 group prologue / extract
-  // my 1/WPB share of key row R -> ring slot R & 1
-  const unsigned lane_off = (unsigned)lane * 16u;
-  auto issue_row = [&](long R) {
-    glds_chunks<kChunksPerWave>(a.bk_x + (size_t)R * kRowDoubles + (size_t)(wave * kChunksPerWave) * 128, lane_off,
-                                s_key[R & 1] + (wave * kChunksPerWave) * 128);
-  };
-  auto mac_row = [&](double (&s0)[kRegs], double (&s1)[kRegs], const double (&x)[kRegs], int slot) {
-    const double2* k0 = reinterpret_cast<const double2*>(s_key[slot]);
-    const double2* k1 = k0 + kN / 2;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      double2 w0[4], w1[4];
-#pragma unroll
-      for (int v = 0; v < 4; ++v) { w0[v] = k0[(4 * h + v) * 64 + lane]; w1[v] = k1[(4 * h + v) * 64 + lane]; }
-      Xf::mac(s0, s1, x, w0, w1, 4 * h, f);
-    }
-  };
+  const unsigned lane_off = (unsigned)lane * 16u;   // my 1/WPB share of a key row: chunks of 1 KB, 16 bytes per lane
 
   int steps_done = 0;   // CMUX steps of the groups this workgroup has finished (XCD cohorts, rs_cohort.h)
   for (long group = blockIdx.x; group < n_groups; group += gridDim.x, steps_done += n) {
