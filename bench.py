@@ -187,14 +187,16 @@ def sign_agreement(stages, lwe_key, device, strong=32, N=1024):
     independent of flips inherited from earlier layers), and the same over inputs at least 32 steps from a decision boundary.
     `bootstrap_agree_predicted` is what ANY exact TFHE implementation does to these inputs, from first principles: the bootstrap
     decides the sign of the phase AFTER modSwitchFromTorus32(., 2N) of the n + 1 words (lib/GPU/gates.cu:39-42 corroborates the
-    rounding), i.e. of phase + e with e a sum of n rounding errors, each uniform within half a step of 2^32 / 2N: standard deviation
-    sqrt(n / 12) steps of 2^21 = sqrt(350 / 12) x 2 = 10.8 message steps for the shipped set. The expected fraction of inputs that keep
-    their sign is the mean of Phi(d / sigma), d = the input's distance to the nearest decision boundary. Measured and predicted
-    agree to the third digit on every stage: the flips are the parameter set's, not this backend's."""
+    rounding), i.e. of phase + e with e the sum of the rounding errors of b and of the a_i under a key bit 1 (binary key: h of the n),
+    each uniform within half a step of 2^32 / 2N: standard deviation sqrt((h + 1) / 12) steps of 2^21 -- about 7.7 message steps for
+    the shipped set (n = 350, h ~ 175). The expected fraction of inputs that keep
+    their sign is the mean of Phi(d / sigma), d = the input's distance to the nearest decision boundary. Measured beside predicted
+    shows whose flips these are: the parameter set's, not this backend's."""
     import math
     import torch
     key = torch.from_numpy(lwe_key.astype("int64")).to(device)
-    sigma = math.sqrt(len(lwe_key) / 12.0) * (1 << 32) / (2 * N)       # torus32 units
+    weight = int((lwe_key != 0).sum())          # binary key: only the words under a 1 carry their rounding error into the phase (+ the b word)
+    sigma = math.sqrt((weight + 1) / 12.0) * (1 << 32) / (2 * N)       # torus32 units
     per, tot = [], {"units": 0, "agree": 0, "strong": 0, "agree_strong": 0, "bs_agree": 0, "bs_strong": 0, "bs_agree_strong": 0, "pred": 0.0}
     for name, ins, out, pre, bits in stages:
         enc = torch.where(_phase(out, key) >= 0, 1, -1)
@@ -206,9 +208,13 @@ def sign_agreement(stages, lwe_key, device, strong=32, N=1024):
         far = (ph_in.abs() >= (strong << 20)) & (ph_in.abs() <= (1 << 31) - (strong << 20))
         agree = enc == pb
         dist = torch.minimum(ph_in.abs(), (1 << 31) - ph_in.abs()).double()      # to the boundary at 0 or at 1/2
-        pred = float((0.5 * (1.0 + torch.erf(dist / (sigma * math.sqrt(2.0))))).sum())
+        p_keep = 0.5 * (1.0 + torch.erf(dist / (sigma * math.sqrt(2.0))))
+        # a TRIVIAL input (a = 0: a channel whose ternary weights are all zero leaves the bias alone) carries no rounding noise at all
+        trivial = (ins[0][:, :-1] == 0).all(dim=1) if len(ins) == 1 else torch.zeros_like(ph_in, dtype=torch.bool)
+        p_keep = torch.where(trivial, torch.ones_like(p_keep), p_keep)
+        pred = float(p_keep.sum())
         tot["pred"] += pred
-        rec = {"stage": name, "units": int(enc.numel()), "agree": round(float(agree.float().mean()), 5),
+        rec = {"stage": name, "units": int(enc.numel()), "trivial_inputs": int(trivial.sum()), "agree": round(float(agree.float().mean()), 5),
                "bootstrap_agree": round(float((enc == own).float().mean()), 5), "bootstrap_agree_predicted": round(pred / max(1, enc.numel()), 5),
                "bootstrap_agree_strong_input": round(float((enc == own)[far].float().mean()), 5) if bool(far.any()) else None}
         tot["units"] += int(enc.numel()); tot["agree"] += int(agree.sum())
@@ -224,7 +230,7 @@ def sign_agreement(stages, lwe_key, device, strong=32, N=1024):
             "agree_strong": round(tot["agree_strong"] / max(1, tot["strong"]), 5), "strong_units": tot["strong"],
             "bootstrap_agree": round(tot["bs_agree"] / max(1, tot["units"]), 5),
             "bootstrap_agree_predicted": round(tot["pred"] / max(1, tot["units"]), 5),
-            "predicted_from": "mod-switch rounding noise alone: sigma = sqrt(n / 12) steps of 2^32 / 2N = %.1f message steps; mean of Phi(distance to the decision boundary / sigma)" % (sigma / (1 << 20)),
+            "predicted_from": "mod-switch rounding noise alone: sigma = sqrt((h + 1) / 12) steps of 2^32 / 2N (h = %d key bits set) = %.1f message steps; mean of Phi(distance to the decision boundary / sigma)" % (weight, sigma / (1 << 20)),
             "bootstrap_agree_strong_input": round(tot["bs_agree_strong"] / max(1, tot["bs_strong"]), 5), "strong_inputs": tot["bs_strong"],
             "per_stage": per}
 
