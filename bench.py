@@ -211,7 +211,12 @@ def sign_agreement(stages, lwe_key, device, strong=32, N=1024):
         p_keep = 0.5 * (1.0 + torch.erf(dist / (sigma * math.sqrt(2.0))))
         # a TRIVIAL input (a = 0: a channel whose ternary weights are all zero leaves the bias alone) carries no rounding noise at all
         trivial = (ins[0][:, :-1] == 0).all(dim=1) if len(ins) == 1 else torch.zeros_like(ph_in, dtype=torch.bool)
-        p_keep = torch.where(trivial, torch.ones_like(p_keep), p_keep)
+        # ... so its fate is decided by the mod-switch of its b word alone: modSwitchFromTorus32(b, 2N) = (b + 2^(31 - log2 2N)) >> (32 - log2 2N),
+        # +mu for a result in [0, N) (a bias of -1 message step rounds to slot 0 and comes out positive: a deterministic flip)
+        sh = 32 - (2 * N).bit_length() + 1
+        slot = ((ph_in + (1 << (sh - 1))) >> sh) & (2 * N - 1)
+        kept = ((slot < N) == (ph_in >= 0)).double()
+        p_keep = torch.where(trivial, kept, p_keep)
         pred = float(p_keep.sum())
         tot["pred"] += pred
         rec = {"stage": name, "units": int(enc.numel()), "trivial_inputs": int(trivial.sum()), "agree": round(float(agree.float().mean()), 5),
