@@ -15,6 +15,9 @@
 //                 instead -- the instruction mix of a transform built from two 4-stage register passes on 32-lane halves (ONE
 //                 LDS exchange per transform) plus one cross-half swap stage. Prices that formulation before it is written.
 //   64            with 32: the same probe without the swaps (what the exchange volume alone is worth)
+//   128           HALF-KEY TIMING PROBE of the general-ring kernels, RESULTS ARE WRONG: only the first four of a row's eight key
+//                 positions are loaded (the other four multiply whatever the position registers hold) -- what halving the bytes on the
+//                 L2 -> CU path is worth, i.e. the most a form that shares every row between two ciphertexts of a CU could gain
 //
 // Phase stamps (cdna_hip_programming.md section 7, in-kernel stamps): s_memtime behind s_waitcnt lgkmcnt(0) at up to eight
 // phase boundaries, summed per wave into g_rs_stamps and read back by rs_debug_read_stamps (not part of include/redsec_hip.h).
@@ -34,7 +37,8 @@ constexpr int kBits = 0;
 constexpr bool kNoKeyProbe = (kBits & 16) != 0;
 constexpr bool kHalfExchangeProbe = (kBits & 32) != 0;
 constexpr bool kHalfExchangeSwaps = (kBits & 64) == 0;
-constexpr bool kWrongOnPurpose = kNoKeyProbe || kHalfExchangeProbe;   // timing probes: rs_api.cpp then gates and enforces nothing
+constexpr bool kHalfKeyProbe = (kBits & 128) != 0;
+constexpr bool kWrongOnPurpose = kNoKeyProbe || kHalfExchangeProbe || kHalfKeyProbe;   // timing probes: rs_api.cpp then gates and enforces nothing
 // key rows of CMUX step i: step 0's under the probe
 #if defined(__HIPCC__)
 __host__ __device__

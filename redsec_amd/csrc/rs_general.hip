@@ -251,7 +251,7 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
           }
 #pragma unroll
           for (int r = 0; r < 8; ++r) {
-            if (r + LA < 8) {
+            if (r + LA < (diag::kHalfKeyProbe ? 4 : 8)) {
 #pragma unroll
               for (int hc = 0; hc < 4; ++hc) {
                 w[(r + LA) % NB][hc] = gen_key_or_probe(kp + (size_t)hc * M + (r + LA) * T, tb, x[hc + 1], x[hc + 4]);
