@@ -1353,18 +1353,6 @@ __global__ __launch_bounds__(512) void blind_rotate_duo_kernel(BlindRotateArgs a
   };
   // (The eight 1 KB requests of a wave's share of the next quad spread over the six segments of the next forward pair instead of one burst
   // behind the barrier: 7.96 -> 9.97 ms at 1,024 ciphertexts, profiles/r04/aq_*: the rows arrive late and the asm statements cut the pair's schedule.)
-  auto mac_row = [&](double (&s0)[kRegs], double (&s1)[kRegs], const double (&x)[kRegs], int slot) {
-    const double2* k0 = reinterpret_cast<const double2*>(s_key[slot]);
-    const double2* k1 = k0 + kN / 2;
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      double2 w0[4], w1[4];
-#pragma unroll
-      for (int v = 0; v < 4; ++v) { w0[v] = k0[(4 * hh + v) * 64 + lane]; w1[v] = k1[(4 * hh + v) * 64 + lane]; }
-      Xf::mac(s0, s1, x, w0, w1, 4 * hh, f);
-    }
-  };
-
   for (long group = blockIdx.x; group < n_groups; group += gridDim.x) {
     const long ct = group * kCts + c;
     const bool active = ct < a.B;
