@@ -417,7 +417,8 @@ def cifar_batch_leg(local_rank, rank, world, dist_on, rehearsal, net_name, n_ima
     mine = sharding.image_assignment(n, rank, world)
     check = [(k + 1) % n for k in mine]                             # the neighbour's images, re-run after the timed region
     cts = {k: torch.from_numpy(sk.encrypt_image(pix[images[k]], seed=100 + images[k])).to(dev) for k in set(mine) | set(check)}
-    enc.run(cts[mine[0] if mine else check[0]])                     # warm-up: allocator, first launches
+    if cts:                                                         # (a rank of a batch smaller than the job has neither an image nor a check)
+        enc.run(cts[mine[0] if mine else check[0]])                 # warm-up: allocator, first launches
     torch.cuda.synchronize()
     if dist_on:
         import torch.distributed as dist
