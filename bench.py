@@ -240,7 +240,7 @@ def sign_agreement(stages, lwe_key, device, strong=32, N=1024):
             "per_stage": per}
 
 
-def redsec_set_legs(device_index, gates, with_cifar=True):
+def redsec_set_legs(device_index, gates, with_cifar=True, with_cpu=True):
     """The second half of BASELINE.json's metric (configs[2]): ONE encrypted MNIST sign1024x1 image, device-resident, through
     the layer chain of redsec_amd/nets.py on the parameter set REDsec ships (1,220 bootstraps in batches of 196 and 1,024;
     trained weights and a bundled test image from tests/golden). The same image is pushed through the split-key mode as
@@ -285,6 +285,27 @@ def redsec_set_legs(device_index, gates, with_cifar=True):
     enc.run(ct, taps=etaps)
     res["sign_agreement"] = sign_agreement([("layer%d" % k, (etaps["pre%d" % k],), etaps["bits%d" % k], ptaps["pre%d" % k], ptaps["bits%d" % k]) for k in (0, 1)],
                                            sk.lwe_key, ct.device)
+    if with_cpu:
+        # BASELINE configs[0], the CPU plumbing baseline, beside configs[2] in the same run: the SAME encrypted image under the SAME key
+        # through the oracle's layer chain (tests/oracle_net.py; its FP64-FFT product path, OpenMP over the gates of a layer) on this box's
+        # host cores -- and the ten logit ciphertexts it returns must equal the GPU's word for word (the checker checking the product:
+        # nothing measured above went through it)
+        import oracle_lib as ol
+        import oracle_net
+
+        class _K:
+            pass
+        k = _K(); k.p = ol.params("redsec_small_v2"); k.bk = sk.bk.ravel(); k.ksk = sk.ksk.ravel()
+        cores = host_cpu_share()
+        ol.lib().ro_set_threads(cores)
+        octx = ol.Ctx(k)
+        octx.set_fft(True)
+        t0 = time.perf_counter()
+        out_cpu = oracle_net.run(octx, enc.net, sk.encrypt_image(pixels[1], seed=5))
+        cpu_s = time.perf_counter() - t0
+        res["cpu_baseline"] = {"s_per_image": round(cpu_s, 3), "cores": int(cores), "kind": "port", "bootstraps_per_s": round(1220 / cpu_s, 1),
+                               "logit_ciphertexts_equal_gpu": bool(np.array_equal(out_cpu, out_f.cpu().numpy())),
+                               "what": "BASELINE configs[0] (nets/mnist/sign1024x1, 1 encrypted image, CPU): the oracle's layer chain on the host cores, same key and image"}
     # "also run the REDsec set" -- the same 65,536-NAND step on the shipped parameters
     rng = np.random.default_rng(11)
     ba, bb = rng.integers(0, 2, gates), rng.integers(0, 2, gates)
@@ -889,7 +910,7 @@ def main():
             "headline_mode": args.mode,
             "guaranteed_exact_throughput_form": "split (lock-step workgroup kernel on the split key); the exact-NTT mode is the per-wave form and serves as the gated recomputation path",
         }
-        mnist, redsec_nands, cifar = redsec_set_legs(local_rank, G, not args.no_cifar) if (world == 1 and not args.no_mnist and args.params == "default128") else (None, None, None)
+        mnist, redsec_nands, cifar = redsec_set_legs(local_rank, G, not args.no_cifar, args.cpu_sample != 0) if (world == 1 and not args.no_mnist and args.params == "default128") else (None, None, None)
 
         line = {
             "metric": "gate bootstraps/sec (N=1024)", "value": round(value, 1), "unit": "bootstraps/s",
