@@ -147,7 +147,7 @@ __global__ __launch_bounds__(Gen<LOGN>::T) __attribute__((amdgpu_waves_per_eu(2,
   // memory (N >= 2048: its levels lie above the LDS-staged ones): same-box +3.7 % at N = 4096 and +3.4 % at N = 8192 -- those loads
   // were requested one exchange ahead of their use and mostly waited for (profiles/r03/h_general_ab_last_pass_twiddles_kept.txt,
   // h_general_ab_which_pass_kept.txt). Keeping an LDS-served pass costs more in spilled registers than its reads save (pass 1 or 2
-  // at N = 4096: -0.7 % / -3.8 %). RS_GEN_KEEP_PASS forces a pass (-1: none).
+  // at N = 4096: -0.7 % / -3.8 %).
   constexpr bool kLastPassGlobal = !kGenStageTw<LOGN> || (2 << (Gen<LOGN>::LOGM - 1)) > kGenTwLds;
   constexpr int kKeepPass = (Gen<LOGN>::P >= 2 && kLastPassGlobal) ? Gen<LOGN>::P - 1 : -1;
   GenPassTw tw_kept;
