@@ -124,3 +124,25 @@ def test_kernel_sources_carry_no_experiment_switches():
             assert not (m and m.group(1) not in allowed), "overridable default in %s: %s" % (name, line.strip())
     assert seen <= allowed, sorted(seen - allowed)
     assert conditionals <= 40, conditionals                          # 25 today, most of them __HIP_DEVICE_COMPILE__ / __HIPCC__
+
+
+@pytest.mark.parametrize("src,flags", [
+    ("rs_bootstrap.hip", ["-DRS_DIAG=253"]),                       # stamps of the three part-1 kernels + every timing probe
+    ("rs_bootstrap.hip", ["-DRS_DIAG=2", "-DRS_BS_PART=2"]),      # stamps of the split lock-step kernel: the array lives in part 2
+    ("rs_bootstrap.hip", ["-DRS_DIAG=2", "-DRS_BS_PART=1"]),      # ... and part 1 of that build declares it without defining it
+    ("rs_general.hip", ["-DRS_DIAG=144"]),                         # no-key and half-key probes of the general rings
+    ("rs_api.cpp", ["-DRS_DIAG=48"]),                              # the probes' switch that turns the exactness gates off
+])
+def test_diagnostic_builds_compile(src, flags):
+    """Everything diagnostic sits behind -DRS_DIAG=<bits> (csrc/rs_diag.h) and no product build defines it: nothing but this test would
+    notice those paths rotting. Front end only (hipcc -fsyntax-only instantiates every kernel the launchers name): seconds."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "redsec_amd", "csrc")
+    r = subprocess.run([hipcc, "-fsyntax-only", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-command-line-argument",
+                        "-I" + os.path.join(ROOT, "include"), "-I" + csrc] + (["-x", "hip"] if src.endswith(".cpp") else []) + flags + [os.path.join(csrc, src)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
