@@ -515,6 +515,8 @@ def main():
                          "followed by its certificate-gated exact recomputation on the device (library default); exact = NTT over "
                          "a 51-bit prime (exact by construction)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="gates timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-fft-sample", type=int, default=-1, help="gates of the batch pushed through the oracle's FP64-FFT path for the CPU baseline and "
+                    "compared word for word (default: 1,024 per host core, about 16 s; the whole batch -- 65,536 -- takes about a minute)")
     ap.add_argument("--no-exact-check", action="store_true", help="skip the exact-NTT mode leg (its throughput and the full-batch cross-check)")
     ap.add_argument("--no-mnist", action="store_true", help="skip the legs on the parameter set REDsec ships: encrypted-MNIST-image latency and the same NAND step (N = 1 only)")
     ap.add_argument("--no-cifar", action="store_true", help="skip the encrypted CIFAR binarynet image (BASELINE configs[3]; about 20 s at N = 1)")
@@ -886,7 +888,7 @@ def main():
                 # (2) CPU baseline: the oracle's double-precision FFT path (the arithmetic class of TFHE's CPU
                 # library; ~8x faster than the exact path and bit-equal to it) on a larger sample of the batch
                 octx.set_fft(True)
-                bsample = min(G, 1024 * cores)     # ~16 s of CPU work at ~16 ms per gate and core
+                bsample = min(G, args.cpu_fft_sample if args.cpu_fft_sample > 0 else 1024 * cores)     # ~16 s of CPU work at ~16 ms per gate and core
                 octx.gate_batch("NAND", ca_h[:min(cores, bsample)], cb_h[:min(cores, bsample)])  # warm caches / threads
                 t1 = time.perf_counter()
                 ref_fft = octx.gate_batch("NAND", ca_h[:bsample], cb_h[:bsample])
