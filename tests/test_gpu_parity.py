@@ -188,6 +188,35 @@ def test_empty_batch_and_host_api(be_toy_default, toy_default):
     assert np.array_equal(be.mux_host(ca, cb, ca), ctx.mux_batch(ca, cb, ca))
 
 
+def test_host_pointer_calls_pipelined_in_chunks_equal_the_device_calls(toy_default, monkeypatch):
+    """rs_gate / rs_bootstrap / rs_mux with HOST pointers (the call shape of the reference's TFHE API) move
+    batches of at least two chunks (a chunk = 4 rounds of 8 x #CUs ciphertexts) through pinned slots while the previous chunk is
+    bootstrapped (rs_api.cpp host_roundtrip_pipelined): the result must equal the device-pointer call on the whole batch word for
+    word -- a batch of whole chunks, a ragged last chunk, three operands -- and the one-copy path (RS_NO_HOST_PIPELINE=1)."""
+    import torch
+    ks, ctx = toy_default
+    be = _backend(ks, "default128")
+    chunk = 4 * 8 * be.info()["num_cus"]
+    for B in (2 * chunk, 3 * chunk + 1000):
+        _, ca = _bits(ks, B, 31)
+        _, cb = _bits(ks, B, 32)
+        want = be.gate("XOR", _dev(ca), _dev(cb)).cpu().numpy()
+        assert np.array_equal(be.gate_host("XOR", ca, cb), want), B
+    B = 2 * chunk + 7
+    _, ca = _bits(ks, B, 33); _, cb = _bits(ks, B, 34); _, cc = _bits(ks, B, 35)
+    assert np.array_equal(be.mux_host(ca, cb, cc), be.mux(_dev(ca), _dev(cb), _dev(cc)).cpu().numpy())
+    want = be.bootstrap(_dev(ca), 1 << 20).cpu().numpy()
+    assert np.array_equal(be.bootstrap_host(ca, 1 << 20), want)
+    sample = np.r_[0:4, chunk - 2:chunk + 2, B - 4:B]
+    assert np.array_equal(want[sample], ctx.bootstrap_batch(ca[sample], 1 << 20))
+    monkeypatch.setenv("RS_NO_HOST_PIPELINE", "1")
+    be2 = _backend(ks, "default128")
+    monkeypatch.delenv("RS_NO_HOST_PIPELINE")
+    assert np.array_equal(be2.bootstrap_host(ca, 1 << 20), want)
+    be2.close()
+    be.close()
+
+
 def test_full_default128_nand_bit_exact_and_decrypts(be_full_default, full_default):
     """BASELINE config 2 shape at oracle-checkable size: default-128 NANDs, every word equal."""
     be = be_full_default
