@@ -905,7 +905,7 @@ def main():
                     "calls_recomputed_exactly_on_device": recomputed,
                     "statement": "every call is followed on the device by the exact-NTT kernels, which recompute it unless its largest rounding distance stayed below 1/4; "
                                  "an undetected wrong word needs an FFT error beyond 3/4 in a call whose every distance stayed below 1/4 (largest ever observed: 0.0156 = one unit in the last place at the magnitudes reached, "
-                                 "over 2.4e14 rounded values, profiles/r02/r_certificate_survey_large.jsonl + profiles/r03/q_certificate_survey_*.jsonl + profiles/r04/{o,s,au,av,bl,bq}_certificate_survey_*.jsonl: 48 times the largest deviation seen); no a-priori proof"},
+                                 "over 2.9e14 rounded values, profiles/r02/r_certificate_survey_large.jsonl + profiles/r03/q_certificate_survey_*.jsonl + profiles/r04/{o,s,au,av,bl,bq}_certificate_survey_*.jsonl + profiles/r05/{k,m,s}_certificate_survey_*.jsonl: 48 times the largest deviation seen); no a-priori proof"},
             "split": {"status": "proved", "a_priori_bound": split_mode["a_priori_bound"] if split_mode else None, "needs": "< 1/2",
                       "statement": "worst-case FFT error bound derived in csrc/rs_general.h for the butterflies used; rounding is exact for every input"},
             "exact": {"status": "proved", "statement": "exact NTT over a 51-bit prime carried in FP64; every step exact by construction, schedule validated at rs_create"},
