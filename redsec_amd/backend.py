@@ -180,10 +180,16 @@ class Backend:
         _check(self.L, self.L.rs_create(C.byref(h), C.byref(p), device))
         self.h = h
 
+    @property
+    def closed(self):
+        """True once rs_destroy has run: every other method would hand the library a null context."""
+        return not getattr(self, "h", None)
+
     def close(self, check=None):
         """rs_destroy; raises if the enforced split-mode certificate of some stream's last call had failed (nothing else would
         look at it any more) -- unless another exception is already on its way out (a close() in a `finally:` block must not
-        mask the error that brought the caller there) or check=False says the caller has dealt with the context's state."""
+        mask the error that brought the caller there) or check=False says the caller has dealt with the context's state. A
+        failure that is not raised is never dropped: it is reported as a RuntimeWarning carrying rs_last_error()."""
         if getattr(self, "h", None):
             h, self.h = self.h, None
             rc = self.L.rs_destroy(h)
@@ -192,10 +198,14 @@ class Backend:
                 check = sys.exc_info()[0] is None
             if check:
                 _check(self.L, rc)
+            elif rc != 0:
+                import warnings
+                warnings.warn("rs_destroy reported error %d while another error was being handled: %s"
+                              % (rc, (self.L.rs_last_error() or b"").decode()), RuntimeWarning, stacklevel=2)
 
     def __del__(self):
         try:
-            self.close()
+            self.close(check=False)
         except Exception:
             pass
 

@@ -113,12 +113,6 @@ struct rs_ctx {
   std::vector<int> peers_enabled, peers_denied;
   int32_t* h_stage = nullptr;                       // pinned staging buffer of this context's slice (host-staged exchange only)
   size_t h_stage_bytes = 0;
-  // pipelined host-pointer calls (host_roundtrip): two pinned chunk slots per operand, an upload and a download stream
-  int32_t* h_pipe_in[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-  int32_t* h_pipe_out[2] = {nullptr, nullptr};
-  size_t pipe_chunk = 0;                            // ciphertexts per pinned slot
-  hipStream_t pipe_up = nullptr, pipe_down = nullptr;
-  hipEvent_t pipe_ev_up[2] = {nullptr, nullptr}, pipe_ev_run[2] = {nullptr, nullptr}, pipe_ev_down[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -377,15 +371,6 @@ void destroy_ctx(rs_ctx* c) {
   if (c->ev_staged) (void)hipEventDestroy(c->ev_staged);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-  for (int s = 0; s < 2; ++s) {
-    for (auto& p : c->h_pipe_in[s]) if (p) (void)hipHostFree(p);
-    if (c->h_pipe_out[s]) (void)hipHostFree(c->h_pipe_out[s]);
-    if (c->pipe_ev_up[s]) (void)hipEventDestroy(c->pipe_ev_up[s]);
-    if (c->pipe_ev_run[s]) (void)hipEventDestroy(c->pipe_ev_run[s]);
-    if (c->pipe_ev_down[s]) (void)hipEventDestroy(c->pipe_ev_down[s]);
-  }
-  if (c->pipe_up) (void)hipStreamDestroy(c->pipe_up);
-  if (c->pipe_down) (void)hipStreamDestroy(c->pipe_down);
   delete c;
 }
 
@@ -507,7 +492,6 @@ int rs_create(rs_ctx** out, const rs_params* p, int device) {
   if (const char* v = getenv("REDSEC_SPLIT_CERT_LIMIT")) { const double x = atof(v); if (x > 0.0 && x < 0.25) c->split_cert_limit = x; }   // test hook: can only tighten
   c->opts.no_coop = env_on("RS_NO_COOP"); c->opts.no_wg = env_on("RS_NO_WG"); c->opts.no_duo = env_on("RS_NO_DUO");
   c->opts.no_persist = env_on("RS_NO_PERSIST"); c->opts.no_conv_tiled = env_on("RS_NO_CONV_TILED");
-  c->opts.no_host_pipeline = env_on("RS_NO_HOST_PIPELINE");
   c->opts.no_wg4 = env_on("RS_NO_WG4"); c->opts.no_tail = env_on("RS_NO_TAIL"); c->opts.no_coop8 = env_on("RS_NO_COOP8"); c->opts.ks_atomics = env_on("RS_KS_ATOMICS"); c->opts.force_host_staged = env_on("RS_FORCE_HOST_STAGED"); c->opts.no_cohort = env_on("RS_NO_COHORT");
   Lane* ln = nullptr;
   if (lane_of(c, nullptr, &ln) != RS_OK) { destroy_ctx(c); return RS_ERR_HIP; }   // the default stream's lane
@@ -685,80 +669,6 @@ int rs_keyswitch_dev(rs_ctx* c, int32_t* out, const int32_t* u, size_t B, void* 
 
 // ---- host-pointer conveniences: H2D, the *_dev call on the default stream, D2H. Serialised per context
 // (the per-ciphertext TFHE-style wrappers above this ABI are called from OpenMP regions). ----
-// Large batches travel in CHUNKS through pinned staging slots: while the default stream bootstraps chunk k, the host copies
-// chunk k + 1 into a pinned slot and an upload stream moves it to the device, and a download stream brings chunk k - 1 back
-// (pageable caller memory moved by one blocking hipMemcpy each way kept the GPU idle for a fifth of such a call). A chunk is a
-// whole number of the throughput kernels' rounds (8 ciphertexts per CU), so the chunks run in the same kernel form as the batch
-// would; every ciphertext is independent of the cut. Two slots per operand: slot k & 1 is reused once chunk k - 2 has left it.
-static constexpr size_t kPipeRounds = 4;            // rounds of 8 x #CUs ciphertexts per chunk (8,192 on 256 CUs: 20 MB per operand)
-static int pipe_setup(rs_ctx* c, size_t chunk) {
-  if (c->pipe_chunk >= chunk) return RS_OK;
-  const size_t bytes = chunk * (size_t)(c->p.n + 1) * sizeof(int32_t);
-  for (int s = 0; s < 2; ++s) {
-    for (auto& p : c->h_pipe_in[s]) { if (p) (void)hipHostFree(p); p = nullptr; RS_HIP(hipHostMalloc((void**)&p, bytes, hipHostMallocDefault)); }
-    if (c->h_pipe_out[s]) (void)hipHostFree(c->h_pipe_out[s]);
-    c->h_pipe_out[s] = nullptr;
-    RS_HIP(hipHostMalloc((void**)&c->h_pipe_out[s], bytes, hipHostMallocDefault));
-    if (!c->pipe_ev_up[s]) {
-      RS_HIP(hipEventCreateWithFlags(&c->pipe_ev_up[s], hipEventDisableTiming));
-      RS_HIP(hipEventCreateWithFlags(&c->pipe_ev_run[s], hipEventDisableTiming));
-      RS_HIP(hipEventCreateWithFlags(&c->pipe_ev_down[s], hipEventDisableTiming));
-    }
-  }
-  if (!c->pipe_up) RS_HIP(hipStreamCreateWithFlags(&c->pipe_up, hipStreamNonBlocking));
-  if (!c->pipe_down) RS_HIP(hipStreamCreateWithFlags(&c->pipe_down, hipStreamNonBlocking));
-  c->pipe_chunk = chunk;
-  return RS_OK;
-}
-static int host_roundtrip_pipelined(rs_ctx* c, int32_t* out, const int32_t* const* ins, int n_in, size_t B, size_t chunk,
-                                    int (*run)(rs_ctx*, int32_t*, int32_t* const*, size_t, void*), void* extra) {
-  int rc = pipe_setup(c, chunk);
-  if (rc) return rc;
-  const size_t W = (size_t)(c->p.n + 1), n_chunks = (B + chunk - 1) / chunk;
-  auto rows = [&](size_t k) { return std::min(chunk, B - k * chunk); };
-  auto collect = [&](size_t k) -> int {   // chunk k's results: pinned slot -> the caller's array
-    RS_HIP(hipEventSynchronize(c->pipe_ev_down[k & 1]));
-    memcpy(out + k * chunk * W, c->h_pipe_out[k & 1], rows(k) * W * sizeof(int32_t));
-    return RS_OK;
-  };
-  for (size_t k = 0; k < n_chunks; ++k) {
-    const int s = (int)(k & 1);
-    const size_t r = rows(k), bytes = r * W * sizeof(int32_t);
-    if (k >= 2) {   // slot s still belongs to chunk k - 2: its upload must have left the pinned inputs, its results the pinned output
-      RS_HIP(hipEventSynchronize(c->pipe_ev_up[s]));
-      rc = collect(k - 2);
-      if (rc) return rc;
-    }
-    int32_t* d_in[3] = {nullptr, nullptr, nullptr};
-    for (int i = 0; i < n_in; ++i) {
-      memcpy(c->h_pipe_in[s][i], ins[i] + k * chunk * W, bytes);
-      d_in[i] = c->d_io[i] + k * chunk * W;
-      RS_HIP(hipMemcpyAsync(d_in[i], c->h_pipe_in[s][i], bytes, hipMemcpyHostToDevice, c->pipe_up));
-    }
-    RS_HIP(hipEventRecord(c->pipe_ev_up[s], c->pipe_up));
-    RS_HIP(hipStreamWaitEvent(nullptr, c->pipe_ev_up[s], 0));
-    int32_t* d_out = c->d_io[3] + k * chunk * W;
-    rc = run(c, d_out, d_in, r, extra);
-    if (rc) return rc;
-    RS_HIP(hipEventRecord(c->pipe_ev_run[s], nullptr));
-    RS_HIP(hipStreamWaitEvent(c->pipe_down, c->pipe_ev_run[s], 0));
-    RS_HIP(hipMemcpyAsync(c->h_pipe_out[s], d_out, bytes, hipMemcpyDeviceToHost, c->pipe_down));
-    RS_HIP(hipEventRecord(c->pipe_ev_down[s], c->pipe_down));
-  }
-  RS_HIP(hipStreamSynchronize(nullptr));
-  {
-    Lane* ln = nullptr;
-    rc = lane_of(c, nullptr, &ln);
-    if (rc) return rc;
-    rc = split_check_lane(c, ln);   // a host call never hands back an uncertified split-mode result
-    if (rc) return rc;
-  }
-  for (size_t k = n_chunks >= 2 ? n_chunks - 2 : 0; k < n_chunks; ++k) {
-    rc = collect(k);
-    if (rc) return rc;
-  }
-  return RS_OK;
-}
 static int host_roundtrip(rs_ctx* c, int32_t* out, const int32_t* const* ins, int n_in, size_t B,
                           int (*run)(rs_ctx*, int32_t*, int32_t* const*, size_t, void*), void* extra) {
   int rc = ready(c);
@@ -770,12 +680,7 @@ static int host_roundtrip(rs_ctx* c, int32_t* out, const int32_t* const* ins, in
   const size_t bytes = B * (size_t)(c->p.n + 1) * sizeof(int32_t);
   for (int i = 0; i < n_in; ++i)
     if (!ins[i]) return fail(RS_ERR_INVALID, "null ciphertext pointer");
-  const size_t chunk = kPipeRounds * 8 * (size_t)c->num_cus;
-  if (B >= 2 * chunk && !c->opts.no_host_pipeline) return host_roundtrip_pipelined(c, out, ins, n_in, B, chunk, run, extra);
-  for (int i = 0; i < n_in; ++i) {
-    if (!ins[i]) return fail(RS_ERR_INVALID, "null ciphertext pointer");
-    RS_HIP(hipMemcpy(c->d_io[i], ins[i], bytes, hipMemcpyHostToDevice));
-  }
+  for (int i = 0; i < n_in; ++i) RS_HIP(hipMemcpy(c->d_io[i], ins[i], bytes, hipMemcpyHostToDevice));
   rc = run(c, c->d_io[3], c->d_io, B, extra);
   if (rc) return rc;
   RS_HIP(hipStreamSynchronize(nullptr));

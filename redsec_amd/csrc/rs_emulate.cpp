@@ -800,7 +800,6 @@ int rs_emu_gen_literal_twiddle_check() {
 
 // selects the exchange form emulated by the FFT entry points (0 interleaved, 1 planar)
 void rs_emu_set_planar(int on) { g_planar = on; }
-// selects the inverse transform emulated by the FFT entry points (0 Gentleman-Sande, 1 decimation in time)
 
 // FFT-mode product of a small polynomial with a torus polynomial; returns the largest distance to
 // the nearest integer seen before rounding in *max_dev.

@@ -106,33 +106,18 @@ __device__ __forceinline__ void ks_tile_finish(const KeyswitchArgs& a, const uin
   }
 }
 
-// XCD-aware tile order of the tiled keyswitch kernels (A/B switch, OFF). Workgroups reach the 8 XCDs round-robin in dispatch order
-// (x fastest), so the 256 ciphertext tiles that share one 32-word slice of the KSK are spread over all eight L2s and every L2 pulls
-// every slice (27.6 GB of fabric traffic per 65,536-gate launch for a 62 MB key). With 0=1 the idx-th workgroup an XCD
-// receives takes tile xcd * (total / 8) + idx of the y-major order, so that an XCD works through whole slices: measured 16.8 GB
-// instead of 27.6 GB and 11.30 instead of 11.18 ms (profiles/r04/bm_*) -- the rows are requested behind the lookups since round 4
-// and the kernel is bound by its LDS reads, so the traffic was not what it waited for; left off.
-__device__ __forceinline__ void ks_tile_of_block(unsigned& bx, unsigned& by) {
-  bx = blockIdx.x; by = blockIdx.y;
-  const unsigned nx = gridDim.x, total = gridDim.x * gridDim.y, per = total >> 3;
-  const unsigned lin = blockIdx.x + nx * blockIdx.y;
-  if (0 && gridDim.z == 1 && per > 0 && lin < 8 * per) {
-    const unsigned tile = (lin & 7) * per + (lin >> 3);
-    by = tile / nx; bx = tile - by * nx;
-  }
-}
-
+// Tile order of the tiled keyswitch kernels: dispatch order (x fastest). An XCD-aware order (each XCD working through whole
+// 32-word slices of the KSK) was measured in round 4 -- 16.8 instead of 27.6 GB of fabric traffic, 11.30 instead of 11.18 ms
+// (profiles/r04/bm_*): the kernel is bound by its LDS reads, not by that traffic -- and removed.
 template <int T, int BASEBIT, int KS_IG>  // KS_IG = input coefficients staged per round
 __global__ __launch_bounds__(KS_TILE_THREADS) void keyswitch_tiled_kernel(KeyswitchArgs a) {
   constexpr int BASE = 1 << BASEBIT;
   constexpr int ROWS = KS_IG * T * BASE;
   __shared__ __attribute__((aligned(16))) int32_t s_ksk[2][ROWS * KS_CHP];
   const int tid = threadIdx.x;
-  unsigned bx, by;
-  ks_tile_of_block(bx, by);
-  const long ct = (long)bx * KS_TILE_THREADS + tid;
+  const long ct = (long)blockIdx.x * KS_TILE_THREADS + tid;
   const bool live = ct < a.B;
-  const int w0 = (int)by * KS_CH;
+  const int w0 = (int)blockIdx.y * KS_CH;
   const int W = a.W, N = a.N;   // ring degree of the extracted samples: 1024 ... 8192
   const int32_t* u0 = a.u0 + (live ? ct : 0) * (size_t)(N + 1);
   const int32_t* u1 = a.u1 ? a.u1 + (live ? ct : 0) * (size_t)(N + 1) : nullptr;
@@ -242,11 +227,9 @@ __global__ __launch_bounds__(KS_TILE_THREADS) void keyswitch_tiled_comb_kernel(K
   __shared__ __attribute__((aligned(16))) int32_t s_base[BROWS * KS_CHP];
   __shared__ __attribute__((aligned(16))) int32_t s_tab[TROWS * KS_CHP];
   const int tid = threadIdx.x;
-  unsigned bx, by;
-  ks_tile_of_block(bx, by);
-  const long ct = (long)bx * KS_TILE_THREADS + tid;
+  const long ct = (long)blockIdx.x * KS_TILE_THREADS + tid;
   const bool live = ct < a.B;
-  const int w0 = (int)by * KS_CH;
+  const int w0 = (int)blockIdx.y * KS_CH;
   const int W = a.W, N = a.N;
   const int32_t* u0 = a.u0 + (live ? ct : 0) * (size_t)(N + 1);
   const int32_t* u1 = a.u1 ? a.u1 + (live ? ct : 0) * (size_t)(N + 1) : nullptr;
@@ -642,13 +625,11 @@ hipError_t launch_keyswitch(const KeyswitchArgs& a_in, hipStream_t st) {
     if (e != hipSuccess) return e;
   }
   if (tiled && a.t == 8) {
-    if (1) hipLaunchKernelGGL((keyswitch_tiled_comb_kernel<8, 2, 4, 2>), grid, dim3(KS_TILE_THREADS), 0, st, a);
-    else hipLaunchKernelGGL((keyswitch_tiled_kernel<8, 2, 4>), grid, dim3(KS_TILE_THREADS), 0, st, a);
+    hipLaunchKernelGGL((keyswitch_tiled_comb_kernel<8, 2, 4, 2>), grid, dim3(KS_TILE_THREADS), 0, st, a);
   } else if (tiled && a.t == 9) {
     hipLaunchKernelGGL((keyswitch_tiled_kernel<9, 3, 2>), grid, dim3(KS_TILE_THREADS), 0, st, a);
   } else if (tiled) {
-    if (1) hipLaunchKernelGGL((keyswitch_tiled_comb_kernel<18, 1, 4, 4>), grid, dim3(KS_TILE_THREADS), 0, st, a);
-    else hipLaunchKernelGGL((keyswitch_tiled_kernel<18, 1, 4>), grid, dim3(KS_TILE_THREADS), 0, st, a);
+    hipLaunchKernelGGL((keyswitch_tiled_comb_kernel<18, 1, 4, 4>), grid, dim3(KS_TILE_THREADS), 0, st, a);
   } else {
     // generic gather form: any ring degree, any (t, basebit), any sample width
     const unsigned wy = (unsigned)((a.W + KS_THREADS * KS_MAXR - 1) / (KS_THREADS * KS_MAXR));

@@ -93,7 +93,7 @@ def image_assignment(n_images, rank, world):
     return list(range(int(rank), int(n_images), int(world)))
 
 
-def image_parallel(run_image, images, out_shape, group=None, force=False):
+def image_parallel(run_image, images, out_shape, group=None, force=False, device=None):
     """Image-parallel replicas (partitioning 1): every rank holds a full key replica and runs
     `run_image(images[i])` -> int32 [classes][W] (the logit ciphertexts, on the rank's device) for the images
     image_assignment gives it; the only exchange is ONE all-gather of classes x W words per image at the end (10 x 351 words
@@ -101,7 +101,10 @@ def image_parallel(run_image, images, out_shape, group=None, force=False):
     [n_images][classes][W] in image order, identical on every rank; this rank's seconds of compute before the collective;
     seconds in the collective). `images`: a sequence every rank can index (a rank touches only its own); `out_shape` =
     (classes, W), known to a rank even when it has no image of a short batch. Without an initialised process group (or one
-    rank and not `force`) it is the plain loop."""
+    rank and not `force`) it is the plain loop. `device`: where a rank WITHOUT an image of a short batch builds its (all-zero)
+    contribution and returns the result -- it must be the device the other ranks' logits live on (with the gloo backend on a
+    GPU box that may be the CPU); default: the current HIP device if there is one. An empty batch returns an empty
+    [0][classes][W] tensor and runs no collective."""
     import time
     n = len(images)
     on = dist.is_available() and dist.is_initialized()
@@ -113,13 +116,20 @@ def image_parallel(run_image, images, out_shape, group=None, force=False):
     if outs and outs[0].is_cuda:
         torch.cuda.synchronize(outs[0].device)
     t_compute = time.perf_counter() - t0
+    shape = tuple(int(v) for v in out_shape)
+    if outs:
+        dev = outs[0].device
+    elif device is not None:
+        dev = torch.device(device)
+    else:
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    if n == 0:                                                  # every rank sees the same n: nobody enters the collective
+        return torch.empty((0,) + shape, dtype=torch.int32, device=dev), t_compute, 0.0
     if world == 1 and not force:
         return torch.stack(outs), t_compute, 0.0
     t1 = time.perf_counter()
     per_rank = -(-n // world)                                   # slots per rank; a short rank pads with zeros
-    shape = tuple(int(v) for v in out_shape)
     assert all(tuple(o.shape) == shape for o in outs)
-    dev = outs[0].device if outs else torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     via_host = dev.type == "cuda" and dist.get_backend(group) == "gloo"
     buf_dev = torch.device("cpu") if via_host else dev
     local = torch.zeros((per_rank,) + shape, dtype=torch.int32, device=buf_dev)

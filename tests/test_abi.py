@@ -122,6 +122,10 @@ def test_kernel_sources_carry_no_experiment_switches():
                 seen |= set(re.findall(r"\bRS_[A-Z0-9_]+\b", line))
             m = re.match(r"\s*#\s*ifndef\s+(RS_[A-Z0-9_]+)", line)     # the `#ifndef X / #define X default` idiom of an A/B switch
             assert not (m and m.group(1) not in allowed), "overridable default in %s: %s" % (name, line.strip())
+            code = line.split("//")[0]
+            # what a textual macro replacement leaves behind: branches on a literal, `0=1` in prose
+            assert not re.search(r"\bif\s*\(\s*[01!]\s*(\)|&&|\|\|)|\b(&&|\|\|)\s*[01]\s*\)", code), "constant condition in %s: %s" % (name, line.strip())
+            assert not re.search(r"\b[01]=[01]\b", line), "garbled switch text in %s: %s" % (name, line.strip())
     assert seen <= allowed, sorted(seen - allowed)
     assert conditionals <= 40, conditionals                          # 25 today, most of them __HIP_DEVICE_COMPILE__ / __HIPCC__
 

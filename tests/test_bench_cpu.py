@@ -25,6 +25,22 @@ def test_instruction_count_models():
     assert bench.host_cpu_share() >= 1
 
 
+def test_record_helpers(tmp_path):
+    """What VERDICT round 5 asked the line to carry: the CPU model beside the thread count, the median step beside the mean,
+    the reference's own bootstrap count of CIFAR binarynet beside the fused form's."""
+    f = tmp_path / "cpuinfo"
+    f.write_text("processor\t: 0\nvendor_id\t: X\nmodel name\t: Some CPU 9654 96-Core @ 2.4GHz\nmodel name\t: other\n")
+    assert bench.host_cpu_model(str(f)) == "Some CPU 9654 96-Core @ 2.4GHz"
+    assert bench.host_cpu_model(str(tmp_path / "missing")) == "unknown"
+    assert isinstance(bench.host_cpu_model(), str) and bench.host_cpu_model()
+    med, lo, hi = bench.step_time_stats([10.0, 10.3, 10.61, 10.93, 11.5, 11.81])
+    assert abs(med - 310.0) < 1e-6 and abs(lo - 300.0) < 1e-6 and abs(hi - 570.0) < 1e-6
+    assert bench.step_time_stats([1.0]) == (None, None, None)
+    assert bench.CIFAR_BINARYNET_REFERENCE_BOOTSTRAPS == 693248           # SURVEY.md appendix B
+    import oracle_lib as ol
+    assert ol.lib().ro_max_threads() >= 1                                 # what `omp_threads` in cpu_baseline reports
+
+
 def test_sign_agreement_on_a_simulated_bootstrap():
     import torch
     rng = np.random.default_rng(42)

@@ -1,10 +1,12 @@
 """GPU parity: HIP path (through the C ABI) vs the CPU oracle, bit-exact, on identical keys and
 identical seeded inputs. Integer work => the bar is equality of every ciphertext word."""
+import contextlib
 import os
 import numpy as np
 import pytest
 
 import oracle_lib as ol
+from backend_pool import BackendPool
 
 pytestmark = pytest.mark.gpu
 
@@ -12,18 +14,35 @@ ALPHA = 2.0 ** -15
 ALL_GATES = ["NAND", "OR", "AND", "NOR", "XOR", "XNOR", "ANDNY", "ANDYN", "ORNY", "ORYN"]
 
 
-_BACKENDS = []
+POOL = BackendPool()      # contexts this module keeps alive; a closed one is never called again (tests/backend_pool.py)
 
 
-def _backend(ks, name):
+def _make(ks, name, **fields):
     import torch
     import redsec_amd
     assert torch.cuda.is_available(), "GPU tests need a HIP device"
     p = redsec_amd.params(name, n=ks.p.n)
+    for k, v in fields.items():
+        setattr(p, k, v)
     be = redsec_amd.Backend(p, device=0)
     be.load_keys(ks.bk, ks.ksk)
-    _BACKENDS.append(be)
     return be
+
+
+def _backend(ks, name):
+    """A context for the module's lifetime (the module-scoped fixtures below)."""
+    return POOL.add(_make(ks, name))
+
+
+def _scratch(ks, name, **fields):
+    """`with _scratch(...) as be:` -- a context for one test body, closed and forgotten by the pool."""
+    return POOL.scratch(lambda: _make(ks, name, **fields))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _close_module_contexts():
+    yield
+    POOL.close_all()
 
 
 @pytest.fixture(autouse=True, params=["fft", "exact"])
@@ -31,13 +50,9 @@ def arith_mode(request):
     """Every parity test runs twice: in the FFT mode (default; exact after rounding, checked against the
     SAME exact oracle) and in the guaranteed-exact NTT mode. After an FFT-mode test the rounding
     certificate must be far below 1/2."""
-    for be in _BACKENDS:
-        be.set_mode(request.param)
-        be.rounding_certificate(reset=True)
+    POOL.enter_mode(request.param)
     yield request.param
-    if request.param == "fft":
-        for be in _BACKENDS:
-            assert be.rounding_certificate(reset=True) < 0.2
+    POOL.leave_mode(request.param)
 
 
 @pytest.fixture(scope="module")
@@ -160,18 +175,15 @@ def test_keyswitch_tile_boundaries(which, fix, request):
 
 def test_generic_keyswitch_shape(arith_mode):
     """ks_t = 6 is not one of the tiled instantiations: the generic gather kernel must agree too."""
-    import redsec_amd
     p = ol.params("toy_ks6")
     ks = ol.KeySet(p, seed=9)
     ctx = ol.Ctx(ks)
-    rp = redsec_amd.params("default128", n=p.n)
-    rp.ks_t = 6
-    be = redsec_amd.Backend(rp, device=0)
-    be.load_keys(ks.bk, ks.ksk)
-    be.set_mode(arith_mode)
     _, ca = _bits(ks, 19, 1)
     _, cb = _bits(ks, 19, 2)
-    assert np.array_equal(be.gate("XNOR", _dev(ca), _dev(cb)).cpu().numpy(), ctx.gate_batch("XNOR", ca, cb))
+    with _scratch(ks, "default128", ks_t=6) as be:
+        be.set_mode(arith_mode)
+        assert np.array_equal(be.gate("XNOR", _dev(ca), _dev(cb)).cpu().numpy(), ctx.gate_batch("XNOR", ca, cb))
+    ctx.close()
 
 
 def test_empty_batch_and_host_api(be_toy_default, toy_default):
@@ -188,33 +200,21 @@ def test_empty_batch_and_host_api(be_toy_default, toy_default):
     assert np.array_equal(be.mux_host(ca, cb, ca), ctx.mux_batch(ca, cb, ca))
 
 
-def test_host_pointer_calls_pipelined_in_chunks_equal_the_device_calls(toy_default, monkeypatch):
-    """rs_gate / rs_bootstrap / rs_mux with HOST pointers (the call shape of the reference's TFHE API) move
-    batches of at least two chunks (a chunk = 4 rounds of 8 x #CUs ciphertexts) through pinned slots while the previous chunk is
-    bootstrapped (rs_api.cpp host_roundtrip_pipelined): the result must equal the device-pointer call on the whole batch word for
-    word -- a batch of whole chunks, a ragged last chunk, three operands -- and the one-copy path (RS_NO_HOST_PIPELINE=1)."""
-    import torch
+def test_large_host_pointer_calls_equal_the_device_calls(be_toy_default, toy_default):
+    """rs_gate / rs_bootstrap / rs_mux with HOST pointers (the call shape of the reference's TFHE API, SURVEY.md section 8b;
+    one upload, the device call, one download) on batches of several launch rounds: equal to the device-pointer call on the
+    whole batch word for word, and to the oracle on a sample."""
+    be = be_toy_default
     ks, ctx = toy_default
-    be = _backend(ks, "default128")
-    chunk = 4 * 8 * be.info()["num_cus"]
-    for B in (2 * chunk, 3 * chunk + 1000):
-        _, ca = _bits(ks, B, 31)
-        _, cb = _bits(ks, B, 32)
-        want = be.gate("XOR", _dev(ca), _dev(cb)).cpu().numpy()
-        assert np.array_equal(be.gate_host("XOR", ca, cb), want), B
-    B = 2 * chunk + 7
+    rounds = 8 * be.info()["num_cus"]
+    B = 2 * rounds + 7
     _, ca = _bits(ks, B, 33); _, cb = _bits(ks, B, 34); _, cc = _bits(ks, B, 35)
+    assert np.array_equal(be.gate_host("XOR", ca, cb), be.gate("XOR", _dev(ca), _dev(cb)).cpu().numpy())
     assert np.array_equal(be.mux_host(ca, cb, cc), be.mux(_dev(ca), _dev(cb), _dev(cc)).cpu().numpy())
     want = be.bootstrap(_dev(ca), 1 << 20).cpu().numpy()
     assert np.array_equal(be.bootstrap_host(ca, 1 << 20), want)
-    sample = np.r_[0:4, chunk - 2:chunk + 2, B - 4:B]
+    sample = np.r_[0:4, rounds - 2:rounds + 2, B - 4:B]
     assert np.array_equal(want[sample], ctx.bootstrap_batch(ca[sample], 1 << 20))
-    monkeypatch.setenv("RS_NO_HOST_PIPELINE", "1")
-    be2 = _backend(ks, "default128")
-    monkeypatch.delenv("RS_NO_HOST_PIPELINE")
-    assert np.array_equal(be2.bootstrap_host(ca, 1 << 20), want)
-    be2.close()
-    be.close()
 
 
 def test_full_default128_nand_bit_exact_and_decrypts(be_full_default, full_default):
@@ -292,14 +292,12 @@ def test_workgroup_kernel_ragged_groups_and_identity_steps(which, fix, size, req
         assert (launch["form"], launch["waves_per_block"]) == (("workgroup", 8) if size == "wg8" else (("duo", 8) if ks.p.bk_l % 2 == 0 else ("workgroup", 4)))
     # the launch switches are read once, at context creation: a second context under RS_NO_WG runs the per-wave kernel
     monkeypatch.setenv("RS_NO_WG", "1")
-    be2 = _backend(ks, "default128" if ks.p.bk_l == 3 else "redsec_small_v2")
-    monkeypatch.delenv("RS_NO_WG")
-    be2.set_mode(be.mode())
-    ref = be2.bootstrap(d, mu)
-    assert be2.last_launch()["form"] == "per_wave"
-    assert torch.equal(got, ref)
-    _BACKENDS.remove(be2)
-    be2.close()
+    with _scratch(ks, "default128" if ks.p.bk_l == 3 else "redsec_small_v2") as be2:
+        monkeypatch.delenv("RS_NO_WG")
+        be2.set_mode(be.mode())
+        ref = be2.bootstrap(d, mu)
+        assert be2.last_launch()["form"] == "per_wave"
+        assert torch.equal(got, ref)
     sample = np.r_[0:8, B - 11:B]
     assert np.array_equal(got.cpu().numpy()[sample], ctx.bootstrap_batch(ct[sample], mu))
 
@@ -495,34 +493,31 @@ def test_workgroup_and_duo_kernels_on_full_keys_against_oracle(which, fix, form,
 
 
 @pytest.mark.parametrize("which,fix", [("be_toy_default", "toy_default"), ("be_toy_redsec", "toy_redsec")])
-def test_last_partial_round_runs_in_its_own_form(which, fix, request):
+def test_last_partial_round_runs_in_its_own_form(which, fix, request, monkeypatch):
     """A batch of one full round of the lock-step form plus a remainder of at most 4 x #CUs: the remainder is cut off and
     launched in the form its size would take by itself (cooperative / duo / half-size groups). Outputs -- also of the
     programmable bootstrap, whose test polynomial is chosen by the ciphertext's index in the WHOLE batch -- equal the
     unsplit launch (RS_NO_TAIL context) word for word and the oracle on a sample around the cut."""
-    import os
     import torch
     be = request.getfixturevalue(which)
     ks, ctx = request.getfixturevalue(fix)
     cus = be.info()["num_cus"]
     mu = ol.to_torus(1, 8)
     rng = np.random.default_rng(12)
-    os.environ["RS_NO_TAIL"] = "1"
-    be2 = _backend(ks, "default128" if ks.p.bk_l == 3 else "redsec_small_v2")
-    del os.environ["RS_NO_TAIL"]
-    be2.set_mode(be.mode())
-    luts = _dev(rng.integers(-2**31, 2**31, (7, ks.p.N)).astype(np.int32))
-    for tail in (5, cus + 3, 3 * cus + 1):
-        B = 8 * cus + tail
-        _, ct = _bits(ks, B, 900 + tail)
-        d = _dev(ct)
-        got, ref = be.bootstrap(d, mu), be2.bootstrap(d, mu)
-        assert torch.equal(got, ref), tail
-        assert torch.equal(be.bootstrap_lut(d, luts), be2.bootstrap_lut(d, luts)), tail
-        sample = np.r_[0:4, 8 * cus - 4:8 * cus + 4, B - 4:B]
-        assert np.array_equal(got.cpu().numpy()[sample], ctx.bootstrap_batch(ct[sample], mu)), tail
-    _BACKENDS.remove(be2)
-    be2.close()
+    monkeypatch.setenv("RS_NO_TAIL", "1")         # read once, in rs_create
+    with _scratch(ks, "default128" if ks.p.bk_l == 3 else "redsec_small_v2") as be2:
+        monkeypatch.delenv("RS_NO_TAIL")
+        be2.set_mode(be.mode())
+        luts = _dev(rng.integers(-2**31, 2**31, (7, ks.p.N)).astype(np.int32))
+        for tail in (5, cus + 3, 3 * cus + 1):
+            B = 8 * cus + tail
+            _, ct = _bits(ks, B, 900 + tail)
+            d = _dev(ct)
+            got, ref = be.bootstrap(d, mu), be2.bootstrap(d, mu)
+            assert torch.equal(got, ref), tail
+            assert torch.equal(be.bootstrap_lut(d, luts), be2.bootstrap_lut(d, luts)), tail
+            sample = np.r_[0:4, 8 * cus - 4:8 * cus + 4, B - 4:B]
+            assert np.array_equal(got.cpu().numpy()[sample], ctx.bootstrap_batch(ct[sample], mu)), tail
 
 
 def test_rccl_gather_world_size_one():
@@ -558,10 +553,17 @@ def test_sliced_keyswitch_two_step_equals_the_atomics_form_and_the_oracle(monkey
         be = redsec_amd.Backend(redsec_amd.params(set_name), device=0)
         be.load_synthetic_keys(seed)
         return be
-    be = backend()
-    monkeypatch.setenv("RS_KS_ATOMICS", "1")          # read once, in rs_create
-    be_atomics = backend()
-    monkeypatch.delenv("RS_KS_ATOMICS")
+    with contextlib.ExitStack() as stack:            # both contexts are closed also when an assertion fails
+        be = stack.enter_context(POOL.scratch(backend))
+        monkeypatch.setenv("RS_KS_ATOMICS", "1")          # read once, in rs_create
+        be_atomics = stack.enter_context(POOL.scratch(backend))
+        monkeypatch.delenv("RS_KS_ATOMICS")
+        _sliced_keyswitch_body(be, be_atomics, p, seed)
+
+
+def _sliced_keyswitch_body(be, be_atomics, p, seed):
+    import torch
+    W, N = p.n + 1, p.N
 
     class K:
         pass
@@ -578,4 +580,4 @@ def test_sliced_keyswitch_two_step_equals_the_atomics_form_and_the_oracle(monkey
         assert torch.equal(got, be_atomics.keyswitch(d)), B
         rows = np.unique(np.r_[0, B // 2, B - 1, rng.integers(0, B, 5)])
         assert np.array_equal(got.cpu().numpy()[rows], ctx.keyswitch(u[rows])), B
-    be.close(); be_atomics.close(); ctx.close()
+    ctx.close()

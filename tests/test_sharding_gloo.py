@@ -245,8 +245,9 @@ def _image_worker(rank, world, port, n_images, ret):
         def run_image(x):
             ran.append(int(x[0, 0]))
             return x * 3 - 2                                # stands in for a whole encrypted network
-        got, t_c, t_g = sharding.image_parallel(run_image, images, (10, 5))
-        ok = torch.equal(got, torch.stack([x * 3 - 2 for x in images]))
+        got, t_c, t_g = sharding.image_parallel(run_image, images, (10, 5), device="cpu")
+        want = torch.stack([x * 3 - 2 for x in images]) if images else torch.empty((0, 10, 5), dtype=torch.int32)
+        ok = torch.equal(got, want) and got.device.type == "cpu"
         ok = ok and ran == [7 * i + 1 for i in sharding.image_assignment(n_images, rank, world)] and t_c >= 0 and t_g >= 0
         flag = torch.tensor([1 if ok else 0])
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -256,7 +257,7 @@ def _image_worker(rank, world, port, n_images, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_images", [2, 5, 1])           # one each (configs[4]'s shape), a ragged batch, a rank without an image
+@pytest.mark.parametrize("n_images", [2, 5, 1, 0])        # one each (configs[4]'s shape), a ragged batch, a rank without an image, nobody has one
 def test_image_parallel_replicas_gloo(n_images):
     """BASELINE configs[4] on the CPU: image-parallel replicas over two gloo ranks, the logits gathered in image order."""
     assert sharding.image_assignment(8, 3, 8) == [3] and sharding.image_assignment(5, 1, 2) == [1, 3]
@@ -276,3 +277,7 @@ def test_image_parallel_without_a_process_group_is_the_plain_loop():
     images = [torch.full((10, 3), i, dtype=torch.int32) for i in range(3)]
     got, _, t_g = sharding.image_parallel(lambda x: x + 1, images, (10, 3))
     assert torch.equal(got, torch.stack(images) + 1) and t_g == 0.0
+    # an empty batch: an empty [0][classes][W] tensor on the named device, no collective (also with one rank and `force`)
+    for force in (False, True):
+        got, _, t_g = sharding.image_parallel(lambda x: x + 1, [], (10, 3), force=force, device="cpu")
+        assert got.shape == (0, 10, 3) and got.dtype == torch.int32 and got.device.type == "cpu" and t_g == 0.0
