@@ -20,7 +20,7 @@ EMU_LIB = os.path.join(HERE, "librs_emulate.so")
 
 HIP_SOURCES = ["rs_bootstrap.hip", "rs_general.hip", "rs_kernels.hip", "rs_api.cpp"]
 HIP_DEPS = HIP_SOURCES + ["rs_kernels.h", "rs_cohort.h", "rs_diag.h", "rs_lds_plan.h", "rs_ntt.h", "rs_fft.h", "rs_general.h", "rs_host.h", os.path.join(INCLUDE, "redsec_hip.h")]
-# Objects of the product library: (object name, source, extra flags). rs_bootstrap.hip is compiled twice (its RS_BS_PART
+# Objects of the product library: (object name, source, extra flags). rs_bootstrap.hip is compiled three times (its RS_BS_PART
 # switch): part 1 -- the FFT / exact-NTT blind-rotation kernels and the split duo form -- with LLVM's post-register-allocation
 # scheduler off: its in-block reordering of the hand-laid-out LDS / FP64 sequences costs these kernels 1-3 % (same-box A/B,
 # profiles/r03/y_ab_compiler_scheduling_*.txt: default-128 +1.3 %, REDsec set +0.9 %, sign1024x1 image 12.36 -> 12.11 ms);
@@ -31,6 +31,9 @@ HIP_DEPS = HIP_SOURCES + ["rs_kernels.h", "rs_cohort.h", "rs_diag.h", "rs_lds_pl
 HIP_OBJECTS = [
     ("rs_bootstrap_1", "rs_bootstrap.hip", ["-DRS_BS_PART=1", "-mllvm", "-enable-post-misched=0"]),
     ("rs_bootstrap_2", "rs_bootstrap.hip", ["-DRS_BS_PART=2", "-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]),
+    # part 4 -- blind_rotate_coop8_listed_kernel (round 6) with part 1's flags, in an object of its own: instantiated inside part 1
+    # it changed the instructions of 15 other kernels there (tools/codeobj_digest.py), the measured BASELINE-config forms among them
+    ("rs_bootstrap_4", "rs_bootstrap.hip", ["-DRS_BS_PART=4", "-mllvm", "-enable-post-misched=0"]),
     ("rs_general", "rs_general.hip", []),
     ("rs_kernels", "rs_kernels.hip", []),
     ("rs_api", "rs_api.cpp", []),

@@ -31,13 +31,15 @@
 #include "rs_lds_plan.h"
 #include "rs_ntt.h"
 
-// RS_BS_PART: redsec_amd/build.py compiles this file TWICE, because its kernels want different code-generation flags
+// RS_BS_PART: redsec_amd/build.py compiles this file THREE times, because its kernels want different code-generation flags
 // (profiles/r03/y_ab_compiler_scheduling_*.txt). Bit 1 = every launcher except the one of bit 2 (built with LLVM's post-RA
 // scheduler off: the FFT / exact-NTT kernels and the split duo form gain 1-3 % from it); bit 2 = launch_blind_rotate_split_wg
 // with the split cooperative and split lock-step kernels (built with the default pipeline: they lose 6 % / 0.7 % without that
-// pass). Kernels are templates, so each object holds only what its launchers name. Default 3: one object with everything.
+// pass); bit 4 = launch_coop8_listed with blind_rotate_coop8_listed_kernel (round 6; part 1's flags; apart so that part 1's
+// device code stays what it was, see there). Kernels are templates, so each object holds only what its launchers name.
+// Default 7: one object with everything.
 #ifndef RS_BS_PART
-#define RS_BS_PART 3
+#define RS_BS_PART 7
 #endif
 
 namespace rs {
@@ -1717,6 +1719,176 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_kernel(BlindRotateArgs
 }
 
 // -------------------------------------------------------------------------------------------------
+// The same form with a LISTED step (round 6), for the deals with at most one row per wave whose inverse waves carry no row
+// (coop8_listed: l < 4, default-128). There a step is a serial chain -- mask word -> rotated difference -> ONE row -> atomics ->
+// inverse -- and three of its links are shorter here:
+// * the CMUX steps that are not the identity are listed ONCE, in the prologue, in LDS (s_steps: (i << 16) | bara, compacted by
+//   wave ballots; n <= kCoop8MaxSteps, the launcher's condition for this kernel): a step reads its entry a whole step ahead
+//   instead of waiting ~400 cycles for a global load of the ciphertext word in front of its first instruction;
+// * the prepared rotated difference (X^bara - 1) * acc + gadget offset of BOTH components is built once per step by all 512
+//   threads (4 coefficients each) into s_d[2][N] behind the accumulator update, and the row waves read their 16 values from
+//   there (one more workgroup barrier: three per step); in the kernel above each wave of a component rebuilds all 1,024 of
+//   them (32 LDS reads + ~160 vector instructions per lane);
+// * a wave's key row is requested a phase early, behind barrier 1 of the step before: it travels while the two inverse waves
+//   work and the CU's vector-memory path is otherwise idle.
+// 196 default-128 ciphertexts: 2.65 -> 2.49 (list + shared difference) -> 2.21-2.23 ms (early request), same box
+// (profiles/r06/c_*). For l >= 4 (the REDsec set: five rows per SIMD) the same step was built and measured at +1 %
+// (2.42 against 2.40 ms) and stays with the kernel above: there the rows phase is bound by the SIMDs' instruction issue -- 5 rows
+// x ~2.2 k cycles, the throughput kernel's own cost per transform -- and what is taken out of the phases in front of it shows up
+// again as contention inside it (phase stamps: rotated difference 1.35-1.8 k -> 0.75 k, rows 8.6 / 9.7 k -> 9.3 / 10.9 k cycles);
+// an inverse wave that also carries rows cannot request early without standing ~2,000 cycles in the vector-memory issue queue in
+// front of its transform (3.1 k -> 5.1 k cycles, +8 %).
+// LDS: 104 KB as above + 8 KB rotated difference + 8 KB step list = 120 KB.
+// -------------------------------------------------------------------------------------------------
+template <class Xf>
+__global__ __launch_bounds__(512) void blind_rotate_coop8_listed_kernel(BlindRotateArgs a) {
+  using C = typename Xf::Cfg;
+  static_assert(Xf::kCertificate, "FFT policy only: the exact-NTT reduction schedule is validated for four partials");
+  if (recompute_not_needed(a)) return;
+  constexpr int G = kCoop8Waves, L = C::L, KPL = 2 * L;
+  constexpr int kInvA = coop8_inv_a(L), kInvB = coop8_inv_b(L);   // placement: rs_lds_plan.h (checked on the host)
+  static_assert(coop8_listed(L) && coop8_row_count(L, kInvA) == 0 && coop8_row_count(L, kInvB) == 0, "the early key request assumes inverse waves without rows");
+  __shared__ double s_tw[Xf::kTableDoubles + 1];
+  __shared__ double s_buf[G][kBufDoubles];
+  __shared__ double s_sum[2][kN];   // the two column sums, added up by LDS floating-point atomics (zero between steps)
+  __shared__ int32_t s_acc[2][kN];
+  __shared__ int32_t s_d[2][kN];                   // gadget_prepare((X^bara - 1) * acc) of the step about to run, both components
+  __shared__ uint32_t s_steps[kCoop8MaxSteps + 1];   // the steps with bara != 0, in order: (i << 16) | bara
+  __shared__ int s_step_count;
+  stage_tables(s_tw, a.tw, 64 * G, Xf::kTableDoubles);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const long ct = blockIdx.x;
+  const Field f = a.f;
+  double* buf = s_buf[wave];
+  for (int e = threadIdx.x; e < 2 * kN; e += 64 * G) (&s_sum[0][0])[e] = 0.0;
+  typename Xf::State tw;
+  Xf::init(tw, lane, s_tw, a.tw);
+  const int32_t* row0 = a.in0 + ct * a.W;
+  const int32_t* row1 = a.in1 ? a.in1 + ct * a.W : nullptr;
+  const int n = a.n;
+  // rows [first, first + cnt) of this wave's component (digit index q = first + rr, TGSW row comp * L + q)
+  const int comp = coop8_comp(L, wave), cnt = coop8_row_count(L, wave), first = coop8_row_first(L, wave);
+  [[maybe_unused]] const int r_first = cnt > 0 ? (int)(blockIdx.x % (unsigned)cnt) : 0;
+  double dev = 0.0;
+  RS_C8L_STAMP_DECL;   // -DRS_DIAG=256 (tools/stamp_coop8.py): 0 step entry + shared rotated difference, 1 its barrier, 2 rows (forward +
+                      // multiply-accumulate), 3 atomics issued, 4 barrier 1, 5 inverse + accumulator update, 6 barrier 2, 7 prologue / extract
+  auto word = [&](int i) -> int32_t {
+    uint32_t v = (uint32_t)a.c0 * (uint32_t)row0[i];
+    if (row1) v += (uint32_t)a.c1 * (uint32_t)row1[i];
+    return (int32_t)v;
+  };
+  if (wave < 2) {
+    const int32_t barb = modswitch_2N((int32_t)((uint32_t)word(n) + (uint32_t)a.bconst));
+    const int rot = 2 * kN - barb;
+#pragma unroll
+    for (int r = 0; r < kRegs; ++r) {
+      const int j = lane + 64 * r;
+      s_acc[wave][j] = wave == 0 ? 0 : test_vector(a, ct, j, rot);
+    }
+  } else if (wave == 2) {
+    // the step list: 64 mask words at a time, the non-zero ones compacted in order behind those of the chunks before
+    int count = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int i = i0 + lane;
+      const int32_t bara = i < n ? modswitch_2N(word(i)) : 0;
+      const unsigned long long live = __ballot(bara != 0);
+      if (bara != 0) s_steps[count + __popcll(live & ((1ull << lane) - 1ull))] = ((uint32_t)i << 16) | (uint32_t)bara;
+      count += __popcll(live);
+    }
+    if (lane == 0) { s_steps[count] = 0u; s_step_count = count; }
+  }
+  __syncthreads();
+  constexpr uint32_t offset = gadget_offset<C>();
+  const int trips = __builtin_amdgcn_readfirstlane(s_step_count);
+  uint32_t entry = trips > 0 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_steps[0]) : 0u;
+  double2 w0[8], w1[8];
+  auto request_row = [&](int step_i, int q) {
+    const double* bk_i = a.bk_x + (size_t)diag::key_step(step_i) * KPL * 2 * kN;
+    const double2* bp0 = reinterpret_cast<const double2*>(bk_i + (size_t)((comp * L + q) * 2) * kN);
+    const double2* bp1 = bp0 + kN / 2;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) { w0[v] = bp0[v * 64 + lane]; w1[v] = bp1[v * 64 + lane]; }
+  };
+  if (cnt > 0 && trips > 0) request_row((int)(entry >> 16), first + r_first);
+  RS_C8L_STAMP(7);
+  for (int k = 0; k < trips; ++k) {
+    const int i = (int)(entry >> 16), bara = (int)(entry & 0xffffu);
+    const uint32_t entry_next = s_steps[k + 1];   // requested a whole step ahead (the entry behind the last one exists: 0)
+    // the prepared rotated difference of both components, 4 coefficients per thread (waves 0-3: component 0, waves 4-7: 1)
+    {
+      const int c = coop8_diff_comp(wave), j0 = (int)(threadIdx.x & 255);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) s_d[c][j0 + 256 * m] = gadget_prepare<C>(rotated_diff(s_acc[c], j0 + 256 * m, bara));
+    }
+    RS_C8L_STAMP(0);
+    __syncthreads();   // s_d complete; the accumulator is not read again before its update
+    RS_C8L_STAMP(1);
+    double s0[kRegs], s1[kRegs];
+#pragma unroll
+    for (int u = 0; u < kRegs; ++u) { s0[u] = 0.0; s1[u] = 0.0; }
+    if (cnt > 0) {
+      int32_t d[kRegs];
+#pragma unroll
+      for (int r = 0; r < kRegs; ++r) d[r] = s_d[comp][lane + 64 * r];
+      int r_run = r_first;   // rr = 0 is row blockIdx.x mod cnt of the wave's share in every step (per-workgroup row order, as in the four-wave form)
+#pragma unroll 1
+      for (int rr = 0; rr < cnt; ++rr) {
+        const int q = first + r_run;
+        r_run = r_run + 1 == cnt ? 0 : r_run + 1;
+        if (rr > 0) request_row(i, q);   // the first row's key is already on its way
+        double x[kRegs];
+        Xf::fwd_digits(lane, x, d, q, offset, tw, buf, f);
+        Xf::mac8(s0, s1, x, w0, w1, f);
+      }
+      RS_C8L_STAMP(2);
+    }
+    // every wave adds its two partial sums into the column sums with ds_add_f64 (no return value: 32 instructions that overlap
+    // the other waves' transforms); the order of the floating-point additions is free -- the sums are rounded to the exact
+    // integers afterwards, with the certificate watching the distance as everywhere
+    if (cnt > 0) {
+#pragma unroll
+      for (int u = 0; u < kRegs; ++u) { unsafeAtomicAdd(&s_sum[0][u * 64 + lane], s0[u]); unsafeAtomicAdd(&s_sum[1][u * 64 + lane], s1[u]); }
+    }
+    RS_C8L_STAMP(3);
+    __syncthreads();   // sums complete; every row wave has finished reading the rotated difference
+    RS_C8L_STAMP(4);
+    entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)entry_next);
+    if (cnt > 0 && k + 1 < trips) request_row((int)(entry >> 16), first + r_first);   // the next step's row, while the inverse waves work
+    if (wave == kInvA || wave == kInvB) {
+      double* sum = s_sum[wave == kInvA ? 0 : 1];
+      double x[kRegs];
+#pragma unroll
+      for (int u = 0; u < kRegs; ++u) x[u] = sum[u * 64 + lane];
+#pragma unroll
+      for (int u = 0; u < kRegs; ++u) sum[u * 64 + lane] = 0.0;   // for the next step (same lane, same address: in order)
+      Xf::inverse(lane, x, tw, buf, f);
+      int32_t* acc = s_acc[wave == kInvA ? 0 : 1];
+#pragma unroll
+      for (int r = 0; r < kRegs; ++r) {
+        const int j = lane + 64 * r;
+        acc[j] = (int32_t)((uint32_t)acc[j] + (uint32_t)Xf::to_torus(x[r], dev));
+      }
+    }
+    RS_C8L_STAMP(5);
+    __syncthreads();   // accumulator updated, sums zero
+    RS_C8L_STAMP(6);
+  }
+  int32_t* out = a.u_out + ct * (kN + 1);
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < kRegs; ++r) {
+      const int j = lane + 64 * r;
+      out[j] = (j == 0) ? s_acc[0][0] : (int32_t)(0u - (uint32_t)s_acc[0][kN - j]);
+    }
+    if (lane == 0) out[kN] = s_acc[1][0];
+  }
+  RS_C8L_STAMP(7);
+  RS_C8L_STAMP_FLUSH(wave);
+  if (wave == kInvA || wave == kInvB) publish_certificate(dev, a.dev_flag, lane);
+}
+
+// -------------------------------------------------------------------------------------------------
 // Debug tap: out = a_small * b_torus (negacyclic, mod 2^32) through forward/pointwise/inverse.
 // -------------------------------------------------------------------------------------------------
 template <class Xf, int WPB>
@@ -1797,6 +1969,8 @@ static hipError_t cohort_setup(BlindRotateArgs& w, int* table, long step_bytes, 
 }
 #if RS_BS_PART & 1
 
+hipError_t launch_coop8_listed(int cfg, const BlindRotateArgs& a, hipStream_t st);   // part 4
+
 template <class Xf>
 static hipError_t launch_br_xf(const BlindRotateArgs& a_in, int wpb, long num_cus, bool coop4, const LaunchOpts& o, hipStream_t st, LaunchInfo* info) {
   int* const cohort_table = a_in.progress;   // the caller's offer; only cohort_setup puts it back into a launch's arguments
@@ -1814,6 +1988,12 @@ static hipError_t launch_br_xf(const BlindRotateArgs& a_in, int wpb, long num_cu
     if constexpr (Xf::kWorkgroupForm) {
       // at most one ciphertext per CU: eight waves share it (two per SIMD), see blind_rotate_coop8_kernel
       if (!o.no_coop8 && a.B <= num_cus) {
+        if constexpr (coop8_listed(Xf::Cfg::L)) {   // its own object (RS_BS_PART bit 4): see there
+          if (a.n <= kCoop8MaxSteps) {
+            if (hipError_t e = launch_coop8_listed(std::is_same_v<typename Xf::Cfg, CfgDefault128> ? 0 : 1, a, st); e != hipSuccess) return e;
+            return done(kFormCoop8, 8, 1);
+          }
+        }
         hipLaunchKernelGGL((blind_rotate_coop8_kernel<Xf>), dim3((unsigned)a.B), dim3(512), 0, st, a);
         return done(kFormCoop8, 8, 1);
       }
@@ -1915,6 +2095,22 @@ hipError_t launch_split_duos(int cfg, const BlindRotateArgs& a, long grid, hipSt
   return hipGetLastError();
 }
 #endif  // RS_BS_PART & 1
+
+#if RS_BS_PART & 4
+// blind_rotate_coop8_listed_kernel lives in an object of its own (built with part 1's flags). Instantiated beside the other FFT
+// kernels it changed THEIR code -- 15 of part 1's device functions came out a few instructions different, the REDsec set's
+// coop8 kernel among them (tools/codeobj_digest.py), with the source of none of them touched -- and the kernels of the BASELINE
+// configurations are to stay the instructions that were measured. cfg: 0 default-128, 1 the REDsec set (no listed deal).
+hipError_t launch_coop8_listed(int cfg, const BlindRotateArgs& a, hipStream_t st) {
+  if constexpr (coop8_listed(CfgDefault128::L)) {
+    if (cfg == 0) {
+      hipLaunchKernelGGL((blind_rotate_coop8_listed_kernel<XfFft<CfgDefault128>>), dim3((unsigned)a.B), dim3(512), 0, st, a);
+      return hipGetLastError();
+    }
+  }
+  return hipErrorInvalidValue;
+}
+#endif  // RS_BS_PART & 4
 
 #if RS_BS_PART & 2
 hipError_t launch_split_duos(int cfg, const BlindRotateArgs& a, long grid, hipStream_t st);

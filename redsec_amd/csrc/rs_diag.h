@@ -7,6 +7,7 @@
 //   2             phase stamps in blind_rotate_wgs_kernel (the array then lives in part 2 of rs_bootstrap.hip, RS_BS_PART)
 //   4             phase stamps in blind_rotate_duo_kernel (tools/stamp_coop8.py duo)
 //   8             phase stamps in blind_rotate_coop8_kernel (tools/stamp_coop8.py)
+//   256           phase stamps in blind_rotate_coop8_listed_kernel (tools/stamp_coop8.py; the array then lives in part 4)
 //   16            NO-KEY TIMING PROBE, RESULTS ARE WRONG: every CMUX step reads the key rows of step 0, which stay in the L2s --
 //                 bounds what key streaming can cost a kernel (split lock-step, cooperative, coop8 and general-ring kernels);
 //                 rs_api.cpp then also switches the enforced split certificate off (the sums are garbage by construction)
@@ -102,9 +103,20 @@ namespace rs { extern __device__ unsigned long long g_rs_stamps[256 * 8 * diag::
 #define RS_C8_STAMP(k) ((void)0)
 #define RS_C8_STAMP_FLUSH(wave) ((void)0)
 #endif
-// which object of rs_bootstrap.hip (RS_BS_PART) owns the stamp array: part 2 when the split lock-step kernel is the stamped one
+#if RS_STAMPS_ON(256)
+#define RS_C8L_STAMP_DECL RS_STAMP_DECL_
+#define RS_C8L_STAMP(k) RS_STAMP_(k)
+#define RS_C8L_STAMP_FLUSH(wave) RS_STAMP_FLUSH_(wave)
+#else
+#define RS_C8L_STAMP_DECL ((void)0)
+#define RS_C8L_STAMP(k) ((void)0)
+#define RS_C8L_STAMP_FLUSH(wave) ((void)0)
+#endif
+// which object of rs_bootstrap.hip (RS_BS_PART) owns the stamp array: the part that holds the stamped kernel (one bit per build)
 #if RS_STAMPS_ON(2)
 #define RS_DIAG_STAMP_PART 2
+#elif RS_STAMPS_ON(256)
+#define RS_DIAG_STAMP_PART 4
 #elif RS_STAMPS_ON(1 | 4 | 8)
 #define RS_DIAG_STAMP_PART 1
 #else

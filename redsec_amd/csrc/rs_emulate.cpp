@@ -591,15 +591,38 @@ long model_coop(int G, int broken) {
   }
   return m.conflicts();
 }
-// blind_rotate_coop8_kernel: every wave adds its partials into s_sum[2][N] by LDS f64 atomics; after the
-// barrier the two inverse waves read their column's sum, clear it for the next step, transform, update the accumulator
+// blind_rotate_coop8_kernel. Round-5 step (l >= 4), two epochs: (1) the row waves read their component of the accumulator,
+// transform, and add their partials into s_sum[2][N] by LDS f64 atomics; (2) the two inverse waves read their column's sum,
+// clear it for the next step, transform, update the accumulator. LISTED step (coop8_listed: l < 4), three epochs: all 512
+// threads first build the prepared rotated difference s_d[2][N] from the accumulator (thread t: coefficients (t & 255) + 256 m
+// of component coop8_diff_comp(wave)), and the row waves read s_d instead of the accumulator; the step list s_steps is written
+// once in the prologue (its own epoch) and only read afterwards.
 long model_coop8_atomics(int L, int broken) {
   LdsModel m;
+  const bool listed = rs::coop8_listed(L);
   auto sum = [&](int col) { return LdsModel::PART + col * kPolyBytes; };
+  auto diff = [&](int c) { return LdsModel::KEY + c * kAccBytes; };     // s_d (the form has no key buffer: the window is free)
+  const long steps_lo = LdsModel::KEY + 0x100000L, steps_bytes = 4L * (rs::kCoop8MaxSteps + 1);
+  if (listed) m.wr(2, steps_lo, steps_bytes);                            // prologue: wave 2 lists the steps
+  for (int w = 0; w < 2; ++w) m.wr(w, LdsModel::ACC + w * kAccBytes, kAccBytes);
+  m.barrier();
   for (int step = 0; step < 2; ++step) {
+    if (listed) {
+      for (int w = 0; w < rs::kCoop8Waves; ++w) {
+        const int c = rs::coop8_diff_comp(w);
+        m.rd(w, steps_lo, steps_bytes);
+        m.rd(w, LdsModel::ACC + c * kAccBytes, kAccBytes);               // rotated reads reach the whole component
+        for (int q = 0; q < 4; ++q) m.wr(w, diff(c) + 4L * (256 * q + 64 * (w & 3)), 4L * 64);   // its 4 x 64 coefficients
+      }
+      if (broken != 3) m.barrier();
+    }
+    // perturbation 1, listed step: the inverse waves clear their sums only here, beside the next step's atomics (anywhere up to
+    // the barrier above would be in time: nobody touches the sums while the rotated difference is built)
+    if (listed && broken == 1 && step > 0) for (int col = 0; col < 2; ++col) m.wr(col == 0 ? rs::coop8_inv_a(L) : rs::coop8_inv_b(L), sum(col), kPolyBytes);
     for (int w = 0; w < rs::kCoop8Waves; ++w) {
       if (rs::coop8_row_count(L, w) == 0) continue;
-      m.rd(w, LdsModel::ACC + rs::coop8_comp(L, w) * kAccBytes, kAccBytes);
+      if (listed) m.rd(w, diff(rs::coop8_comp(L, w)), kAccBytes);
+      else m.rd(w, LdsModel::ACC + rs::coop8_comp(L, w) * kAccBytes, kAccBytes);
       m.rw(w, buf_of(w), kBufBytes);
       for (int col = 0; col < 2; ++col) m.atomic(w, sum(col), kPolyBytes);
     }
@@ -607,12 +630,13 @@ long model_coop8_atomics(int L, int broken) {
     for (int col = 0; col < 2; ++col) {
       const int w = col == 0 ? rs::coop8_inv_a(L) : rs::coop8_inv_b(L);
       m.rd(w, sum(col), kPolyBytes);
-      if (broken != 1) m.wr(w, sum(col), kPolyBytes);     // cleared here, before the barrier ...
+      if (broken != 1) m.wr(w, sum(col), kPolyBytes);     // cleared here, in the inverse waves' own epoch ...
       m.rw(w, buf_of(w), kBufBytes);
       m.rw(w, LdsModel::ACC + col * kAccBytes, kAccBytes);
     }
     if (broken != 2) m.barrier();
-    if (broken == 1) for (int col = 0; col < 2; ++col) m.wr(col == 0 ? rs::coop8_inv_a(L) : rs::coop8_inv_b(L), sum(col), kPolyBytes);   // ... not behind it
+    // ... perturbation 1, round-5 step: not behind the barrier, where the next step's atomics already run
+    if (!listed && broken == 1) for (int col = 0; col < 2; ++col) m.wr(col == 0 ? rs::coop8_inv_a(L) : rs::coop8_inv_b(L), sum(col), kPolyBytes);
   }
   return m.conflicts();
 }

@@ -21,11 +21,19 @@ namespace rs {
 // Components alternate (wave & 1), j = wave >> 1 is the wave's place among the four of its component: j = 0, 1 are the older
 // waves of SIMDs 0/1 and 2/3, j = 2, 3 the younger ones.
 constexpr int kCoop8Waves = 8;
+// The LISTED step (round 6; the deals with at most one row per wave, whose inverse waves carry no row: l < 4): the kernel lists
+// the CMUX steps that are not the identity in LDS once, in its prologue ((i << 16) | bara) -- LWE dimensions up to
+// kCoop8MaxSteps, the launcher's condition for the form (larger ones run the four- / two-wave forms) -- and builds the prepared
+// rotated difference of a step with all 512 threads: thread t takes coefficients (t & 255) + 256 m, m < 4, of component t >> 8
+// (waves 0-3: component 0, waves 4-7: component 1), whichever row the wave then transforms.
+constexpr int kCoop8MaxSteps = 2048;
+RS_HD constexpr int coop8_diff_comp(int wave) { return wave >> 2; }
 // l >= 4 (the REDsec set: l = 10): the deal by wave age described above. l < 4 (default-128: l = 3, six rows for eight waves)
 // keeps the deal of the kernel's first form -- waves 0-3 component 0, waves 4-7 component 1, the extra rows to the first waves of
 // component 0 and the last of component 1, inverse transforms on the two waves without rows (3 and 4): measured 2.66 ms against
 // 2.73 ms for the deal by age at 196 default-128 ciphertexts (profiles/r04/aw_*).
 RS_HD constexpr bool coop8_by_age(int L) { return L >= 4; }
+RS_HD constexpr bool coop8_listed(int L) { return !coop8_by_age(L); }
 RS_HD constexpr int coop8_inv_a(int L) { return coop8_by_age(L) ? 6 : 3; }   // inverts column 0: a wave with the fewest rows
 RS_HD constexpr int coop8_inv_b(int L) { return coop8_by_age(L) ? 7 : 4; }   // inverts column 1: likewise, on another SIMD
 RS_HD constexpr int coop8_comp(int L, int wave) { return coop8_by_age(L) ? (wave & 1) : (wave >> 2); }

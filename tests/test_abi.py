@@ -134,6 +134,7 @@ def test_kernel_sources_carry_no_experiment_switches():
     ("rs_bootstrap.hip", ["-DRS_DIAG=253"]),                       # stamps of the three part-1 kernels + every timing probe
     ("rs_bootstrap.hip", ["-DRS_DIAG=2", "-DRS_BS_PART=2"]),      # stamps of the split lock-step kernel: the array lives in part 2
     ("rs_bootstrap.hip", ["-DRS_DIAG=2", "-DRS_BS_PART=1"]),      # ... and part 1 of that build declares it without defining it
+    ("rs_bootstrap.hip", ["-DRS_DIAG=256", "-DRS_BS_PART=4"]),    # stamps of the listed coop8 kernel: the array lives in part 4
     ("rs_general.hip", ["-DRS_DIAG=144"]),                         # no-key and half-key probes of the general rings
     ("rs_api.cpp", ["-DRS_DIAG=48"]),                              # the probes' switch that turns the exactness gates off
 ])

@@ -252,11 +252,12 @@ def test_general_path_digits_equal_tfhe_decomposition(l, bgbit):
 
 # form ids of rs_emu_lds_protocol_conflicts (2 and 3 were coop8's s_part exchange, removed with the switch that selected it)
 LDS_FORMS = {0: "coop<2>", 1: "coop<4>", 4: "coops<2>", 5: "coops<4>", 6: "duo", 7: "duos", 8: "wgs<8>", 9: "wgs<4>", 10: "wg<8>",
-             11: "coop8: sums by LDS atomics (l = 10)", 12: "coop8: sums by LDS atomics (l = 3)",
+             11: "coop8: sums by LDS atomics (l = 10)", 12: "coop8, listed step: shared rotated difference, sums by LDS atomics (l = 3)",
              13: "keyswitch, one lookup per digit (rows stored behind the lookups)", 14: "keyswitch, combined digits (base rows -> sums -> lookups)"}
 # perturbations every form's model knows (rs_emulate.cpp): 1 = one placement / slot-count / hold decision changed the way a
-# plausible edit would change it, 2 = one workgroup barrier dropped, 3 (duo only) = the next quad requested before the swap
-LDS_BROKEN = {0: (1, 2), 1: (1, 2), 4: (1, 2), 5: (1, 2), 6: (1, 2, 3), 7: (1, 2), 8: (1,), 9: (1,), 10: (2,), 11: (1, 2), 12: (1, 2), 13: (1, 2), 14: (1, 2)}
+# plausible edit would change it, 2 = one workgroup barrier dropped, 3 = (duo) the next quad requested before the swap / (coop8, listed step) the
+# barrier between building the shared rotated difference and the rows that read it dropped
+LDS_BROKEN = {0: (1, 2), 1: (1, 2), 4: (1, 2), 5: (1, 2), 6: (1, 2, 3), 7: (1, 2), 8: (1,), 9: (1,), 10: (2,), 11: (1, 2), 12: (1, 2, 3), 13: (1, 2), 14: (1, 2)}
 
 
 @pytest.mark.parametrize("form", sorted(LDS_FORMS), ids=[LDS_FORMS[k] for k in sorted(LDS_FORMS)])

@@ -46,6 +46,7 @@ BUDGETS = [
     (r"23blind_rotate_duo_kernel", "duo kernel (80 B with the last stage group's twiddles kept in registers: all outside the CMUX loop)", 256, 96, 163840),
     (r"24blind_rotate_duos_kernel", "split duo kernel", 256, 48, 163840),
     (r"25blind_rotate_coop8_kernel", "coop8: eight waves of one ciphertext", 256, 16, 163840),
+    (r"32blind_rotate_coop8_listed_kernel", "coop8 with the listed step (l < 4): a key row stays in registers across two barriers -- no scratch", 256, 0, 163840),
     (r"19blind_rotate_kernelINS_5XfNtt.*Li8EEEv", "exact-NTT per-wave kernel: 8 waves fill the LDS", 256, 128, 163840),
     (r"23gen_blind_rotate_kernelILi1[0-3]E", "general ring kernels: pinned to two waves per SIMD", 256, 96, 163840),
     (r"27keyswitch_tiled_comb_kernel", "keyswitch, combined digits: two workgroups per CU", 240, 0, 81920),

@@ -19,6 +19,7 @@ B="$SRC/redsec_amd/csrc"
 if grep -q RS_BS_PART "$B/rs_bootstrap.hip"; then
   cc -DRS_BS_PART=1 $BS_FLAGS "$@" -c "$B/rs_bootstrap.hip" -o "$OBJ/rs_bootstrap_1.o"
   cc -DRS_BS_PART=2 $BS2_FLAGS "$@" -c "$B/rs_bootstrap.hip" -o "$OBJ/rs_bootstrap_2.o"
+  if grep -q "RS_BS_PART & 4" "$B/rs_bootstrap.hip"; then cc -DRS_BS_PART=4 $BS_FLAGS "$@" -c "$B/rs_bootstrap.hip" -o "$OBJ/rs_bootstrap_4.o"; fi
 else   # an older source tree: one object
   cc $BS_FLAGS "$@" -c "$B/rs_bootstrap.hip" -o "$OBJ/rs_bootstrap.o"
 fi
