@@ -26,3 +26,8 @@ if [ -f variants/lib_stamps.so ]; then
   REDSEC_HIP_LIB=$PWD/variants/lib_stamps.so python tools/stamp_profile.py redsec_small_v2 16384 > $OUT/${P}_stamps_wg_redsec.json 2>/dev/null
 fi
 echo "round-3 additions done"
+# round 6 additions: PCIe-inclusive rate of the host-pointer calls, the latency forms on both shipped sets
+python tools/host_api_rate.py > $OUT/${P}_host_api_rate.txt 2>&1; tail -2 $OUT/${P}_host_api_rate.txt
+python tools/small_batch_probe.py 196 1024 --reps 9 > $OUT/${P}_small_batches_redsec_set.txt 2>/dev/null; cat $OUT/${P}_small_batches_redsec_set.txt
+python tools/small_batch_probe.py 196 256 --reps 9 --params default128 > $OUT/${P}_small_batches_default128.txt 2>/dev/null; cat $OUT/${P}_small_batches_default128.txt
+echo "round-6 additions done"
