@@ -789,7 +789,7 @@ def main():
         # this is READ FROM THE COMMITTED PROFILE of the same command (tools/pmc_traffic.py), and labelled as such
         traffic, traffic_src = None, None
         kernel_name = {"workgroup": "blind_rotate_wg_kernel", "duo": "blind_rotate_duo_kernel", "per_wave": "blind_rotate_kernel",
-                       "coop2": "blind_rotate_coop_kernel", "coop4": "blind_rotate_coop_kernel", "coop8": "blind_rotate_coop8_kernel",
+                       "coop2": "blind_rotate_coop_kernel", "coop4": "blind_rotate_coop_kernel", "coop8": "blind_rotate_coop8_kernel", "coop8_listed": "blind_rotate_coop8_listed_kernel",
                        "general": "gen_blind_rotate_kernel", "split_workgroup": "blind_rotate_wgs_kernel",
                        "split_coop": "blind_rotate_coops_kernel", "split_duo": "blind_rotate_duos_kernel"}[launch["form"]]
         under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)

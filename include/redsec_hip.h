@@ -267,7 +267,8 @@ int rs_last_kernel_ms_stream(rs_ctx* ctx, void* stream, float* blind_rotate_ms, 
 /* Facts used by bench.py's roofline accounting. rs_last_launch: what the last blind rotation on `stream`
  * actually ran -- form 0 per-wave, 1 lock-step workgroups, 2 duo, 3 / 4 cooperative (2 / 4 waves per
  * ciphertext), 5 general (one workgroup of N/16 threads per ciphertext), 6 lock-step workgroups on the split key (8 or 4 waves),
- * 7 cooperative on the split key (2 / 4 waves per ciphertext) -- its waves per workgroup, and `resident` = ciphertexts sharing one sweep of the key (R of the
+ * 7 cooperative on the split key (2 / 4 waves per ciphertext), 8 duo on the split key, 9 cooperative with 8 waves per ciphertext,
+ * 10 the same with the listed step (gadgets with l < 4) -- its waves per workgroup, and `resident` = ciphertexts sharing one sweep of the key (R of the
  * algorithmic-bytes formula). rs_info's waves_per_block is that of the default stream's last launch. */
 int rs_last_launch(rs_ctx* ctx, void* stream, int32_t* form, int32_t* waves_per_block, int64_t* resident);
 int rs_info(rs_ctx* ctx, int64_t* bk_device_bytes, int64_t* ksk_device_bytes, int32_t* waves_per_block,

@@ -422,7 +422,7 @@ class Backend:
         """(form, waves per workgroup, ciphertexts per key sweep) of the last blind rotation on the current stream."""
         f, w, r = C.c_int32(), C.c_int32(), C.c_int64()
         _check(self.L, self.L.rs_last_launch(self.h, self._stream(), C.byref(f), C.byref(w), C.byref(r)))
-        return {"form": ["per_wave", "workgroup", "duo", "coop2", "coop4", "general", "split_workgroup", "split_coop", "split_duo", "coop8"][f.value], "waves_per_block": w.value, "resident": r.value}
+        return {"form": ["per_wave", "workgroup", "duo", "coop2", "coop4", "general", "split_workgroup", "split_coop", "split_duo", "coop8", "coop8_listed"][f.value], "waves_per_block": w.value, "resident": r.value}
 
     def fp64_rate(self):
         """FP64 FMA lane-operations per second this device sustains right now (box calibration, see include/redsec_hip.h)."""

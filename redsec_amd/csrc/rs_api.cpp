@@ -492,7 +492,7 @@ int rs_create(rs_ctx** out, const rs_params* p, int device) {
   if (const char* v = getenv("REDSEC_SPLIT_CERT_LIMIT")) { const double x = atof(v); if (x > 0.0 && x < 0.25) c->split_cert_limit = x; }   // test hook: can only tighten
   c->opts.no_coop = env_on("RS_NO_COOP"); c->opts.no_wg = env_on("RS_NO_WG"); c->opts.no_duo = env_on("RS_NO_DUO");
   c->opts.no_persist = env_on("RS_NO_PERSIST"); c->opts.no_conv_tiled = env_on("RS_NO_CONV_TILED");
-  c->opts.no_wg4 = env_on("RS_NO_WG4"); c->opts.no_tail = env_on("RS_NO_TAIL"); c->opts.no_coop8 = env_on("RS_NO_COOP8"); c->opts.ks_atomics = env_on("RS_KS_ATOMICS"); c->opts.force_host_staged = env_on("RS_FORCE_HOST_STAGED"); c->opts.no_cohort = env_on("RS_NO_COHORT");
+  c->opts.no_wg4 = env_on("RS_NO_WG4"); c->opts.no_tail = env_on("RS_NO_TAIL"); c->opts.no_coop8 = env_on("RS_NO_COOP8"); c->opts.no_coop8_listed = env_on("RS_NO_COOP8_LISTED"); c->opts.ks_atomics = env_on("RS_KS_ATOMICS"); c->opts.force_host_staged = env_on("RS_FORCE_HOST_STAGED"); c->opts.no_cohort = env_on("RS_NO_COHORT");
   Lane* ln = nullptr;
   if (lane_of(c, nullptr, &ln) != RS_OK) { destroy_ctx(c); return RS_ERR_HIP; }   // the default stream's lane
   *out = c;

@@ -1989,9 +1989,9 @@ static hipError_t launch_br_xf(const BlindRotateArgs& a_in, int wpb, long num_cu
       // at most one ciphertext per CU: eight waves share it (two per SIMD), see blind_rotate_coop8_kernel
       if (!o.no_coop8 && a.B <= num_cus) {
         if constexpr (coop8_listed(Xf::Cfg::L)) {   // its own object (RS_BS_PART bit 4): see there
-          if (a.n <= kCoop8MaxSteps) {
+          if (!o.no_coop8_listed && a.n <= kCoop8MaxSteps) {
             if (hipError_t e = launch_coop8_listed(std::is_same_v<typename Xf::Cfg, CfgDefault128> ? 0 : 1, a, st); e != hipSuccess) return e;
-            return done(kFormCoop8, 8, 1);
+            return done(kFormCoop8Listed, 8, 1);
           }
         }
         hipLaunchKernelGGL((blind_rotate_coop8_kernel<Xf>), dim3((unsigned)a.B), dim3(512), 0, st, a);

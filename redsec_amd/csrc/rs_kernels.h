@@ -48,11 +48,11 @@ constexpr int kCohortSlots = 64;   // workgroups per XCD the table has room for 
 
 // Launch policy switches, read from the environment ONCE at rs_create (A/B experiments only).
 struct LaunchOpts {
-  bool no_coop = false, no_wg = false, no_duo = false, no_persist = false, no_conv_tiled = false, no_wg4 = false, no_tail = false, no_coop8 = false, ks_atomics = false, force_host_staged = false, no_cohort = false;
+  bool no_coop = false, no_wg = false, no_duo = false, no_persist = false, no_conv_tiled = false, no_wg4 = false, no_tail = false, no_coop8 = false, no_coop8_listed = false, ks_atomics = false, force_host_staged = false, no_cohort = false;
 };
 // What a blind-rotate launch actually ran: kernel form and how many ciphertexts share one sweep of the key
 // from L2/HBM (R of SURVEY.md section 8d).
-enum { kFormPerWave = 0, kFormWorkgroup = 1, kFormDuo = 2, kFormCoop2 = 3, kFormCoop4 = 4, kFormGeneral = 5, kFormSplitWorkgroup = 6, kFormSplitCoop = 7, kFormSplitDuo = 8, kFormCoop8 = 9 };
+enum { kFormPerWave = 0, kFormWorkgroup = 1, kFormDuo = 2, kFormCoop2 = 3, kFormCoop4 = 4, kFormGeneral = 5, kFormSplitWorkgroup = 6, kFormSplitCoop = 7, kFormSplitDuo = 8, kFormCoop8 = 9, kFormCoop8Listed = 10 };
 struct LaunchInfo { int form = -1; int waves_per_block = 0; long resident = 0; };
 
 struct KeyswitchArgs {

@@ -13,7 +13,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-EXPECTED_FORMS = {"fft/coop8", "fft/coop2", "fft/duo", "fft/workgroup", "exact/per_wave", "exact/coop2", "exact/coop4",
+EXPECTED_FORMS = {"fft/coop8", "fft/coop8_listed", "fft/coop2", "fft/duo", "fft/workgroup", "exact/per_wave", "exact/coop2", "exact/coop4",
                   "split/split_coop", "split/split_duo", "split/split_workgroup"}
 
 

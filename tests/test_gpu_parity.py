@@ -302,6 +302,54 @@ def test_workgroup_kernel_ragged_groups_and_identity_steps(which, fix, size, req
     assert np.array_equal(got.cpu().numpy()[sample], ctx.bootstrap_batch(ct[sample], mu))
 
 
+@pytest.mark.parametrize("fix", ["toy_default", "full_default"])
+def test_coop8_listed_step_equals_the_round5_kernel_and_the_oracle(fix, request, monkeypatch):
+    """blind_rotate_coop8_listed_kernel (gadgets with l < 4, B <= #CUs; round 6: the CMUX steps listed once in LDS, the rotated
+    difference built once per step by all 512 threads, key rows requested a phase early) against blind_rotate_coop8_kernel
+    (RS_NO_COOP8_LISTED=1: the form every earlier round measured) on WHOLE batches word for word -- gates, a bootstrap whose test
+    polynomial depends on the ciphertext's index, batches of 1, a few and #CUs ciphertexts, ciphertexts with identity steps at
+    the front, in the middle, at the end, everywhere -- and against the oracle on sampled rows (tfhe_blindRotate_FFT skips
+    bara = 0 as the step list does)."""
+    import torch
+    ks, ctx = request.getfixturevalue(fix)
+    be = request.getfixturevalue("be_" + fix)
+    if be.mode() != "fft":
+        pytest.skip("the listed step is a form of the FFT mode")
+    cus = be.info()["num_cus"]
+    n = ks.p.n
+    mu = ol.to_torus(1, 8)
+    rng = np.random.default_rng(77)
+    monkeypatch.setenv("RS_NO_COOP8_LISTED", "1")          # read once, in rs_create
+    with _scratch(ks, "default128") as old:
+        monkeypatch.delenv("RS_NO_COOP8_LISTED")
+        old.set_mode("fft")
+        luts = _dev(rng.integers(-2**31, 2**31, (5, ks.p.N)).astype(np.int32))
+        for B in (1, 9, cus):
+            _, ca = _bits(ks, B, 500 + B)
+            _, cb = _bits(ks, B, 600 + B)
+            ca = ca.copy()
+            ca[0, : n // 3] = 0                  # leading identity steps
+            if B > 4:
+                ca[1, n // 3: 2 * n // 3] = 0    # in the middle
+                ca[2, -1 - n // 4:-1] = 0        # trailing (the b word stays)
+                ca[3, 1:n:2] = 0                 # every other one
+                ca[4, :n] = 0                    # the whole blind rotation is the identity: an empty step list
+            da, db = _dev(ca), _dev(cb)
+            got = be.bootstrap(da, mu)
+            assert be.last_launch() == {"form": "coop8_listed", "waves_per_block": 8, "resident": 1}
+            ref = old.bootstrap(da, mu)
+            assert old.last_launch()["form"] == "coop8"
+            assert torch.equal(got, ref), B
+            assert torch.equal(be.gate("XNOR", da, db), old.gate("XNOR", da, db)), B
+            assert torch.equal(be.bootstrap_lut(da, luts, first=3), old.bootstrap_lut(da, luts, first=3)), B
+            sample = np.unique(np.r_[0:min(B, 6), B - 1])
+            if fix == "full_default":
+                sample = sample[:3] if B > 1 else sample     # the oracle takes a third of a second per full-key gate
+            assert np.array_equal(got.cpu().numpy()[sample], ctx.bootstrap_batch(ca[sample], mu)), B
+        assert old.fft_fallbacks() == 0
+    assert be.fft_fallbacks() == 0
+
+
 def test_host_calls_are_certified_without_fallbacks(be_toy_default, toy_default, arith_mode):
     """Every FFT-mode call records its rounding certificate and folds it into the stream's running maximum
     (include/redsec_hip.h RS_CERTIFICATE_LIMIT); no call needs the exact recomputation."""
