@@ -1817,9 +1817,12 @@ __global__ __launch_bounds__(512) void blind_rotate_coop8_listed_kernel(BlindRot
     const uint32_t entry_next = s_steps[k + 1];   // requested a whole step ahead (the entry behind the last one exists: 0)
     // the prepared rotated difference of both components, 4 coefficients per thread (waves 0-3: component 0, waves 4-7: 1)
     {
-      const int c = coop8_diff_comp(wave), j0 = (int)(threadIdx.x & 255);
+      const int c = coop8_diff_comp(wave);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) s_d[c][j0 + 256 * m] = gadget_prepare<C>(rotated_diff(s_acc[c], j0 + 256 * m, bara));
+      for (int m = 0; m < kCoop8DiffPerThread; ++m) {
+        const int j = coop8_diff_coeff((int)threadIdx.x, m);
+        s_d[c][j] = gadget_prepare<C>(rotated_diff(s_acc[c], j, bara));
+      }
     }
     RS_C8L_STAMP(0);
     __syncthreads();   // s_d complete; the accumulator is not read again before its update

@@ -1048,6 +1048,21 @@ long rs_emu_coop8_row_split_violations(int L) {
   return bad;
 }
 
+// coop8, listed step: the 512 threads' shares of the shared rotated difference (rs_lds_plan.h: coop8_diff_comp / coop8_diff_coeff)
+// cover every coefficient of both components exactly once, and a wave writes only inside its component
+long rs_emu_coop8_diff_cover_violations() {
+  long bad = 0;
+  std::vector<int> hits(2 * kN, 0);
+  for (int t = 0; t < 64 * rs::kCoop8Waves; ++t)
+    for (int m = 0; m < rs::kCoop8DiffPerThread; ++m) {
+      const int c = rs::coop8_diff_comp(t >> 6), j = rs::coop8_diff_coeff(t, m);
+      if (c < 0 || c > 1 || j < 0 || j >= kN) { ++bad; continue; }
+      ++hits[c * kN + j];
+    }
+  for (int v : hits) bad += v != 1;
+  return bad;
+}
+
 // keyswitch with combined digits: for the word `aibar` and a (t, basebit, D) shape, the number of (group, k) positions whose
 // digit, recovered from the group's row index, differs from the digit the per-digit kernel extracts (must be 0), plus groups whose
 // row index leaves the table

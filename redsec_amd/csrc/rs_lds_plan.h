@@ -28,6 +28,8 @@ constexpr int kCoop8Waves = 8;
 // (waves 0-3: component 0, waves 4-7: component 1), whichever row the wave then transforms.
 constexpr int kCoop8MaxSteps = 2048;
 RS_HD constexpr int coop8_diff_comp(int wave) { return wave >> 2; }
+RS_HD constexpr int coop8_diff_coeff(int thread, int m) { return (thread & 255) + 256 * m; }   // m < kCoop8DiffPerThread
+constexpr int kCoop8DiffPerThread = 4;
 // l >= 4 (the REDsec set: l = 10): the deal by wave age described above. l < 4 (default-128: l = 3, six rows for eight waves)
 // keeps the deal of the kernel's first form -- waves 0-3 component 0, waves 4-7 component 1, the extra rows to the first waves of
 // component 0 and the last of component 1, inverse transforms on the two waves without rows (3 and 4): measured 2.66 ms against

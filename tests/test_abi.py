@@ -101,6 +101,27 @@ def test_header_is_plain_c99_and_a_c_program_links(tmp_path):
         assert "refused: " in r.stdout and "no HIP device" in r.stdout, r.stdout
 
 
+def test_kernel_form_names_of_the_binding_follow_the_library_enum():
+    """rs_last_launch reports a form id (csrc/rs_kernels.h kForm*); backend.Backend.last_launch names it. A form added on one side only
+    would index past the list or mislabel a launch."""
+    import re
+    text = open(os.path.join(ROOT, "redsec_amd", "csrc", "rs_kernels.h")).read()
+    enum = re.search(r"enum \{ (kFormPerWave = 0[^}]*)\}", text).group(1)
+    ids = {name: int(v) for name, v in re.findall(r"(kForm\w+) = (\d+)", enum)}
+    assert sorted(ids.values()) == list(range(len(ids)))
+    src = open(os.path.join(ROOT, "redsec_amd", "backend.py")).read()
+    names = re.search(r'return \{"form": \[([^\]]*)\]\[f\.value\]', src).group(1)
+    names = [n.strip().strip('"') for n in names.split(",")]
+    assert len(names) == len(ids)
+    norm = lambda s: s.replace("_", "").lower()
+    for name, v in ids.items():
+        assert norm(name[len("kForm"):]) == norm(names[v]), (name, v, names[v])
+    header = open(os.path.join(ROOT, "include", "redsec_hip.h")).read()
+    doc = header[header.index("rs_last_launch: what the last blind rotation"):header.index("int rs_last_launch(")]
+    for v in ids.values():
+        assert re.search(r"\b%d\b" % v, doc), "form id %d is not described in include/redsec_hip.h" % v
+
+
 def test_kernel_sources_carry_no_experiment_switches():
     """Round 5 deleted the ~70 compile-time experiment switches of rounds 1-4 (RS_T_*, RS_WG_*, RS_GEN_* ...: each measured, none adopted,
     verdicts in MEASUREMENTS.md) together with their code paths. What may still select code in csrc/: RS_BS_PART (which launchers an

@@ -279,6 +279,12 @@ def test_lds_protocols_of_the_n1024_forms_have_no_cross_wave_conflict(form):
         assert L.rs_emu_lds_protocol_conflicts(form, broken) > 0, (LDS_FORMS[form], broken)
 
 
+def test_coop8_listed_step_shares_of_the_rotated_difference_cover_every_coefficient_once():
+    L = emu_lib.lib()
+    L.rs_emu_coop8_diff_cover_violations.restype = ctypes.c_long
+    assert L.rs_emu_coop8_diff_cover_violations() == 0
+
+
 def test_coop8_row_split_covers_every_row_once_and_balances_the_simds():
     L = emu_lib.lib()
     L.rs_emu_coop8_row_split_violations.restype = ctypes.c_long
