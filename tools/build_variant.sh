@@ -8,6 +8,7 @@ ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 NAME="$1"; SRC="${2:-$ROOT}"; shift; shift || true
 BS_FLAGS="${BS_FLAGS:--mllvm -enable-post-misched=0}"   # rs_bootstrap.hip part 1 only (FFT / NTT kernels, split duo form)
 BS2_FLAGS="${BS2_FLAGS:--mllvm -amdgpu-sched-strategy=max-memory-clause}"                               # rs_bootstrap.hip part 2 only (split cooperative / lock-step kernels)
+BS4_FLAGS="${BS4_FLAGS:-$BS_FLAGS}"                      # rs_bootstrap.hip part 4 only (coop8 with the listed step): part 1's flags by default
 K_FLAGS="${K_FLAGS:-}"                                   # rs_kernels.hip only (A/B)
 GEN_FLAGS="${GEN_FLAGS:-}"                               # rs_general.hip only (A/B)
 mkdir -p "$ROOT/variants"
@@ -19,7 +20,7 @@ B="$SRC/redsec_amd/csrc"
 if grep -q RS_BS_PART "$B/rs_bootstrap.hip"; then
   cc -DRS_BS_PART=1 $BS_FLAGS "$@" -c "$B/rs_bootstrap.hip" -o "$OBJ/rs_bootstrap_1.o"
   cc -DRS_BS_PART=2 $BS2_FLAGS "$@" -c "$B/rs_bootstrap.hip" -o "$OBJ/rs_bootstrap_2.o"
-  if grep -q "RS_BS_PART & 4" "$B/rs_bootstrap.hip"; then cc -DRS_BS_PART=4 $BS_FLAGS "$@" -c "$B/rs_bootstrap.hip" -o "$OBJ/rs_bootstrap_4.o"; fi
+  if grep -q "RS_BS_PART & 4" "$B/rs_bootstrap.hip"; then cc -DRS_BS_PART=4 $BS4_FLAGS "$@" -c "$B/rs_bootstrap.hip" -o "$OBJ/rs_bootstrap_4.o"; fi
 else   # an older source tree: one object
   cc $BS_FLAGS "$@" -c "$B/rs_bootstrap.hip" -o "$OBJ/rs_bootstrap.o"
 fi
